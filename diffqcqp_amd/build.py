@@ -1,0 +1,76 @@
+"""Builds libdiffqcqp_hip.so (the C-ABI library of include/diffqcqp_hip.h) for gfx950.
+
+hipcc cross-compiles without a GPU.  Every translation unit is compiled for
+gfx950 only; the forward fast path allows FMA contraction, everything that has
+to reproduce the reference's operation order (backward, dense path) is built
+with -ffp-contract=off.  Output: diffqcqp_amd/lib/libdiffqcqp_hip.so (in-tree,
+git-ignored, shipped to the GPU box with the snapshot).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIBDIR = os.path.join(_HERE, "lib")
+LIB = os.path.join(LIBDIR, "libdiffqcqp_hip.so")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-fvisibility=hidden",
+          "-Wall", "-Wno-unused-function"]
+# translation unit -> extra flags
+UNITS = {
+    "fwd_diag.hip": ["-ffp-contract=fast"],
+    "bwd_diag.hip": ["-ffp-contract=off"],
+    "dense.hip": ["-ffp-contract=off"],
+    "capi.hip": ["-ffp-contract=off", "-fvisibility=default"],
+}
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _sources():
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "diffqcqp_hip.h")]
+    return deps
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in _sources() + [os.path.abspath(__file__)])
+
+
+def _compile(unit, flags, objdir, verbose):
+    obj = os.path.join(objdir, unit.replace(".hip", ".o"))
+    cmd = [_hipcc()] + COMMON + flags + ["-I", INCLUDE, "-c", os.path.join(CSRC, unit), "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return obj
+
+
+def build(force=False, verbose=False):
+    """Compile and link; returns the library path."""
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(lambda kv: _compile(kv[0], kv[1], objdir, verbose), UNITS.items()))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,173 @@
+// admm_core.h -- per-problem ADMM forward solve for a DIAGONAL P.
+//
+// Restates Solver::solveQP (reference qcqplib/Solver.cpp:61-123) and
+// Solver::solveQCQP (Solver.cpp:521-582, prox_circle :505-519, radius product
+// pybindings.cpp:57) for the case where P -- and therefore P + (rho+mu) I and
+// its inverse -- is diagonal, so the Cholesky factorisation + explicit inverse
+// the reference performs at every rho update (Solver.cpp:76-77, 100-101,
+// 114-115) collapses to E reciprocals.  Same update order, same constants,
+// same rho / tau / cpt state machine, same stopping tests; the shifted diagonal
+// M is ACCUMULATED (M += rho*(tau-1)), not recomputed, as the reference does.
+//
+// A problem of dimension n is held by a group G of LPP lanes, E = n/LPP
+// consecutive coordinates per lane (E even, so a QCQP contact pair never
+// straddles two lanes).  All lanes of a group hold bit-identical copies of the
+// scalar state (rho, tau, cpt, ...) because G's reductions are symmetric.
+//
+// Deliberate ulp-level departures from the dense reference arithmetic (all far
+// inside the 1e-6 parity tolerance; the trajectory -- rho schedule, iteration
+// count -- is unchanged, tests/ check that): 1/M instead of (1/sqrt(M))/sqrt(M);
+// u*(1/rho) instead of u/rho; power-iteration normalisation by a reciprocal;
+// compiler FMA contraction; group (tree) sums when LPP > 1.
+#pragma once
+
+#include "common.h"
+
+namespace dqq {
+
+// KIND 0 = QP (x >= 0), 1 = QCQP (per-contact disk of radius rad[c]).
+// p, q: this lane's E coordinates; rad: this lane's E/2 radii (KIND 1).
+// valid = false: the lane only keeps the wave's control flow company.
+// Returns the number of ADMM iterations executed (Solver.cpp:79 / :538 loop).
+template <int KIND, int E, class G>
+DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const double* rad, int n, double eps,
+                         double mu, int max_iter, int adaptive, bool valid, double (&x)[E])
+{
+    static_assert(E % 2 == 0, "E must be even");
+    double v[E], M[E], Minv[E], qp[E], l2[E], u[E];
+
+    // ---- power_iteration, Solver.cpp:46-59 (10 steps for QP :71, 100 for QCQP :530)
+    const int pi_steps = (KIND == 0) ? 10 : 100;
+    {
+        const double c = 1.0 / sqrt((double)n);
+        double s = 0.0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) { v[e] = c; s += c * c; }
+        s = G::sum(s);
+        if (s > 0) {
+            const double nn = sqrt(s);
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = v[e] / nn;
+        }
+    }
+    for (int k = 0; k < pi_steps; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) { v[e] = p[e] * v[e]; s += v[e] * v[e]; }
+        s = G::sum(s);
+        if (s > 0) {
+            const double inv = 1.0 / sqrt(s);
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = v[e] * inv;
+        }
+    }
+    double L = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) L += v[e] * (p[e] * v[e]);
+    L = G::sum(L);
+
+    // ---- Solver.cpp:72-77 / 531-536
+    double rho = sqrt(mu * L) * pow(L / mu, .4);
+    double tau_inc = pow(L / mu, .15), tau_dec = tau_inc;
+    double inv_rho = 1.0 / rho;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        M[e] = p[e] + (rho + mu);
+        Minv[e] = 1.0 / M[e];
+        qp[e] = q[e];
+        l2[e] = 0.0;
+        u[e] = 0.0;
+    }
+
+    int rho_up = 0, cpt = 0, iters = 0;
+    bool done = !valid;
+    for (int it = 0; it < max_iter; ++it) {
+        if (!done) {
+            double rd = 0.0, rp = 0.0, nl = 0.0;
+            double w[E], z[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const double l = Minv[e] * (rho * l2[e] - u[e] - qp[e]);      // :80 / :539
+                qp[e] = q[e] - mu * l;                                        // :81 / :540
+                w[e] = kAlpha * l + (1 - kAlpha) * l2[e];                     // alpha*l + (1-alpha)*l2_pred
+                z[e] = w[e] + u[e] * inv_rho;                                 // :82 / :541
+                if (KIND == 1) nl += l * l;
+            }
+            if (KIND == 0) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) z[e] = z[e] < 0 ? 0 : z[e];       // cwiseMax(0), :82
+            } else {
+#pragma unroll
+                for (int c = 0; c < E / 2; ++c) {                             // prox_circle, :505-519
+                    const double a = z[2 * c], b = z[2 * c + 1];
+                    const double nrm = sqrt(a * a + b * b);
+                    if (nrm > rad[c]) {
+                        z[2 * c] = a * rad[c] / nrm;
+                        z[2 * c + 1] = b * rad[c] / nrm;
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                u[e] += rho * (w[e] - z[e]);                                  // :83 / :543
+                rd = fmax(rd, fabs(z[e] - l2[e]));                            // :84-85 / :544-545
+                rp = fmax(rp, fabs(z[e] - w[e]));                             // :86 / :546
+                l2[e] = z[e];                                                 // :87 / :547
+            }
+            rd = G::max(rd);
+            rp = G::max(rp);
+            const double res_dual = rho * rd;   // max|rho*d| == rho*max|d| for rho > 0
+            const double res_prim = rp;
+            iters = it + 1;
+            bool stop = res_dual < eps;                                       // :88
+            if (KIND == 1) {
+                if (stop) stop = res_prim < eps + kEpsRel * sqrt(G::sum(nl)); // :548
+            }
+            if (stop) {
+                done = true;
+            } else if (adaptive) {
+                bool upd = false;
+                double delta = 0.0;
+                if (res_prim > kMuThresh * res_dual) {                        // :92 / :552
+                    if (cpt % 5 == 0) {
+                        if (rho_up == -1) {
+                            tau_inc = 1 + .8 * (tau_inc - 1);
+                            if (KIND == 0) tau_dec = 1 + .8 * (tau_dec - 1);  // :94-97 (QP damps both)
+                        }
+                        delta = rho * (tau_inc - 1);                          // :98 / :557
+                        rho *= tau_inc;
+                        rho_up = 1;
+                        upd = true;
+                    }
+                    cpt++;
+                } else if (res_dual > kMuThresh * res_prim) {                 // :106 / :566
+                    if (cpt % 5 == 0) {
+                        if (rho_up == 1) {
+                            if (KIND == 0) tau_inc = 1 + .8 * (tau_inc - 1);  // :108-111 (QP damps both)
+                            tau_dec = 1 + .8 * (tau_dec - 1);
+                        }
+                        delta = rho * (1. / tau_dec - 1);                     // :112 / :571
+                        rho /= tau_dec;
+                        rho_up = -1;
+                        upd = true;
+                    }
+                    cpt++;
+                }
+                if (upd) {   // the reference's llt() + solveInPlace(Identity), diagonal case
+                    inv_rho = 1.0 / rho;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        M[e] += delta;
+                        Minv[e] = 1.0 / M[e];
+                    }
+                }
+            }
+        }
+        if (G::wave_all(done)) break;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) x[e] = l2[e];
+    return iters;
+}
+
+} // namespace dqq

@@ -1,0 +1,222 @@
+// bwd_diag.hip -- batched implicit-function backward, diagonal-P fast path.
+//
+// One launch replaces the Python batch loop + torch.bmm gradient assembly of
+// the reference (QPFn2.backward qcqp.py:36-52, QCQPFn2.backward qcqp.py:156-181).
+// It is a streaming kernel: per problem it reads P (N^2), q, x, grad_x (and
+// l_n, mu) once and writes grad_P (N^2), grad_q (and grad_l_n, grad_mu) once.
+//
+// A wave64 owns a tile of T = 128/N consecutive problems; lane = (problem,
+// coordinate pair / contact), i.e. N/2 lanes per problem, so q, x, grad_x,
+// grad_q are read/written as one fully coalesced 1 KiB double2 access per wave
+// and each QCQP contact (3x3 KKT block, kkt_core.h) lives in one lane.
+//   phase A  stream the tile of P (N coalesced 1 KiB loads per wave), verify the
+//            off-diagonals are exactly +-0, park the diagonal in LDS;
+//   phase B  per-lane KKT blocks + the refinement loop of Solver.cpp:15-44; the
+//            problem-wide residual norm is summed from LDS in the reference's
+//            entry order, so the loop exit is bit-identical to a dense solve;
+//   phase C  stream grad_P = -dl x^T back with the access pattern of phase A
+//            (dl and x are picked out of LDS).
+// Tiles with a non-zero off-diagonal are queued for the general dense kernel.
+//
+// Compile with -ffp-contract=off (see kkt_core.h).
+#include "kkt_core.h"
+#include "launch.h"
+
+namespace dqq {
+
+template <int KIND, int N, int WPB>
+__global__ __launch_bounds__(64 * WPB) void bwd_diag_kernel(
+    const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ l_n,
+    const double* __restrict__ mu_c, const double* __restrict__ x, const double* __restrict__ grad_x,
+    double* __restrict__ grad_P, double* __restrict__ grad_q, double* __restrict__ grad_l_n,
+    double* __restrict__ grad_mu, long B, int layout, int* __restrict__ ir_steps, int* __restrict__ ws)
+{
+    constexpr int HL = N / 2;          // lanes per problem
+    constexpr int T = 64 / HL;         // problems per wave tile (T*N == 128)
+    constexpr int NC = N / 2;          // contacts per problem
+    constexpr int RS = (KIND == 0) ? N : N + NC; // residual entries per problem
+    static_assert(N >= 2 && (N & (N - 1)) == 0 && N <= 128, "N must be a power of two");
+    __shared__ double s_pd[WPB][128], s_dl[WPB][128], s_x[WPB][128], s_rs[WPB][T * RS];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long tile = (long)blockIdx.x * WPB + wave;
+    const long first = tile * T;
+    if (first >= B) return; // whole wave leaves; no workgroup barrier is used below
+    const int nvalid = (B - first) < T ? (int)(B - first) : T;
+    const int pl = lane / HL, j = lane % HL;
+    const bool valid = pl < nvalid;
+    double *pd = s_pd[wave], *dlv = s_dl[wave], *xs = s_x[wave], *rs = s_rs[wave];
+    const int limit = nvalid * N * N;
+
+    // ---------------- phase A: P -> diagonal (LDS), off-diagonal zero check
+    double2 pv;
+    if (layout == DQQ_P_DIAG) {
+        pv = valid ? *reinterpret_cast<const double2*>(P + first * N + 2 * lane) : make_double2(1.0, 1.0);
+    } else {
+        const double* Pw = P + first * (long)(N * N);
+        unsigned nz = 0;
+        constexpr int U = N < 8 ? N : 8;
+        for (int k0 = 0; k0 < N; k0 += U) {
+            double2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int f = (k0 + u) * 128 + 2 * lane;
+                v[u] = f < limit ? *reinterpret_cast<const double2*>(Pw + f) : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int f = (k0 + u) * 128 + 2 * lane;
+                const int row = f / N;           // == prob*N + r  (T*N == 128 rows in the tile)
+                const int r = row % N, c = f % N;
+                const unsigned b0 = nonzero_bits(v[u].x), b1 = nonzero_bits(v[u].y);
+                if (c == r) { pd[row] = v[u].x; nz |= b1; }
+                else if (c + 1 == r) { pd[row] = v[u].y; nz |= b0; }
+                else nz |= b0 | b1;
+            }
+        }
+        if (__any(nz != 0)) { // wave-uniform: hand the tile to the dense kernel
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&ws[kWsCount], nvalid);
+            base = __shfl(base, 0, 64);
+            if (lane < nvalid) ws[kWsEntries + base + lane] = (int)(first + lane);
+            return;
+        }
+        wave_lds_fence();
+        pv = valid ? *reinterpret_cast<const double2*>(pd + 2 * lane) : make_double2(1.0, 1.0);
+    }
+
+    // ---------------- phase B: per-lane KKT blocks + iterative refinement
+    const long co = first * N + 2 * lane;
+    const double2 zero2 = make_double2(0.0, 0.0);
+    const double2 qv = valid ? *reinterpret_cast<const double2*>(q + co) : zero2;
+    const double2 xv = valid ? *reinterpret_cast<const double2*>(x + co) : zero2;
+    const double2 gv = valid ? *reinterpret_cast<const double2*>(grad_x + co) : zero2;
+    double dl0, dl1;
+    int steps = 0;
+    IrControl ctl;
+    ctl.init();
+    bool done = !valid;
+
+    if (KIND == 0) {
+        QpCoord c0, c1;
+        c0.setup(pv.x, qv.x, xv.x, gv.x);
+        c1.setup(pv.y, qv.y, xv.y, gv.y);
+        for (int it = 0; it < kIrMaxIter; ++it) {
+            if (!done) {
+                rs[pl * RS + 2 * j] = c0.step();
+                rs[pl * RS + 2 * j + 1] = c1.step();
+            }
+            wave_lds_fence();
+            if (!done) {
+                double s = 0.0;
+                for (int i = 0; i < RS; ++i) s += rs[pl * RS + i]; // reference entry order
+                steps = it + 1;
+                if (ctl.update(sqrt(s))) done = true;
+            }
+            wave_lds_fence();
+            if (__all(done)) break;
+        }
+        dl0 = c0.dl();
+        dl1 = c1.dl();
+    } else {
+        const long cc = first * NC + lane;
+        const double ln = valid ? l_n[cc] : 1.0, mc = valid ? mu_c[cc] : 1.0;
+        QcqpContact ct;
+        ct.setup(pv.x, pv.y, qv.x, qv.y, xv.x, xv.y, gv.x, gv.y, ln, mc);
+        for (int it = 0; it < kIrMaxIter; ++it) {
+            if (!done) {
+                double dsq[3];
+                ct.step(dsq);
+                rs[pl * RS + j] = dsq[0];
+                rs[pl * RS + NC + 2 * j] = dsq[1];
+                rs[pl * RS + NC + 2 * j + 1] = dsq[2];
+            }
+            wave_lds_fence();
+            if (!done) {
+                double s = 0.0;
+                for (int i = 0; i < RS; ++i) s += rs[pl * RS + i]; // gamma entries, then l entries
+                steps = it + 1;
+                if (ctl.update(sqrt(s))) done = true;
+            }
+            wave_lds_fence();
+            if (__all(done)) break;
+        }
+        dl0 = ct.dla();
+        dl1 = ct.dlb();
+        if (valid) {
+            const double dg = ct.dgamma();
+            if (grad_l_n != nullptr) grad_l_n[cc] = QcqpContact::e2(ct.gamma, ln, mc) * dg; // qcqp.py:178
+            if (grad_mu != nullptr) grad_mu[cc] = QcqpContact::e1(ct.gamma, ln, mc) * dg;   // qcqp.py:180
+        }
+    }
+    if (valid) {
+        if (grad_q != nullptr) *reinterpret_cast<double2*>(grad_q + co) = make_double2(-dl0, -dl1); // qcqp.py:51/176
+        if (ir_steps != nullptr && j == 0) ir_steps[first + pl] = steps;
+    }
+    if (grad_P == nullptr) return;
+
+    // ---------------- phase C: grad_P = -dl x^T  (qcqp.py:49 / :174)
+    if (layout == DQQ_P_DIAG) {
+        if (valid) *reinterpret_cast<double2*>(grad_P + co) = make_double2(-(dl0 * xv.x), -(dl1 * xv.y));
+        return;
+    }
+    dlv[2 * lane] = dl0;
+    dlv[2 * lane + 1] = dl1;
+    xs[2 * lane] = xv.x;
+    xs[2 * lane + 1] = xv.y;
+    wave_lds_fence();
+    double* Gw = grad_P + first * (long)(N * N);
+#pragma unroll 4
+    for (int k = 0; k < N; ++k) {
+        const int f = k * 128 + 2 * lane;
+        if (f < limit) {
+            const int row = f / N, col = (row / N) * N + f % N;
+            const double d = dlv[row];
+            const double2 xx = *reinterpret_cast<const double2*>(xs + col);
+            *reinterpret_cast<double2*>(Gw + f) = make_double2(-(d * xx.x), -(d * xx.y));
+        }
+    }
+}
+
+template <int KIND, int N, int WPB>
+static hipError_t launch_one(const BwdArgs& a, hipStream_t s)
+{
+    constexpr int T = 128 / N;
+    const long ntiles = (a.B + T - 1) / T;
+    const long nblocks = (ntiles + WPB - 1) / WPB;
+    if (nblocks == 0) return hipSuccess;
+    hipLaunchKernelGGL((bwd_diag_kernel<KIND, N, WPB>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q, a.l_n,
+                       a.mu, a.x, a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.B, a.layout, a.ir_steps, a.ws);
+    return hipGetLastError();
+}
+
+template <int KIND, int N>
+static hipError_t launch_wpb(const BwdArgs& a, int wpb, hipStream_t s)
+{
+    if (wpb == 1) return launch_one<KIND, N, 1>(a, s);
+    return launch_one<KIND, N, 4>(a, s);
+}
+
+bool bwd_diag_supported(int N) { return N == 2 || N == 4 || N == 8 || N == 16 || N == 32 || N == 64; }
+
+template <int KIND>
+static hipError_t launch_kind(const BwdArgs& a, int wpb, hipStream_t s)
+{
+    switch (a.N) {
+    case 2: return launch_wpb<KIND, 2>(a, wpb, s);
+    case 4: return launch_wpb<KIND, 4>(a, wpb, s);
+    case 8: return launch_wpb<KIND, 8>(a, wpb, s);
+    case 16: return launch_wpb<KIND, 16>(a, wpb, s);
+    case 32: return launch_wpb<KIND, 32>(a, wpb, s);
+    case 64: return launch_wpb<KIND, 64>(a, wpb, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_bwd_diag(int kind, const BwdArgs& a, int wpb, hipStream_t s)
+{
+    if (wpb != 1 && wpb != 4) wpb = 4;
+    return kind == 0 ? launch_kind<0>(a, wpb, s) : launch_kind<1>(a, wpb, s);
+}
+
+} // namespace dqq

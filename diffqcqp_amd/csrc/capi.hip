@@ -1,0 +1,162 @@
+// capi.hip -- the extern "C" boundary declared in include/diffqcqp_hip.h:
+// argument checks, path selection (diagonal fast path / general dense kernel /
+// both, chained through the fallback work-list), launches on the caller's stream.
+#include <atomic>
+#include <cstring>
+
+#include "launch.h"
+
+namespace {
+
+std::atomic<int> g_fwd_lpp{0};      // 0 = built-in choice
+std::atomic<int> g_wpb{0};          // 0 = built-in choice
+std::atomic<int> g_auto_fallback{1}; // 0 = skip the dense fallback launch of DQQ_P_AUTO (measurement only)
+
+struct Option {
+    const char* name;
+    std::atomic<int>* slot;
+};
+Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback", &g_auto_fallback}};
+
+int check_common(int64_t B, int N, int p_layout, bool qcqp)
+{
+    if (B < 0 || N < 1 || B > 0x7fffffffLL) return DQQ_E_BAD_SIZE;
+    if (qcqp && (N % 2) != 0) return DQQ_E_BAD_SIZE;
+    if (p_layout != DQQ_P_AUTO && p_layout != DQQ_P_DENSE && p_layout != DQQ_P_DIAG) return DQQ_E_BAD_LAYOUT;
+    return 0;
+}
+
+int check_ws(const void* ws, size_t bytes, int64_t B)
+{
+    if (ws == nullptr || bytes < dqq_workspace_bytes(B)) return DQQ_E_WORKSPACE;
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+size_t dqq_workspace_bytes(int64_t B)
+{
+    if (B < 0) B = 0;
+    size_t n = (size_t)dqq::kWsEntries + (size_t)B;
+    n = (n + 63) & ~(size_t)63;
+    return n * sizeof(int);
+}
+
+int dqq_max_n(int kind) { return dqq::dense_max_n(kind); }
+
+const char* dqq_version(void) { return "diffqcqp_hip 0.1.0 gfx950"; }
+
+int dqq_set_option(const char* name, int value)
+{
+    if (name == nullptr) return DQQ_E_NULLPTR;
+    for (auto& o : g_options)
+        if (std::strcmp(o.name, name) == 0) { o.slot->store(value); return 0; }
+    return DQQ_E_BAD_OPTION;
+}
+
+int dqq_get_option(const char* name, int* value)
+{
+    if (name == nullptr || value == nullptr) return DQQ_E_NULLPTR;
+    for (auto& o : g_options)
+        if (std::strcmp(o.name, name) == 0) { *value = o.slot->load(); return 0; }
+    return DQQ_E_BAD_OPTION;
+}
+
+static int fwd_dispatch(int kind, dqq::FwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t s)
+{
+    if (a.B == 0) return 0;
+    const bool fast_ok = dqq::fwd_diag_supported(a.N);
+    const bool dense_ok = a.N <= dqq::dense_max_n(kind);
+    hipError_t e;
+    if (a.layout == DQQ_P_DIAG) {
+        if (!fast_ok) return DQQ_E_UNSUPPORTED_N;
+        e = dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), s);
+        return (int)e;
+    }
+    if (a.layout == DQQ_P_DENSE || !fast_ok) {
+        if (!dense_ok) return DQQ_E_UNSUPPORTED_N;
+        e = dqq::launch_fwd_dense(kind, a, false, s);
+        return (int)e;
+    }
+    // DQQ_P_AUTO: fast path over every tile, dense kernel over the tiles it queued
+    if (int rc = check_ws(workspace, workspace_bytes, a.B)) return rc;
+    a.ws = static_cast<int*>(workspace);
+    e = dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), s);
+    if (e != hipSuccess) return (int)e;
+    if (dense_ok && g_auto_fallback.load() != 0) e = dqq::launch_fwd_dense(kind, a, true, s);
+    return (int)e;
+}
+
+static int bwd_dispatch(int kind, dqq::BwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t s)
+{
+    if (a.B == 0) return 0;
+    const bool fast_ok = dqq::bwd_diag_supported(a.N);
+    const bool dense_ok = a.N <= dqq::dense_max_n(kind == 0 ? 0 : 2);
+    hipError_t e;
+    if (a.layout == DQQ_P_DIAG) {
+        if (!fast_ok) return DQQ_E_UNSUPPORTED_N;
+        return (int)dqq::launch_bwd_diag(kind, a, g_wpb.load(), s);
+    }
+    if (a.layout == DQQ_P_DENSE || !fast_ok) {
+        if (!dense_ok) return DQQ_E_UNSUPPORTED_N;
+        return (int)dqq::launch_bwd_dense(kind, a, false, s);
+    }
+    if (int rc = check_ws(workspace, workspace_bytes, a.B)) return rc;
+    a.ws = static_cast<int*>(workspace);
+    e = dqq::launch_bwd_diag(kind, a, g_wpb.load(), s);
+    if (e != hipSuccess) return (int)e;
+    if (dense_ok && g_auto_fallback.load() != 0) e = dqq::launch_bwd_dense(kind, a, true, s);
+    return (int)e;
+}
+
+int dqq_qp_fwd_f64(const double* P, const double* q, double* x, int64_t B, int N, double eps, double mu_prox,
+                   int max_iter, int adaptive_rho, int p_layout, int* iters, void* workspace,
+                   size_t workspace_bytes, void* stream)
+{
+    if (int rc = check_common(B, N, p_layout, false)) return rc;
+    if (B > 0 && (P == nullptr || q == nullptr || x == nullptr)) return DQQ_E_NULLPTR;
+    dqq::FwdArgs a{P, q, nullptr, nullptr, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0,
+                   p_layout, iters, nullptr};
+    return fwd_dispatch(0, a, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int dqq_qcqp_fwd_f64(const double* P, const double* q, const double* l_n, const double* mu, double* x, int64_t B,
+                     int N, double eps, double mu_prox, int max_iter, int adaptive_rho, int p_layout, int* iters,
+                     void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (int rc = check_common(B, N, p_layout, true)) return rc;
+    if (B > 0 && (P == nullptr || q == nullptr || l_n == nullptr || mu == nullptr || x == nullptr))
+        return DQQ_E_NULLPTR;
+    dqq::FwdArgs a{P, q, l_n, mu, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0, p_layout, iters,
+                   nullptr};
+    return fwd_dispatch(1, a, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int dqq_qp_bwd_f64(const double* P, const double* q, const double* x, const double* grad_x, double* grad_P,
+                   double* grad_q, int64_t B, int N, int p_layout, int* ir_steps, void* workspace,
+                   size_t workspace_bytes, void* stream)
+{
+    if (int rc = check_common(B, N, p_layout, false)) return rc;
+    if (B > 0 && (P == nullptr || q == nullptr || x == nullptr || grad_x == nullptr)) return DQQ_E_NULLPTR;
+    dqq::BwdArgs a{P, q, nullptr, nullptr, x, grad_x, grad_P, grad_q, nullptr, nullptr, (long)B, N, p_layout,
+                   ir_steps, nullptr};
+    return bwd_dispatch(0, a, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int dqq_qcqp_bwd_f64(const double* P, const double* q, const double* l_n, const double* mu, const double* x,
+                     const double* grad_x, double* grad_P, double* grad_q, double* grad_l_n, double* grad_mu,
+                     int64_t B, int N, int p_layout, int* ir_steps, void* workspace, size_t workspace_bytes,
+                     void* stream)
+{
+    if (int rc = check_common(B, N, p_layout, true)) return rc;
+    if (B > 0 && (P == nullptr || q == nullptr || l_n == nullptr || mu == nullptr || x == nullptr ||
+                  grad_x == nullptr))
+        return DQQ_E_NULLPTR;
+    dqq::BwdArgs a{P, q, l_n, mu, x, grad_x, grad_P, grad_q, grad_l_n, grad_mu, (long)B, N, p_layout, ir_steps,
+                   nullptr};
+    return bwd_dispatch(1, a, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+} // extern "C"

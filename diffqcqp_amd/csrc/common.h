@@ -1,0 +1,119 @@
+// common.h -- shared definitions for the gfx950 kernels of libdiffqcqp_hip.so.
+//
+// The per-problem arithmetic lives in host/device templates (admm_core.h,
+// kkt_core.h) parameterised by a "group" type that supplies the cross-lane
+// reductions.  On the device a group is LPP adjacent lanes of one wave64 that
+// share a problem; tests/host_core_check.cpp instantiates the same templates
+// with HostGroup (one lane per problem) to check them against the oracle on a
+// machine without a GPU.  That host build is a test artefact: the C ABI never
+// calls it.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define DQQ_HD __host__ __device__ __forceinline__
+#define DQQ_D __device__ __forceinline__
+#else
+#define DQQ_HD inline
+#endif
+
+namespace dqq {
+
+// ADMM constants of the reference (Solver.cpp:64, 523-524)
+constexpr double kMuThresh = 10.0;
+constexpr double kAlpha = 1.5;
+constexpr double kEpsRel = 1e-4;
+// backward constants (Solver.cpp:15 defaults, :140, :639; pybindings.cpp:24,62)
+constexpr double kMuIr = 1e-7;
+constexpr double kIrEps = 1e-10;
+constexpr int kIrMaxIter = 10;
+constexpr double kActiveEps = 1e-10;
+
+// One lane owns the whole problem: reductions are the identity.
+struct HostGroup {
+    static DQQ_HD double sum(double v) { return v; }
+    static DQQ_HD double max(double v) { return v; }
+    static DQQ_HD bool wave_all(bool b) { return b; }
+};
+
+#if defined(__HIPCC__)
+
+constexpr int kWave = 64;
+
+// DPP controls (GFX9 encoding)
+constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;        // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141; // row_half_mirror: lane i <-> 7-i within 8
+constexpr int kDppRor8 = 0x128;       // row_ror:8: lane i <-> i^8 within 16
+
+template <int CTRL>
+DQQ_D double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Value held by the lane whose index differs in bit log2(STEP), valid when the
+// value is already uniform over aligned groups of STEP lanes (which is what an
+// all-reduce butterfly guarantees).  Pairings are symmetric, so both partners of
+// a pair compute bit-identical results for commutative ops: all lanes of a
+// problem take identical branches.
+template <int STEP>
+DQQ_D double partner(double v)
+{
+    if constexpr (STEP == 1) return dpp_f64<kDppXor1>(v);
+    else if constexpr (STEP == 2) return dpp_f64<kDppXor2>(v);
+    else if constexpr (STEP == 4) return dpp_f64<kDppHalfMirror>(v);
+    else if constexpr (STEP == 8) return dpp_f64<kDppRor8>(v);
+    else return __shfl_xor(v, STEP, 64);
+}
+
+// LPP adjacent lanes (LPP a power of two, aligned) share one problem.
+template <int LPP>
+struct LaneGroup {
+    static DQQ_D double sum(double v)
+    {
+        if constexpr (LPP >= 2) v = v + partner<1>(v);
+        if constexpr (LPP >= 4) v = v + partner<2>(v);
+        if constexpr (LPP >= 8) v = v + partner<4>(v);
+        if constexpr (LPP >= 16) v = v + partner<8>(v);
+        if constexpr (LPP >= 32) v = v + partner<16>(v);
+        if constexpr (LPP >= 64) v = v + partner<32>(v);
+        return v;
+    }
+    static DQQ_D double max(double v)
+    {
+        if constexpr (LPP >= 2) v = fmax(v, partner<1>(v));
+        if constexpr (LPP >= 4) v = fmax(v, partner<2>(v));
+        if constexpr (LPP >= 8) v = fmax(v, partner<4>(v));
+        if constexpr (LPP >= 16) v = fmax(v, partner<8>(v));
+        if constexpr (LPP >= 32) v = fmax(v, partner<16>(v));
+        if constexpr (LPP >= 64) v = fmax(v, partner<32>(v));
+        return v;
+    }
+    static DQQ_D bool wave_all(bool b) { return __all(b); }
+};
+
+// LDS traffic between lanes of ONE wave: program order is enough in hardware
+// (a wave's DS operations execute in order); this only stops the compiler from
+// moving accesses across the hand-off.
+DQQ_D void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// true when the double is neither +0.0 nor -0.0 (NaN counts as non-zero)
+DQQ_D unsigned nonzero_bits(double v)
+{
+    return (unsigned)__double2loint(v) | ((unsigned)__double2hiint(v) & 0x7fffffffu);
+}
+
+#endif // __HIPCC__
+
+} // namespace dqq

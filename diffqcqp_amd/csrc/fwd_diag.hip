@@ -1,0 +1,183 @@
+// fwd_diag.hip -- batched ADMM forward solve, diagonal-P fast path (gfx950).
+//
+// One launch replaces the Python batch loop of the reference (qcqp.py:29-31 for
+// QPFn2.forward, :149-151 for QCQPFn2.forward).  A wave64 owns a TILE of
+// PPW = 64/LPP consecutive problems; LPP adjacent lanes share a problem and
+// each lane keeps E = N/LPP coordinates of every state vector in VGPRs for the
+// whole solve (admm_core.h).  Nothing but P, q, (l_n, mu) is read from HBM and
+// nothing but x (and the optional iteration counts) is written.
+//
+// P arrives in the drop-in layout (B,N,N).  The wave streams its tile of P with
+// fully coalesced 16-byte loads (1 KiB per wave instruction), checks on the fly
+// that every off-diagonal entry is exactly +-0, and drops the diagonal entries
+// into LDS in [problem][coordinate] order, from where each lane picks up its E
+// values.  A tile with any non-zero off-diagonal is NOT solved here: its
+// problem indices are appended to the fallback work-list that the general
+// dense kernel (dense.hip) drains right after this launch.
+#include "admm_core.h"
+#include "launch.h"
+
+namespace dqq {
+
+template <int KIND, int N, int LPP, int WPB>
+__global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __restrict__ P,
+                                                            const double* __restrict__ q,
+                                                            const double* __restrict__ l_n,
+                                                            const double* __restrict__ mu_c, double* __restrict__ x,
+                                                            long B, double eps, double mu_prox, int max_iter,
+                                                            int adaptive, int layout, int* __restrict__ iters,
+                                                            int* __restrict__ ws)
+{
+    constexpr int E = N / LPP;       // coordinates per lane
+    constexpr int PPW = 64 / LPP;    // problems per wave tile
+    constexpr int NCH = N * E / 2;   // 16-byte-per-lane chunks in a tile of P
+    static_assert(E >= 2 && E % 2 == 0 && E * LPP == N, "bad N/LPP");
+    __shared__ double s_diag[WPB][64 * E];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long tile = (long)blockIdx.x * WPB + wave;
+    const long first = tile * PPW;
+    if (first >= B) return; // whole wave leaves; no workgroup barrier is used below
+    const int nvalid = (B - first) < PPW ? (int)(B - first) : PPW;
+    const int pl = lane / LPP;
+    const bool valid = pl < nvalid;
+
+    double p[E], qv[E], xv[E], rad[E / 2];
+
+    if (layout == DQQ_P_DIAG) {
+        const double* pp = P + first * N + lane * E;
+#pragma unroll
+        for (int e = 0; e < E; e += 2) {
+            double2 t = valid ? *reinterpret_cast<const double2*>(pp + e) : make_double2(1.0, 1.0);
+            p[e] = t.x; p[e + 1] = t.y;
+        }
+    } else {
+        const double* Pw = P + first * (long)(N * N);
+        const int limit = nvalid * N * N; // doubles of P that belong to this tile
+        double* sd = s_diag[wave];
+        unsigned nz = 0;
+        constexpr int U = NCH < 8 ? NCH : 8;
+        for (int k0 = 0; k0 < NCH; k0 += U) {
+            double2 v[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int f = (k0 + j) * 128 + 2 * lane;
+                v[j] = f < limit ? *reinterpret_cast<const double2*>(Pw + f) : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int f = (k0 + j) * 128 + 2 * lane;
+                const int prob = f / (N * N), rem = f % (N * N);
+                const int r = rem / N, c = rem % N; // c is even; (r,c) and (r,c+1) are this lane's entries
+                const unsigned b0 = nonzero_bits(v[j].x), b1 = nonzero_bits(v[j].y);
+                if (c == r) { sd[prob * N + r] = v[j].x; nz |= b1; }
+                else if (c + 1 == r) { sd[prob * N + r] = v[j].y; nz |= b0; }
+                else nz |= b0 | b1;
+            }
+        }
+        if (__any(nz != 0)) { // wave-uniform: hand the tile to the dense kernel
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&ws[kWsCount], nvalid);
+            base = __shfl(base, 0, 64);
+            if (lane < nvalid) ws[kWsEntries + base + lane] = (int)(first + lane);
+            return;
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int e = 0; e < E; ++e) p[e] = valid ? sd[lane * E + e] : 1.0;
+    }
+
+    {
+        const double* qq = q + first * N + lane * E;
+#pragma unroll
+        for (int e = 0; e < E; e += 2) {
+            double2 t = valid ? *reinterpret_cast<const double2*>(qq + e) : make_double2(0.0, 0.0);
+            qv[e] = t.x; qv[e + 1] = t.y;
+        }
+    }
+    if (KIND == 1) {
+        const long co = first * (N / 2) + lane * (E / 2);
+#pragma unroll
+        for (int c = 0; c < E / 2; ++c) rad[c] = valid ? l_n[co + c] * mu_c[co + c] : 1.0; // pybindings.cpp:57
+    } else {
+#pragma unroll
+        for (int c = 0; c < E / 2; ++c) rad[c] = 0.0;
+    }
+
+    const int it = admm_fwd_diag<KIND, E, LaneGroup<LPP>>(p, qv, rad, N, eps, mu_prox, max_iter, adaptive, valid, xv);
+
+    if (valid) {
+        double* xx = x + first * N + lane * E;
+#pragma unroll
+        for (int e = 0; e < E; e += 2) *reinterpret_cast<double2*>(xx + e) = make_double2(xv[e], xv[e + 1]);
+        if (iters != nullptr && (lane % LPP) == 0) iters[first + pl] = it;
+    }
+}
+
+template <int KIND, int N, int LPP, int WPB>
+static hipError_t launch_one(const FwdArgs& a, hipStream_t s)
+{
+    constexpr int PPW = 64 / LPP;
+    const long ntiles = (a.B + PPW - 1) / PPW;
+    const long nblocks = (ntiles + WPB - 1) / WPB;
+    if (nblocks == 0) return hipSuccess;
+    hipLaunchKernelGGL((fwd_diag_kernel<KIND, N, LPP, WPB>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q,
+                       a.l_n, a.mu, a.x, a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.layout, a.iters, a.ws);
+    return hipGetLastError();
+}
+
+template <int KIND, int N, int LPP>
+static hipError_t launch_wpb(const FwdArgs& a, int wpb, hipStream_t s)
+{
+    if (wpb == 1) return launch_one<KIND, N, LPP, 1>(a, s);
+    return launch_one<KIND, N, LPP, 4>(a, s);
+}
+
+// Built-in lanes-per-problem choice (E = N/LPP coordinates per lane); see
+// DESIGN.md for the measurements behind it.
+int fwd_diag_default_lpp(int N)
+{
+    switch (N) {
+    case 2: return 1;
+    case 4: return 1;
+    case 8: return 2;
+    case 16: return 4;
+    case 32: return 8;
+    case 64: return 16;
+    default: return 0;
+    }
+}
+
+bool fwd_diag_supported(int N) { return fwd_diag_default_lpp(N) != 0; }
+
+template <int KIND>
+static bool launch_kind(const FwdArgs& a, int lpp, int wpb, hipStream_t s, hipError_t& err)
+{
+#define DQQ_CASE(NN, LL) \
+    if (a.N == NN && lpp == LL) { err = launch_wpb<KIND, NN, LL>(a, wpb, s); return true; }
+    DQQ_CASE(2, 1)
+    DQQ_CASE(4, 1) DQQ_CASE(4, 2)
+    DQQ_CASE(8, 1) DQQ_CASE(8, 2) DQQ_CASE(8, 4)
+    DQQ_CASE(16, 2) DQQ_CASE(16, 4) DQQ_CASE(16, 8)
+    DQQ_CASE(32, 4) DQQ_CASE(32, 8) DQQ_CASE(32, 16)
+    DQQ_CASE(64, 8) DQQ_CASE(64, 16) DQQ_CASE(64, 32)
+#undef DQQ_CASE
+    return false;
+}
+
+// lpp / wpb == 0 -> built-in choice; an lpp the kernel is not instantiated for
+// falls back to the built-in one.
+hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, hipStream_t s)
+{
+    if (wpb != 1 && wpb != 4) wpb = 4;
+    if (lpp <= 0) lpp = fwd_diag_default_lpp(a.N);
+    hipError_t e = hipErrorInvalidValue;
+    bool found = kind == 0 ? launch_kind<0>(a, lpp, wpb, s, e) : launch_kind<1>(a, lpp, wpb, s, e);
+    if (!found) {
+        lpp = fwd_diag_default_lpp(a.N);
+        found = kind == 0 ? launch_kind<0>(a, lpp, wpb, s, e) : launch_kind<1>(a, lpp, wpb, s, e);
+    }
+    return found ? e : hipErrorInvalidValue;
+}
+
+} // namespace dqq

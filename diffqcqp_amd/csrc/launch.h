@@ -1,0 +1,62 @@
+// launch.h -- argument bundles and launcher prototypes shared by the kernel
+// translation units and capi.hip.
+#pragma once
+
+#include "../../include/diffqcqp_hip.h"
+#include "common.h"
+
+namespace dqq {
+
+// Fallback work-list in the caller's workspace (ints).  [0] number of queued
+// problem indices, [1] exit ticket of the dense kernel (its last workgroup
+// re-zeroes both), entries from [kWsEntries].
+constexpr int kWsCount = 0;
+constexpr int kWsTicket = 1;
+constexpr int kWsEntries = 4;
+
+struct FwdArgs {
+    const double* P;
+    const double* q;
+    const double* l_n; // QCQP only
+    const double* mu;  // QCQP only
+    double* x;
+    long B;
+    int N;
+    double eps, mu_prox;
+    int max_iter, adaptive, layout;
+    int* iters;
+    int* ws;
+};
+
+struct BwdArgs {
+    const double* P;
+    const double* q;
+    const double* l_n;
+    const double* mu;
+    const double* x;
+    const double* grad_x;
+    double* grad_P;
+    double* grad_q;
+    double* grad_l_n;
+    double* grad_mu;
+    long B;
+    int N;
+    int layout;
+    int* ir_steps;
+    int* ws;
+};
+
+// diagonal fast paths (fwd_diag.hip, bwd_diag.hip)
+bool fwd_diag_supported(int N);
+int fwd_diag_default_lpp(int N);
+hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, hipStream_t s);
+bool bwd_diag_supported(int N);
+hipError_t launch_bwd_diag(int kind, const BwdArgs& a, int wpb, hipStream_t s);
+
+// general dense kernels (dense.hip).  use_worklist: solve only the problems the
+// fast path queued in a.ws, then re-zero the work-list header.
+int dense_max_n(int kind); // 0 QP fwd/bwd, 1 QCQP fwd, 2 QCQP bwd
+hipError_t launch_fwd_dense(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s);
+hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);
+
+} // namespace dqq

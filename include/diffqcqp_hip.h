@@ -1,0 +1,109 @@
+/*
+ * diffqcqp_hip.h -- C ABI of libdiffqcqp_hip.so: batched ADMM QP / QCQP solve
+ * and implicit-function backward on MI355X (gfx950), float64.
+ *
+ * This is the drop-in boundary for the batched path of quentinll/diffqcqp.
+ * The reference crosses Python -> C++ once PER PROBLEM through the pybind11
+ * module `diffqcqp` (reference pybindings.cpp:74-83) from the batch loops of
+ * qcqp.py:29-31, 45-47, 149-151, 167-172.  Each entry point below replaces one
+ * of those loops (loop + per-problem call + the torch.bmm gradient assembly
+ * that follows it) with one asynchronous launch over the whole batch.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into memory the caller owns (borrowed
+ *     for the duration of the stream-ordered work); tensors are contiguous and
+ *     batch-major exactly as torch lays them out:
+ *         P (B,N,N)   q, x, grad_x, grad_q (B,N,1)   l_n, mu, grad_l_n, grad_mu (B,N/2,1)
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL =
+ *     the default stream) and the call returns without synchronising;
+ *   - return value: 0 on success, <0 for an invalid argument (DQQ_E_*), >0 a
+ *     hipError_t from the launch.  Nothing throws, there is no global state
+ *     besides the tuning knobs of dqq_set_option();
+ *   - like the reference (Solver.cpp:76, :100), numerical failure is not
+ *     signalled: a non-PD P or L=0 yields NaNs in the output;
+ *   - `warm_start` does not appear: the reference accepts it and overwrites it
+ *     before reading it (Solver.cpp:70/80, 529/539).
+ *
+ * p_layout
+ *   DQQ_P_AUTO  (0)  P is (B,N,N).  Tiles whose off-diagonals are all exactly
+ *                    zero run the diagonal fast path; every other tile is
+ *                    solved by the general dense kernel.  Never assumes.
+ *   DQQ_P_DENSE (1)  P is (B,N,N); always the general dense kernel.
+ *   DQQ_P_DIAG  (2)  extension: P is the compact diagonal (B,N); grad_P (if
+ *                    requested) is the compact diagonal of -dl x^T, (B,N).
+ */
+#ifndef DIFFQCQP_HIP_H
+#define DIFFQCQP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DQQ_P_AUTO 0
+#define DQQ_P_DENSE 1
+#define DQQ_P_DIAG 2
+
+#define DQQ_E_NULLPTR (-1)     /* a required pointer is NULL */
+#define DQQ_E_BAD_SIZE (-2)    /* B < 0, N < 1, odd N for QCQP */
+#define DQQ_E_UNSUPPORTED_N (-3) /* N beyond what the kernels hold in LDS (see dqq_max_n) */
+#define DQQ_E_BAD_LAYOUT (-4)
+#define DQQ_E_WORKSPACE (-5)   /* workspace missing or too small */
+#define DQQ_E_BAD_OPTION (-6)
+
+/* Bytes of device workspace the calls below need for a batch of B problems
+ * (fallback work-list of the AUTO layout).  The workspace must be zero-filled
+ * ONCE when it is allocated; every call leaves it zeroed again.  One workspace
+ * must not be shared by calls that may run concurrently on different streams. */
+size_t dqq_workspace_bytes(int64_t B);
+
+/* Largest N accepted: kind 0 = QP forward/backward, 1 = QCQP forward, 2 = QCQP backward. */
+int dqq_max_n(int kind);
+
+/* Replaces the loop qcqp.py:29-31 (QPFn2.forward -> diffqcqp.solveQP,
+ * pybindings.cpp:17-22 -> Solver::solveQP, Solver.cpp:61-123).
+ * iters (B ints, ADMM iterations executed per problem) may be NULL. */
+int dqq_qp_fwd_f64(const double* P, const double* q, double* x, int64_t B, int N, double eps, double mu_prox,
+                   int max_iter, int adaptive_rho, int p_layout, int* iters, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* Replaces the loop qcqp.py:45-47 + the assembly qcqp.py:48-51
+ * (QPFn2.backward -> diffqcqp.solveDerivativesQP, pybindings.cpp:24-30 ->
+ * Solver::dualFromPrimalQP / solveDerivativesQP, Solver.cpp:125-196):
+ *   grad_P = -dl x^T (B,N,N), grad_q = -dl (B,N,1).  Either may be NULL
+ * (ctx.needs_input_grad).  ir_steps (B ints) may be NULL. */
+int dqq_qp_bwd_f64(const double* P, const double* q, const double* x, const double* grad_x, double* grad_P,
+                   double* grad_q, int64_t B, int N, int p_layout, int* ir_steps, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* Replaces the loop qcqp.py:149-151 (QCQPFn2.forward -> diffqcqp.solveQCQP,
+ * pybindings.cpp:54-60 -> Solver::solveQCQP, Solver.cpp:521-582).  l_n and mu
+ * are the raw inputs; the radius l_n*mu is formed inside (pybindings.cpp:57). */
+int dqq_qcqp_fwd_f64(const double* P, const double* q, const double* l_n, const double* mu, double* x,
+                     int64_t B, int N, double eps, double mu_prox, int max_iter, int adaptive_rho,
+                     int p_layout, int* iters, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Replaces the loop qcqp.py:167-172 + the assembly qcqp.py:173-180
+ * (QCQPFn2.backward -> diffqcqp.solveDerivativesQCQP, pybindings.cpp:62-71 ->
+ * Solver.cpp:584-691):  grad_P = -dl x^T, grad_q = -dl, grad_l_n = E2 dgamma,
+ * grad_mu = E1 dgamma.  Any output may be NULL. */
+int dqq_qcqp_bwd_f64(const double* P, const double* q, const double* l_n, const double* mu, const double* x,
+                     const double* grad_x, double* grad_P, double* grad_q, double* grad_l_n, double* grad_mu,
+                     int64_t B, int N, int p_layout, int* ir_steps, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* Tuning knobs (process-wide, read at launch time).  Unknown name -> DQQ_E_BAD_OPTION.
+ *   "fwd_lpp"   lanes per problem of the diagonal forward kernel (0 = built-in choice)
+ *   "wpb"       waves per workgroup of the diagonal kernels (1, 2 or 4; 0 = built-in) */
+int dqq_set_option(const char* name, int value);
+int dqq_get_option(const char* name, int* value);
+
+/* "diffqcqp_hip <version> gfx950" */
+const char* dqq_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFQCQP_HIP_H */
