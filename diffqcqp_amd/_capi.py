@@ -1,0 +1,76 @@
+"""ctypes binding of libdiffqcqp_hip.so (include/diffqcqp_hip.h).
+
+The library is the product: if it is missing or cannot be loaded this module
+raises -- there is no CPU or PyTorch fallback behind it.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdiffqcqp_hip.so")
+
+P_AUTO, P_DENSE, P_DIAG = 0, 1, 2
+
+_ERRORS = {
+    -1: "DQQ_E_NULLPTR: a required pointer is NULL",
+    -2: "DQQ_E_BAD_SIZE: B < 0, N < 1, or odd N for a QCQP",
+    -3: "DQQ_E_UNSUPPORTED_N: N is larger than the kernels hold in LDS (see dqq_max_n)",
+    -4: "DQQ_E_BAD_LAYOUT: unknown p_layout",
+    -5: "DQQ_E_WORKSPACE: workspace missing or too small",
+    -6: "DQQ_E_BAD_OPTION: unknown option name",
+}
+
+_lib = None
+_vp, _i, _d, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_int64, ctypes.c_size_t
+
+# name -> argtypes, in the order of include/diffqcqp_hip.h
+SIGNATURES = {
+    "dqq_workspace_bytes": ([_i64], _sz),
+    "dqq_max_n": ([_i], _i),
+    "dqq_qp_fwd_f64": ([_vp, _vp, _vp, _i64, _i, _d, _d, _i, _i, _i, _vp, _vp, _sz, _vp], _i),
+    "dqq_qp_bwd_f64": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _sz, _vp], _i),
+    "dqq_qcqp_fwd_f64": ([_vp, _vp, _vp, _vp, _vp, _i64, _i, _d, _d, _i, _i, _i, _vp, _vp, _sz, _vp], _i),
+    "dqq_qcqp_bwd_f64": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _sz, _vp], _i),
+    "dqq_set_option": ([ctypes.c_char_p, _i], _i),
+    "dqq_get_option": ([ctypes.c_char_p, ctypes.POINTER(_i)], _i),
+    "dqq_version": ([], ctypes.c_char_p),
+}
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raises if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "diffqcqp_amd: %s not found. Build it with `python -m diffqcqp_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the library does not export it
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise ValueError("%s failed: %s" % (what, _ERRORS.get(rc, "error %d" % rc)))
+    raise RuntimeError("%s failed: hipError_t %d" % (what, rc))
+
+
+def set_option(name, value):
+    check(lib().dqq_set_option(name.encode(), int(value)), "dqq_set_option(%s)" % name)
+
+
+def get_option(name):
+    v = _i(0)
+    check(lib().dqq_get_option(name.encode(), ctypes.byref(v)), "dqq_get_option(%s)" % name)
+    return v.value
+
+
+def version():
+    return lib().dqq_version().decode()

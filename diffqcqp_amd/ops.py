@@ -1,0 +1,125 @@
+"""Tensor-level entry points over the C ABI: one asynchronous launch per batch.
+
+Inputs are float64 CUDA (ROCm) tensors in the reference's layouts -- P (B,N,N),
+q (B,N,1), l_n / mu (B,N/2,1) -- and every call runs on torch's current stream.
+torch is used here for device memory and streams only.
+"""
+import torch
+
+from . import _capi
+
+_workspaces = {}
+
+
+def _workspace(device, B):
+    """Zero-initialised fallback work-list, cached per (device, stream); the
+    kernels leave it zeroed (include/diffqcqp_hip.h: dqq_workspace_bytes)."""
+    stream = torch.cuda.current_stream(device)
+    key = (device.index, stream.cuda_stream)
+    need = _capi.lib().dqq_workspace_bytes(int(B))
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.zeros(max(need // 4, 1024), dtype=torch.int32, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _prep(t, name, shape=None):
+    if not t.is_cuda:
+        raise ValueError("%s must live on the GPU (got %s)" % (name, t.device))
+    if t.dtype != torch.float64:
+        t = t.to(torch.float64)
+    t = t.detach().contiguous()
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+    return t
+
+
+def _dims(P, q, layout):
+    B, N = q.shape[0], q.shape[1]
+    pshape = (B, N) if layout == _capi.P_DIAG else (B, N, N)
+    return B, N, pshape
+
+
+def qp_forward(P, q, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, layout=_capi.P_AUTO, return_iters=False,
+               out=None):
+    """Batched QP solve min 1/2 x'Px + q'x, x >= 0 (reference qcqp.py:24-33). -> x (B,N,1)"""
+    B, N, pshape = _dims(P, q, layout)
+    P, q = _prep(P, "P", pshape), _prep(q, "q", (B, N, 1))
+    x = out if out is not None else torch.empty((B, N, 1), dtype=torch.float64, device=q.device)
+    iters = torch.empty(B, dtype=torch.int32, device=q.device) if return_iters else None
+    ws = _workspace(q.device, B)
+    with torch.cuda.device(q.device):
+        rc = _capi.lib().dqq_qp_fwd_f64(_ptr(P), _ptr(q), _ptr(x), B, N, float(eps), float(mu_prox), int(max_iter),
+                                        int(bool(adaptive_rho)), layout, _ptr(iters), _ptr(ws), ws.numel() * 4,
+                                        torch.cuda.current_stream().cuda_stream)
+    _capi.check(rc, "dqq_qp_fwd_f64")
+    return (x, iters) if return_iters else x
+
+
+def qcqp_forward(P, q, l_n, mu, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, layout=_capi.P_AUTO,
+                 return_iters=False, out=None):
+    """Batched QCQP solve, ||x_(i)|| <= mu_i*l_n_i per contact (reference qcqp.py:144-153)."""
+    B, N, pshape = _dims(P, q, layout)
+    P, q = _prep(P, "P", pshape), _prep(q, "q", (B, N, 1))
+    l_n, mu = _prep(l_n, "l_n", (B, N // 2, 1)), _prep(mu, "mu", (B, N // 2, 1))
+    x = out if out is not None else torch.empty((B, N, 1), dtype=torch.float64, device=q.device)
+    iters = torch.empty(B, dtype=torch.int32, device=q.device) if return_iters else None
+    ws = _workspace(q.device, B)
+    with torch.cuda.device(q.device):
+        rc = _capi.lib().dqq_qcqp_fwd_f64(_ptr(P), _ptr(q), _ptr(l_n), _ptr(mu), _ptr(x), B, N, float(eps),
+                                          float(mu_prox), int(max_iter), int(bool(adaptive_rho)), layout, _ptr(iters),
+                                          _ptr(ws), ws.numel() * 4, torch.cuda.current_stream().cuda_stream)
+    _capi.check(rc, "dqq_qcqp_fwd_f64")
+    return (x, iters) if return_iters else x
+
+
+def qp_backward(P, q, x, grad_x, need_P=True, need_q=True, layout=_capi.P_AUTO, return_steps=False, out=None):
+    """Implicit-function backward of the QP (reference qcqp.py:36-52). -> (grad_P|None, grad_q|None)"""
+    B, N, pshape = _dims(P, q, layout)
+    P, q = _prep(P, "P", pshape), _prep(q, "q", (B, N, 1))
+    x, grad_x = _prep(x, "x", (B, N, 1)), _prep(grad_x, "grad_x", (B, N, 1))
+    dev = q.device
+    if out is not None:
+        gP, gq = out
+    else:
+        gP = torch.empty(pshape, dtype=torch.float64, device=dev) if need_P else None
+        gq = torch.empty((B, N, 1), dtype=torch.float64, device=dev) if need_q else None
+    steps = torch.empty(B, dtype=torch.int32, device=dev) if return_steps else None
+    ws = _workspace(dev, B)
+    with torch.cuda.device(dev):
+        rc = _capi.lib().dqq_qp_bwd_f64(_ptr(P), _ptr(q), _ptr(x), _ptr(grad_x), _ptr(gP), _ptr(gq), B, N, layout,
+                                        _ptr(steps), _ptr(ws), ws.numel() * 4,
+                                        torch.cuda.current_stream().cuda_stream)
+    _capi.check(rc, "dqq_qp_bwd_f64")
+    return (gP, gq, steps) if return_steps else (gP, gq)
+
+
+def qcqp_backward(P, q, l_n, mu, x, grad_x, need=(True, True, True, True), layout=_capi.P_AUTO, return_steps=False,
+                  out=None):
+    """Implicit-function backward of the QCQP (reference qcqp.py:156-181).
+    -> (grad_P, grad_q, grad_l_n, grad_mu), None where not needed."""
+    B, N, pshape = _dims(P, q, layout)
+    P, q = _prep(P, "P", pshape), _prep(q, "q", (B, N, 1))
+    l_n, mu = _prep(l_n, "l_n", (B, N // 2, 1)), _prep(mu, "mu", (B, N // 2, 1))
+    x, grad_x = _prep(x, "x", (B, N, 1)), _prep(grad_x, "grad_x", (B, N, 1))
+    dev = q.device
+    if out is not None:
+        gP, gq, gl, gm = out
+    else:
+        gP = torch.empty(pshape, dtype=torch.float64, device=dev) if need[0] else None
+        gq = torch.empty((B, N, 1), dtype=torch.float64, device=dev) if need[1] else None
+        gl = torch.empty((B, N // 2, 1), dtype=torch.float64, device=dev) if need[2] else None
+        gm = torch.empty((B, N // 2, 1), dtype=torch.float64, device=dev) if need[3] else None
+    steps = torch.empty(B, dtype=torch.int32, device=dev) if return_steps else None
+    ws = _workspace(dev, B)
+    with torch.cuda.device(dev):
+        rc = _capi.lib().dqq_qcqp_bwd_f64(_ptr(P), _ptr(q), _ptr(l_n), _ptr(mu), _ptr(x), _ptr(grad_x), _ptr(gP),
+                                          _ptr(gq), _ptr(gl), _ptr(gm), B, N, layout, _ptr(steps), _ptr(ws),
+                                          ws.numel() * 4, torch.cuda.current_stream().cuda_stream)
+    _capi.check(rc, "dqq_qcqp_bwd_f64")
+    return (gP, gq, gl, gm, steps) if return_steps else (gP, gq, gl, gm)

@@ -1,0 +1,81 @@
+"""Drop-in for the reference's `qcqp.py`: the `QPFn2` and `QCQPFn2`
+`torch.autograd.Function`s with the same forward/backward signatures, argument
+order, output shapes and `None` padding (reference qcqp.py:22-52, 141-181), but
+each pass is ONE launch of a hand-written HIP kernel over the whole batch
+instead of a Python loop over per-problem C++ calls.
+
+    from diffqcqp_amd.qcqp import QPFn2, QCQPFn2
+    x = QPFn2.apply(P, q, warm_start, eps, max_iter)          # (B,N,1)
+    x = QCQPFn2.apply(P, q, l_n, mu, warm_start, eps, max_iter)
+
+Behaviour kept from the reference:
+  * importing this module sets torch's default dtype to float64 (qcqp.py:13);
+  * `warm_start` is accepted and has no effect on the result (the reference
+    overwrites it before reading it, Solver.cpp:70/80, 529/539); it gets no grad;
+  * backward honours ctx.needs_input_grad and returns 6 / 8 values.
+Differences: tensors on the GPU are used in place and results stay there; CPU
+tensors are staged through cuda:0 and the result is returned on the CPU.  There
+is no CPU solver in this package: without a GPU and the HIP library the calls
+raise.
+"""
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+torch.set_default_dtype(torch.double)
+
+
+def _device_for(t):
+    if t.is_cuda:
+        return t.device
+    if not torch.cuda.is_available():
+        raise RuntimeError("diffqcqp_amd needs an MI355X (ROCm) device: the solver is a HIP kernel and "
+                           "there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class QPFn2(Function):
+    @staticmethod
+    def forward(ctx, P, q, warm_start, eps, max_iter, mu_prox=1e-7):
+        dev = _device_for(q)
+        Pd, qd = P.detach().to(dev), q.detach().to(dev)
+        l_2 = ops.qp_forward(Pd, qd, eps, max_iter, mu_prox, adaptive_rho=True)
+        ctx.save_for_backward(Pd, qd, l_2)
+        ctx.home = q.device
+        return l_2.to(q.device)
+
+    @staticmethod
+    def backward(ctx, grad_l):
+        P, q, l = ctx.saved_tensors
+        need_P, need_q = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        grad_P, grad_q = None, None
+        if need_P or need_q:
+            grad_P, grad_q = ops.qp_backward(P, q, l, grad_l.to(l.device), need_P, need_q)
+            if grad_P is not None:
+                grad_P = grad_P.to(ctx.home)
+            if grad_q is not None:
+                grad_q = grad_q.to(ctx.home)
+        return grad_P, grad_q, None, None, None, None
+
+
+class QCQPFn2(Function):
+    @staticmethod
+    def forward(ctx, P, q, l_n, mu, warm_start, eps, max_iter, mu_prox=1e-7):
+        dev = _device_for(q)
+        Pd, qd = P.detach().to(dev), q.detach().to(dev)
+        lnd, mud = l_n.detach().to(dev), mu.detach().to(dev)
+        l_2 = ops.qcqp_forward(Pd, qd, lnd, mud, eps, max_iter, mu_prox, adaptive_rho=True)
+        ctx.save_for_backward(Pd, qd, lnd, mud, l_2)
+        ctx.home = q.device
+        return l_2.to(q.device)
+
+    @staticmethod
+    def backward(ctx, grad_l):
+        P, q, l_n, mu, l = ctx.saved_tensors
+        need = tuple(ctx.needs_input_grad[0:4])
+        grads = (None, None, None, None)
+        if any(need):
+            grads = ops.qcqp_backward(P, q, l_n, mu, l, grad_l.to(l.device), need)
+            grads = tuple(None if g is None else g.to(ctx.home) for g in grads)
+        return grads + (None, None, None, None)

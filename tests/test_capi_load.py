@@ -1,0 +1,76 @@
+"""CPU checks of the drop-in boundary: libdiffqcqp_hip.so builds for gfx950,
+loads, exports every symbol include/diffqcqp_hip.h declares, and validates its
+arguments before touching a GPU.  No compute call is made here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from diffqcqp_amd import build, _capi
+    build.build()
+    return _capi.lib()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "diffqcqp_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dqq_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib):
+    names = _declared_symbols()
+    assert {"dqq_qp_fwd_f64", "dqq_qp_bwd_f64", "dqq_qcqp_fwd_f64", "dqq_qcqp_bwd_f64"} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), "library does not export %s" % n
+    from diffqcqp_amd import _capi
+    assert set(_capi.SIGNATURES) == set(names), "python binding and header disagree"
+
+
+def test_version_and_limits(lib):
+    assert b"gfx950" in lib.dqq_version()
+    assert lib.dqq_max_n(0) == 64 and lib.dqq_max_n(1) == 64 and lib.dqq_max_n(2) == 42
+    assert lib.dqq_workspace_bytes(0) >= 16
+    assert lib.dqq_workspace_bytes(65536) >= 4 * 65536
+
+
+def test_argument_validation_without_gpu(lib):
+    one = ctypes.c_void_p(8)  # never dereferenced: the checks fail first
+    f = lib.dqq_qp_fwd_f64
+    assert f(one, one, one, -1, 8, 1e-7, 1e-7, 10, 1, 0, None, None, 0, None) == -2
+    assert f(one, one, one, 4, 0, 1e-7, 1e-7, 10, 1, 0, None, None, 0, None) == -2
+    assert f(one, one, one, 4, 8, 1e-7, 1e-7, 10, 1, 7, None, None, 0, None) == -4
+    assert f(None, one, one, 4, 8, 1e-7, 1e-7, 10, 1, 0, None, None, 0, None) == -1
+    assert f(one, one, one, 4, 8, 1e-7, 1e-7, 10, 1, 0, None, None, 0, None) == -5  # AUTO needs a workspace
+    assert f(one, one, one, 4, 200, 1e-7, 1e-7, 10, 1, 1, None, None, 0, None) == -3
+    assert f(one, one, one, 0, 8, 1e-7, 1e-7, 10, 1, 0, None, None, 0, None) == 0   # empty batch is a no-op
+    g = lib.dqq_qcqp_fwd_f64
+    assert g(one, one, one, one, one, 4, 7, 1e-7, 1e-7, 10, 1, 0, None, None, 0, None) == -2  # odd N
+    assert lib.dqq_qcqp_bwd_f64(one, one, one, one, one, one, None, None, None, None, 4, 48, 1, None, None, 0, None) == -3
+    assert lib.dqq_set_option(b"no_such_knob", 1) == -6
+
+
+def test_python_layer_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from diffqcqp_amd.qcqp import QPFn2
+    P = torch.eye(2).unsqueeze(0)
+    q = -torch.ones(1, 2, 1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        QPFn2.apply(P, q, torch.zeros(1, 2, 1), 1e-7, 100)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under diffqcqp_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "diffqcqp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "liboracle" not in text and "from oracle" not in text and "import oracle" not in text, f

@@ -1,0 +1,360 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through
+the C ABI (diffqcqp_amd.ops -> libdiffqcqp_hip.so), against the CPU oracle on the
+same seeded inputs, against the committed golden fixtures, and -- at the full
+BASELINE.json batch sizes -- through size-independent properties.
+
+Tolerances (float64):
+  x          |x_hip - x_oracle| <= 1e-6 everywhere (the north-star tolerance); in practice the
+             trajectories coincide (same iteration count) and the difference is ~1e-13, which the
+             tests also assert through the median and the iteration-count match rate;
+  gradients  with IDENTICAL x fed to both sides the backward is required to be bit-exact on the
+             diagonal fast path and within 1e-9 relative on the dense path; end to end (x from the
+             HIP forward) within 1e-6 relative to the gradient scale.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_problem
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+X_TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    from diffqcqp_amd import build, ops as _ops, _capi
+    build.build()
+    _capi.lib()
+    yield _ops
+    _capi.set_option("fwd_lpp", 0)
+    _capi.set_option("wpb", 0)
+
+
+def dev(d):
+    return {k: v.cuda() for k, v in d.items()}
+
+
+def npy(t):
+    return None if t is None else t.detach().cpu().numpy()
+
+
+def oracle_fwd(O, kind, d, eps=1e-7, max_iter=1000):
+    if kind == "qp":
+        return O.qp_fwd_batch(d["P"].numpy(), d["q"].numpy(), eps, max_iter, nthreads=8)
+    return O.qcqp_fwd_batch(d["P"].numpy(), d["q"].numpy(), d["l_n"].numpy(), d["mu"].numpy(), eps, max_iter, nthreads=8)
+
+
+def oracle_bwd(O, kind, d, x):
+    if kind == "qp":
+        return O.qp_bwd_batch(d["P"].numpy(), d["q"].numpy(), x, d["grad_x"].numpy(), nthreads=8)
+    return O.qcqp_bwd_batch(d["P"].numpy(), d["q"].numpy(), d["l_n"].numpy(), d["mu"].numpy(), x, d["grad_x"].numpy(), nthreads=8)
+
+
+def hip_fwd(ops, kind, g, layout=0, eps=1e-7, max_iter=1000):
+    if kind == "qp":
+        return ops.qp_forward(g["P"], g["q"], eps, max_iter, layout=layout, return_iters=True)
+    return ops.qcqp_forward(g["P"], g["q"], g["l_n"], g["mu"], eps, max_iter, layout=layout, return_iters=True)
+
+
+def hip_bwd(ops, kind, g, x, layout=0):
+    if kind == "qp":
+        gP, gq, st = ops.qp_backward(g["P"], g["q"], x, g["grad_x"], layout=layout, return_steps=True)
+        return [gP, gq], st
+    gP, gq, gl, gm, st = ops.qcqp_backward(g["P"], g["q"], g["l_n"], g["mu"], x, g["grad_x"], layout=layout,
+                                           return_steps=True)
+    return [gP, gq, gl, gm], st
+
+
+def check_forward(xh, ith, xo, ito, min_match=0.999):
+    diff = np.abs(npy(xh) - xo)
+    assert np.isfinite(npy(xh)).all()
+    assert diff.max() <= X_TOL, "max |x_hip - x_oracle| = %g" % diff.max()
+    match = (npy(ith) == ito).mean()
+    assert match >= min_match, "iteration counts differ on %.3f%% of the problems" % (100 * (1 - match))
+    assert np.median(diff.max(axis=(1, 2))) < 1e-11
+
+
+def check_backward_exact(grads, steps, ref, exact=True, rtol=1e-9):
+    *gref, sref = ref
+    assert np.array_equal(npy(steps), sref), "refinement step counts differ"
+    for a, b in zip(grads, gref):
+        a = npy(a)
+        if exact:
+            assert np.array_equal(a, b), "max diff %g" % np.abs(a - b).max()
+        else:
+            assert np.allclose(a, b, rtol=rtol, atol=rtol * max(1.0, np.abs(b).max()))
+
+
+# ---------------------------------------------------------------- diagonal fast path
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("N,B", [(2, 777), (4, 500), (8, 2051), (16, 301), (32, 131), (64, 37)])
+def test_diag_fast_path_matches_oracle(oracle, ops, kind, N, B):
+    d = make_problem(kind, B, N, 100 + N)
+    g = dev(d)
+    xo, ito = oracle_fwd(oracle, kind, d)
+    xh, ith = hip_fwd(ops, kind, g)
+    check_forward(xh, ith, xo, ito)
+    # backward on IDENTICAL x: bit-exact, including the 1-vs-3 refinement step decision
+    grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda())
+    check_backward_exact(grads, st, oracle_bwd(oracle, kind, d, xo), exact=True)
+    # end to end
+    grads2, _ = hip_bwd(ops, kind, g, xh)
+    for a, b in zip(grads2, oracle_bwd(oracle, kind, d, xo)[:-1]):
+        assert np.abs(npy(a) - b).max() <= 1e-6 * max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("N,lpps", [(8, (1, 2, 4)), (16, (2, 4, 8)), (32, (4, 8, 16)), (64, (8, 16, 32)), (4, (1, 2))])
+def test_every_lanes_per_problem_variant(oracle, ops, kind, N, lpps):
+    from diffqcqp_amd import _capi
+    d = make_problem(kind, 333, N, 200 + N)
+    g = dev(d)
+    xo, ito = oracle_fwd(oracle, kind, d)
+    for wpb in (1, 4):
+        for lpp in lpps:
+            _capi.set_option("fwd_lpp", lpp)
+            _capi.set_option("wpb", wpb)
+            xh, ith = hip_fwd(ops, kind, g)
+            check_forward(xh, ith, xo, ito)
+    _capi.set_option("fwd_lpp", 0)
+    _capi.set_option("wpb", 0)
+    grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda())  # wpb = default after the wpb=1 sweep
+    check_backward_exact(grads, st, oracle_bwd(oracle, kind, d, xo))
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("B", [0, 1, 7, 8, 9, 31, 32, 33, 63, 64, 65, 255, 257])
+def test_ragged_and_empty_batches(oracle, ops, kind, B):
+    N = 8
+    if B == 0:
+        e = lambda *s: torch.empty(s, dtype=torch.float64, device="cuda")
+        if kind == "qp":
+            assert ops.qp_forward(e(0, N, N), e(0, N, 1), 1e-7, 100).shape == (0, N, 1)
+        else:
+            assert ops.qcqp_forward(e(0, N, N), e(0, N, 1), e(0, 4, 1), e(0, 4, 1), 1e-7, 100).shape == (0, N, 1)
+        return
+    d = make_problem(kind, B, N, 300 + B)
+    g = dev(d)
+    # guard bands: the kernels must not write past the batch
+    xbuf = torch.full((B + 4, N, 1), 7.0, dtype=torch.float64, device="cuda")
+    xo, ito = oracle_fwd(oracle, kind, d)
+    if kind == "qp":
+        ops.qp_forward(g["P"], g["q"], 1e-7, 1000, out=xbuf[:B])
+    else:
+        ops.qcqp_forward(g["P"], g["q"], g["l_n"], g["mu"], 1e-7, 1000, out=xbuf[:B])
+    assert (xbuf[B:] == 7.0).all()
+    assert np.abs(npy(xbuf[:B]) - xo).max() <= X_TOL
+    grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda())
+    check_backward_exact(grads, st, oracle_bwd(oracle, kind, d, xo))
+
+
+def test_compact_diagonal_layout_extension(oracle, ops):
+    """DQQ_P_DIAG: P given as (B,N) -- same numbers as the (B,N,N) layout."""
+    from diffqcqp_amd import _capi
+    d = make_problem("qcqp", 1000, 8, 401)
+    g = dev(d)
+    pdiag = torch.diagonal(g["P"], dim1=1, dim2=2).contiguous()
+    x0 = ops.qcqp_forward(g["P"], g["q"], g["l_n"], g["mu"], 1e-7, 1000)
+    x1 = ops.qcqp_forward(pdiag, g["q"], g["l_n"], g["mu"], 1e-7, 1000, layout=_capi.P_DIAG)
+    assert torch.equal(x0, x1)
+    g0 = ops.qcqp_backward(g["P"], g["q"], g["l_n"], g["mu"], x0, g["grad_x"])
+    g1 = ops.qcqp_backward(pdiag, g["q"], g["l_n"], g["mu"], x0, g["grad_x"], layout=_capi.P_DIAG)
+    assert torch.equal(torch.diagonal(g0[0], dim1=1, dim2=2), g1[0])
+    for a, b in zip(g0[1:], g1[1:]):
+        assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------- general dense path
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("N,B,structure", [(8, 200, "dense"), (8, 100, "diag"), (4, 64, "dense"), (12, 40, "dense"),
+                                           (16, 40, "dense"), (32, 12, "dense"), (6, 50, "dense")])
+def test_dense_kernel_matches_oracle(oracle, ops, kind, N, B, structure):
+    from diffqcqp_amd import _capi
+    d = make_problem(kind, B, N, 500 + N, structure)
+    g = dev(d)
+    xo, ito = oracle_fwd(oracle, kind, d)
+    xh, ith = hip_fwd(ops, kind, g, layout=_capi.P_DENSE)
+    check_forward(xh, ith, xo, ito, min_match=0.99)
+    grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
+    check_backward_exact(grads, st, oracle_bwd(oracle, kind, d, xo), exact=False)
+
+
+@pytest.mark.parametrize("N", [3, 5, 7])
+def test_dense_kernel_odd_n_qp(oracle, ops, N):
+    d = make_problem("qp", 60, N, 600 + N, "dense")
+    g = dev(d)
+    xo, ito = oracle_fwd(oracle, "qp", d)
+    xh, ith = hip_fwd(ops, "qp", g)  # AUTO: no fast path for odd N -> dense kernel
+    check_forward(xh, ith, xo, ito, min_match=0.99)
+    grads, st = hip_bwd(ops, "qp", g, torch.from_numpy(xo).cuda())
+    check_backward_exact(grads, st, oracle_bwd(oracle, "qp", d, xo), exact=False)
+
+
+def test_dense_n64_config5_shape(oracle, ops):
+    """BASELINE.json configs[4] at a reduced batch: N=64 dense-P QP, P = S S^T/64 + 0.1 I."""
+    d = make_problem("qp", 24, 64, 1005, "dense")
+    g = dev(d)
+    xo, ito = oracle_fwd(oracle, "qp", d)
+    xh, ith = hip_fwd(ops, "qp", g)
+    check_forward(xh, ith, xo, ito, min_match=0.9)
+    grads, st = hip_bwd(ops, "qp", g, torch.from_numpy(xo).cuda())
+    check_backward_exact(grads, st, oracle_bwd(oracle, "qp", d, xo), exact=False)
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("N", [8, 32])
+def test_auto_layout_mixed_batch_uses_fallback(oracle, ops, kind, N):
+    """Diagonal and dense problems interleaved: tiles with a non-zero off-diagonal go through the
+    work-list to the dense kernel, the rest through the fast path; the work-list is left zeroed."""
+    B = 500 if N == 8 else 61
+    d = make_problem(kind, B, N, 700 + N, "mixed")
+    g = dev(d)
+    xo, ito = oracle_fwd(oracle, kind, d)
+    for _ in range(2):  # twice: the second call relies on the first having re-zeroed the workspace
+        xh, ith = hip_fwd(ops, kind, g)
+        check_forward(xh, ith, xo, ito, min_match=0.99)
+        grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda())
+        check_backward_exact(grads, st, oracle_bwd(oracle, kind, d, xo), exact=False)
+    for ws in ops._workspaces.values():
+        assert int(ws[:4].abs().sum()) == 0
+
+
+def test_single_nonzero_offdiagonal_is_detected(oracle, ops):
+    """One tiny off-diagonal entry anywhere in a tile must route that tile to the dense kernel."""
+    N, B = 8, 256
+    d = make_problem("qp", B, N, 801)
+    for (b, i, j) in [(0, 0, 1), (77, 7, 0), (130, 3, 4), (255, 6, 7)]:
+        d["P"][b, i, j] = 1e-3
+        d["P"][b, j, i] = 1e-3
+    d["P"][200, 2, 5] = -0.0  # a negative zero is still zero
+    g = dev(d)
+    xo, ito = oracle_fwd(oracle, "qp", d)
+    xh, ith = hip_fwd(ops, "qp", g)
+    check_forward(xh, ith, xo, ito, min_match=0.99)
+    # and the detection matters: the diagonal-only answer differs on the touched problems
+    pd = torch.diagonal(g["P"], dim1=1, dim2=2).contiguous()
+    from diffqcqp_amd import _capi
+    xd = ops.qp_forward(pd, g["q"], 1e-7, 1000, layout=_capi.P_DIAG)
+    assert (xd[0] - xh[0]).abs().max() > 1e-6
+
+
+# ---------------------------------------------------------------- golden fixtures
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))), ids=os.path.basename)
+def test_hip_reproduces_golden(ops, path):
+    d = np.load(path)
+    kind = "qcqp" if "l_n" in d.files else "qp"
+    g = {k: torch.from_numpy(d[k]).cuda() for k in ("P", "q", "grad_x", "l_n", "mu") if k in d.files}
+    eps, mi = float(d["eps"]), int(d["max_iter"])
+    xh, ith = hip_fwd(ops, kind, g, eps=eps, max_iter=mi)
+    assert np.abs(npy(xh) - d["x"]).max() <= X_TOL
+    assert (npy(ith) == d["iters"]).mean() >= 0.95
+    grads, st = hip_bwd(ops, kind, g, torch.from_numpy(d["x"]).cuda())
+    names = ["grad_P", "grad_q", "grad_l_n", "grad_mu"][: len(grads)]
+    assert np.array_equal(npy(st), d["ir_steps"])
+    for a, n in zip(grads, names):
+        assert np.allclose(npy(a), d[n], rtol=1e-9, atol=1e-9 * max(1.0, np.abs(d[n]).max()))
+
+
+# ---------------------------------------------------------------- autograd drop-in surface
+def test_autograd_functions_match_reference_contract(oracle, ops):
+    from diffqcqp_amd.qcqp import QPFn2, QCQPFn2
+    d = make_problem("qcqp", 64, 8, 901)
+    P, q = d["P"].cuda().requires_grad_(True), d["q"].cuda().requires_grad_(True)
+    l_n, mu = d["l_n"].cuda().requires_grad_(True), d["mu"].cuda().requires_grad_(True)
+    ws = torch.zeros_like(q)
+    x = QCQPFn2.apply(P, q, l_n, mu, ws, 1e-7, 1000)
+    assert x.shape == (64, 8, 1) and x.is_cuda
+    (x * d["grad_x"].cuda()).sum().backward()
+    xo, _ = oracle_fwd(oracle, "qcqp", d)
+    ref = oracle_bwd(oracle, "qcqp", d, xo)
+    for t, r in zip((P, q, l_n, mu), ref[:-1]):
+        assert t.grad.shape == r.shape and np.abs(npy(t.grad) - r).max() <= 1e-6 * max(1.0, np.abs(r).max())
+    # QP, only q requires grad, warm_start has no effect and gets no grad; CPU tensors are staged via the GPU
+    dq = make_problem("qp", 10, 8, 902)
+    Pc, qc = dq["P"], dq["q"].clone().requires_grad_(True)
+    w1 = torch.zeros(10, 8, 1, requires_grad=True)
+    x1 = QPFn2.apply(Pc, qc, w1, 1e-7, 1000)
+    x2 = QPFn2.apply(Pc, qc, torch.randn(10, 8, 1), 1e-7, 1000)
+    assert not x1.is_cuda and torch.equal(x1, x2)
+    x1.sum().backward()
+    assert w1.grad is None and qc.grad is not None and qc.grad.shape == (10, 8, 1)
+    out = QPFn2.backward(type("C", (), {"saved_tensors": (Pc.cuda(), qc.detach().cuda(), x1.detach().cuda()),
+                                        "needs_input_grad": (False, True, False, False, False, False),
+                                        "home": torch.device("cpu")})(), torch.ones(10, 8, 1))
+    assert len(out) == 6 and out[0] is None and out[2:] == (None, None, None, None)
+
+
+def test_runs_on_a_non_default_stream(oracle, ops):
+    d = make_problem("qp", 300, 8, 903)
+    g = dev(d)
+    xo, _ = oracle_fwd(oracle, "qp", d)
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        x = ops.qp_forward(g["P"], g["q"], 1e-7, 1000)
+    s.synchronize()
+    assert np.abs(npy(x) - xo).max() <= X_TOL
+
+
+# ---------------------------------------------------------------- full BASELINE sizes: properties
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+def test_full_size_b65536_n8_properties(oracle, ops, kind):
+    """configs[1]/[2] sizes.  Size-independent properties + the oracle on a 4096-problem sample."""
+    B, N = 65536, 8
+    d = make_problem(kind, B, N, 1002 if kind == "qp" else 1003)
+    g = dev(d)
+    x, it = hip_fwd(ops, kind, g)
+    assert torch.isfinite(x).all() and int(it.max()) < 200
+    p = torch.diagonal(g["P"], dim1=1, dim2=2)
+    if kind == "qp":
+        cf = torch.clamp(-g["q"][:, :, 0] / p, min=0)
+        err = (x[:, :, 0] - cf).abs().amax(1)
+        assert float(err.median()) < 1e-6 and float(err.max()) < 1e-3 and float(x.min()) >= 0.0
+    else:
+        r = (g["l_n"] * g["mu"])[:, :, 0]
+        nrm = torch.sqrt(x[:, 0::2, 0] ** 2 + x[:, 1::2, 0] ** 2)
+        assert float((nrm - r).max()) < 1e-12
+    # permutation equivariance: problems are independent, tiles must not leak into each other
+    perm = torch.randperm(B, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    gp = {k: v[perm].contiguous() for k, v in g.items()}
+    xp, _ = hip_fwd(ops, kind, gp)
+    assert torch.equal(xp, x[perm])
+    grads, st = hip_bwd(ops, kind, g, x)
+    gradsp, _ = hip_bwd(ops, kind, gp, xp)
+    for a, b in zip(grads, gradsp):
+        assert torch.equal(b, a[perm])
+    # grad_P is the outer product of grad_q and x (qcqp.py:49-51): exact by construction
+    assert torch.equal(grads[0], grads[1] * x.transpose(1, 2))
+    # oracle on a sample
+    idx = torch.arange(0, B, 16)
+    ds = {k: v[idx].contiguous() for k, v in d.items()}
+    xo, ito = oracle_fwd(oracle, kind, ds)
+    check_forward(x[idx.cuda()], it[idx.cuda()], xo, ito)
+    ref = oracle_bwd(oracle, kind, ds, xo)
+    gs, sts = hip_bwd(ops, kind, dev(ds), torch.from_numpy(xo).cuda())
+    check_backward_exact(gs, sts, ref)
+
+
+def test_full_size_config4_per_gpu_shard(oracle, ops):
+    """configs[3]: B=262144 N=32 over 8 GPUs = 32768 problems per GPU; one shard here."""
+    B, N = 32768, 32
+    d = make_problem("qp", B, N, 1004)
+    g = dev(d)
+    x, it = hip_fwd(ops, "qp", g)
+    p = torch.diagonal(g["P"], dim1=1, dim2=2)
+    cf = torch.clamp(-g["q"][:, :, 0] / p, min=0)
+    assert float((x[:, :, 0] - cf).abs().amax(1).median()) < 1e-6
+    grads, st = hip_bwd(ops, "qp", g, x)
+    assert torch.equal(grads[0], grads[1] * x.transpose(1, 2))
+    idx = torch.arange(0, B, 64)
+    ds = {k: v[idx].contiguous() for k, v in d.items()}
+    xo, ito = oracle_fwd(oracle, "qp", ds)
+    check_forward(x[idx.cuda()], it[idx.cuda()], xo, ito)
+    gs, sts = hip_bwd(ops, "qp", dev(ds), torch.from_numpy(xo).cuda())
+    check_backward_exact(gs, sts, oracle_bwd(oracle, "qp", ds, xo))

@@ -1,0 +1,218 @@
+"""CPU tests of the oracle (oracle/diffqcqp_oracle.c).
+
+The reference has no test with an expected value, so the oracle is
+pinned by properties and by the reference's own two checking methods: KKT
+residuals (Solver.cpp:825,867 printouts) and finite differences
+(test_script.py:34-43, Solver.cpp:830-851).  PARITY UNPINNED by reference outputs.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_problem
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_seed5_inputs_match_authors_constants():
+    """test_script.py:23-29 inputs reproduce the constants the author hard-coded at
+    test_script.py:153-154 and Solver.cpp:783,796 (0.4979/0.3295/0.2432, -0.3661/-0.9514)."""
+    d = np.load(os.path.join(GOLDEN, "qp_seed5.npz"))
+    P, q = d["P"][0], d["q"][0, :, 0]
+    assert np.allclose(P, [[0.4979, 0.3295], [0.3295, 0.2432]], atol=5e-5)
+    assert np.allclose(q, [-0.3661, -0.9514], atol=5e-5)
+    torch.manual_seed(5)
+    S = torch.rand(1, 2, 2, dtype=torch.float64) + 0.01
+    assert np.array_equal(torch.bmm(S, S.transpose(1, 2)).numpy(), d["P"])
+
+
+def test_seed5_solution_and_fd_gradient(oracle):
+    """The FD check of test_script.py:23-43: analytic dP of x[1] vs central differences."""
+    d = np.load(os.path.join(GOLDEN, "qp_seed5.npz"))
+    P, q = d["P"][0], d["q"][0, :, 0]
+    x, it = oracle.solveQP(P, q, np.zeros(2), 1e-12, 1e-7, 10000, True, return_iters=True)
+    assert it == 123
+    assert x[0] == 0.0 and abs(x[1] - 3.91173314626397) < 1e-9
+    bl = oracle.solveDerivativesQP(P, q, x, np.array([0.0, 1.0]))
+    grad_P = -np.outer(bl, x)
+    fd = np.zeros((2, 2))
+    for i in range(2):
+        for j in range(2):
+            e = np.zeros((2, 2))
+            e[i, j] = 1e-8
+            fd[i, j] = (oracle.solveQP(P + e, q, None, 1e-12, 1e-7, 10000)[1]
+                        - oracle.solveQP(P - e, q, None, 1e-12, 1e-7, 10000)[1]) / 2e-8
+    assert abs(grad_P[1, 1] + 16.0827925) < 1e-6
+    assert np.allclose(grad_P, fd, atol=1e-4)
+
+
+def test_readme_example_is_degenerate(oracle):
+    """README.md:35-38: q >= 0 => x == 0 after ONE iteration, all gradients 0."""
+    d = np.load(os.path.join(GOLDEN, "qp_readme.npz"))
+    x, it = oracle.qp_fwd_batch(d["P"], d["q"], 1e-7, 1000)
+    assert np.all(x == 0.0) and np.all(it == 1)
+    gP, gq, _ = oracle.qp_bwd_batch(d["P"], d["q"], x, d["grad_x"])
+    assert np.all(gP == 0.0) and np.all(gq == 0.0)
+
+
+def test_diag_qp_closed_form_and_backward_identity(oracle):
+    """x* = max(-q/p, 0) within the solver's accuracy; dl_i = p g/(p^2+1e-7) on the inactive set."""
+    d = make_problem("qp", 512, 8, 11)
+    P, q, g = d["P"].numpy(), d["q"].numpy(), d["grad_x"].numpy()
+    p = np.diagonal(P, axis1=1, axis2=2)
+    x, it = oracle.qp_fwd_batch(P, q, 1e-7, 1000)
+    cf = np.maximum(-q[:, :, 0] / p, 0)
+    err = np.abs(x[:, :, 0] - cf)
+    assert np.median(err.max(1)) < 1e-6 and err.max() < 1e-3
+    assert it.max() < 60
+    gP, gq, steps = oracle.qp_bwd_batch(P, q, x, g)
+    assert np.all(steps == 1)
+    xx = x[:, :, 0]
+    active = (xx <= 1e-10) & (-(p * xx + q[:, :, 0]) < -1e-10)
+    dl = np.where(active, 0.0, p * g[:, :, 0] / (p * p + 1e-7))
+    assert np.abs(-gq[:, :, 0] - dl).max() < 1e-13
+    assert np.allclose(gP, -dl[:, :, None] * xx[:, None, :], atol=1e-15)
+
+
+@pytest.mark.parametrize("structure,N", [("diag", 8), ("dense", 8), ("dense", 16)])
+def test_qp_kkt(oracle, structure, N):
+    """KKT of min 1/2 x'Px+q'x, x>=0: x>=0, Px+q>=0, x.(Px+q)=0 (to solver accuracy)."""
+    d = make_problem("qp", 64, N, 21, structure)
+    P, q = d["P"].numpy(), d["q"].numpy()
+    x, _ = oracle.qp_fwd_batch(P, q, 1e-10, 100000)
+    r = np.einsum("bij,bj->bi", P, x[:, :, 0]) + q[:, :, 0]
+    assert x.min() >= 0.0
+    assert r.min() > -1e-5
+    assert np.abs(x[:, :, 0] * r).max() < 1e-5
+
+
+@pytest.mark.parametrize("structure", ["diag", "dense"])
+def test_qcqp_kkt(oracle, structure):
+    """Feasibility + stationarity Px+q+2 gamma_i x_(i) = 0 with the recovered duals gamma >= 0."""
+    N = 8
+    d = make_problem("qcqp", 64, N, 22, structure)
+    P, q, ln, mu = d["P"].numpy(), d["q"].numpy(), d["l_n"].numpy(), d["mu"].numpy()
+    x, _ = oracle.qcqp_fwd_batch(P, q, ln, mu, 1e-10, 100000)
+    r = (ln * mu)[:, :, 0]
+    nrm = np.sqrt(x[:, 0::2, 0] ** 2 + x[:, 1::2, 0] ** 2)
+    assert (nrm - r).max() < 1e-9
+    for b in range(8):
+        _, _, _, _, gam = oracle.solveDerivativesQCQP(P[b], q[b], ln[b], mu[b], x[b], np.zeros(N), return_steps=True)
+        assert gam.min() > -1e-6
+        stat = P[b] @ x[b, :, 0] + q[b, :, 0] + 2 * np.repeat(gam, 2) * x[b, :, 0]
+        assert np.abs(stat).max() < 1e-4
+
+
+def _fd(fun, arr, h):
+    out = np.zeros_like(arr)
+    it = np.nditer(arr, flags=["multi_index"])
+    for _ in it:
+        i = it.multi_index
+        a, b = arr.copy(), arr.copy()
+        a[i] += h
+        b[i] -= h
+        out[i] = (fun(a) - fun(b)) / (2 * h)
+    return out
+
+
+def test_qp_dense_fd_gradients(oracle):
+    d = make_problem("qp", 4, 4, 31, "dense")
+    for b in range(4):
+        P, q, g = d["P"][b].numpy(), d["q"][b, :, 0].numpy(), d["grad_x"][b, :, 0].numpy()
+        x = oracle.solveQP(P, q, None, 1e-13, 1e-7, 100000)
+        bl = oracle.solveDerivativesQP(P, q, x, g)
+        fq = _fd(lambda qq: g @ oracle.solveQP(P, qq, None, 1e-13, 1e-7, 100000), q, 1e-6)
+        assert np.allclose(-bl, fq, atol=2e-4, rtol=1e-3)
+        # The factorisation reads only the lower triangle of P (Eigen LLT, Solver.cpp:76), so P is
+        # perturbed symmetrically and compared with grad_P[i,j] + grad_P[j,i].
+        gP = -np.outer(bl, x)
+        for i in range(4):
+            for j in range(i + 1):
+                e = np.zeros((4, 4))
+                e[i, j] = e[j, i] = 1e-6
+                fd = (g @ oracle.solveQP(P + e, q, None, 1e-13, 1e-7, 100000)
+                      - g @ oracle.solveQP(P - e, q, None, 1e-13, 1e-7, 100000)) / 2e-6
+                an = gP[i, i] if i == j else gP[i, j] + gP[j, i]
+                assert abs(fd - an) < 2e-4 + 1e-3 * abs(an), (i, j, fd, an)
+
+
+def test_qcqp_fd_gradients(oracle):
+    """QCQP backward.  The reference solves the differentiated KKT system A^T b = [0; g] only in the
+    Tikhonov sense, b = (A A^T + 1e-7 I)^-1 A [0; g] iterated 1 or 3 times (Solver.cpp:15-44), which is
+    visibly inexact once cond(A)^2 * 1e-7 is not small.  So the check is split:
+      (1) the restated KKT matrix is right: an EXACT solve with it matches finite differences;
+      (2) the oracle output equals that (iterated) Tikhonov solution, and E1/E2 scale dgamma."""
+    d = make_problem("qcqp", 4, 4, 32, "dense")
+    n, nc = 4, 2
+    for b in range(4):
+        P, q, g = d["P"][b].numpy(), d["q"][b, :, 0].numpy(), d["grad_x"][b, :, 0].numpy()
+        ln, mu = d["l_n"][b, :, 0].numpy() * 0.3, d["mu"][b, :, 0].numpy()
+        sol = lambda PP, qq, ll, mm: oracle.solveQCQP(PP, qq, ll, mm, None, 1e-13, 1e-7, 100000)
+        x = sol(P, q, ln, mu)
+        E1, E2, blg, steps, gam = oracle.solveDerivativesQCQP(P, q, ln, mu, x, g, return_steps=True)
+        r = ln * mu
+        S = np.array([x[2 * i] ** 2 + x[2 * i + 1] ** 2 - r[i] ** 2 for i in range(nc)])
+        act = [i for i in range(nc) if S[i] > -1e-10 and r[i] > 1e-10]
+        na = len(act)
+        A = np.zeros((n + na, n + na))
+        for k, c in enumerate(act):
+            A[k, k] = S[c]
+            A[k, na + 2 * c: na + 2 * c + 2] = gam[c] * 2 * x[2 * c: 2 * c + 2]
+            A[na + 2 * c: na + 2 * c + 2, k] = 2 * x[2 * c: 2 * c + 2]
+        A[na:, na:] = P + np.diag(2 * np.repeat(gam, 2))
+        rhs = np.concatenate([np.zeros(na), g])
+        # (1) exact solve vs finite differences
+        bex = np.linalg.solve(A.T, rhs)
+        dgam_ex = np.zeros(nc)
+        dgam_ex[act] = bex[:na]
+        assert np.allclose(-bex[na:], _fd(lambda qq: g @ sol(P, qq, ln, mu), q, 1e-6), atol=2e-5, rtol=2e-3)
+        assert np.allclose(np.diag(E2) * dgam_ex, _fd(lambda ll: g @ sol(P, q, ll, mu), ln, 1e-6), atol=2e-5, rtol=2e-3)
+        assert np.allclose(np.diag(E1) * dgam_ex, _fd(lambda mm: g @ sol(P, q, ln, mm), mu, 1e-6), atol=2e-5, rtol=2e-3)
+        # (2) the oracle is the iterated Tikhonov solve
+        K = A @ A.T + 1e-7 * np.eye(n + na)
+        xs = np.zeros(n + na)
+        for _ in range(steps):
+            xs = np.linalg.solve(K, 1e-7 * xs + A @ rhs)
+        ref = np.zeros(nc + n)
+        ref[act] = xs[:na]
+        ref[nc:] = xs[na:]
+        assert np.allclose(blg, ref, rtol=1e-6, atol=1e-12)
+        assert np.allclose(np.diag(E1), 2 * gam * ln * ln * mu) and np.allclose(np.diag(E2), 2 * gam * ln * mu * mu)
+
+
+def test_warm_start_is_dead(oracle):
+    """Solver.cpp:70 then :80 -- the argument cannot change the result."""
+    d = make_problem("qp", 1, 8, 41, "dense")
+    P, q = d["P"][0].numpy(), d["q"][0].numpy()
+    a = oracle.solveQP(P, q, np.zeros(8), 1e-8, 1e-7, 1000)
+    b = oracle.solveQP(P, q, np.random.default_rng(0).normal(size=8), 1e-8, 1e-7, 1000)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))), ids=os.path.basename)
+def test_oracle_reproduces_golden(oracle, path):
+    """The committed fixtures are what the oracle computes (here and on the GPU box's host)."""
+    d = np.load(path)
+    eps, mi = float(d["eps"]), int(d["max_iter"])
+    if "l_n" in d.files:
+        x, it = oracle.qcqp_fwd_batch(d["P"], d["q"], d["l_n"], d["mu"], eps, mi)
+        gP, gq, gl, gm, st = oracle.qcqp_bwd_batch(d["P"], d["q"], d["l_n"], d["mu"], d["x"], d["grad_x"])
+        assert np.allclose(gl, d["grad_l_n"], rtol=1e-9, atol=1e-12) and np.allclose(gm, d["grad_mu"], rtol=1e-9, atol=1e-12)
+    else:
+        x, it = oracle.qp_fwd_batch(d["P"], d["q"], eps, mi)
+        gP, gq, st = oracle.qp_bwd_batch(d["P"], d["q"], d["x"], d["grad_x"])
+    # libm pow() may differ by an ulp between hosts; everything else is IEEE-exact
+    assert np.array_equal(it, d["iters"])
+    assert np.allclose(x, d["x"], rtol=0, atol=1e-11)
+    assert np.array_equal(st, d["ir_steps"])
+    assert np.allclose(gP, d["grad_P"], rtol=1e-9, atol=1e-12) and np.allclose(gq, d["grad_q"], rtol=1e-9, atol=1e-12)
+
+
+def test_oracle_openmp_matches_serial(oracle):
+    d = make_problem("qcqp", 257, 8, 51)
+    a = oracle.qcqp_fwd_batch(d["P"].numpy(), d["q"].numpy(), d["l_n"].numpy(), d["mu"].numpy(), 1e-7, 1000, nthreads=1)
+    b = oracle.qcqp_fwd_batch(d["P"].numpy(), d["q"].numpy(), d["l_n"].numpy(), d["mu"].numpy(), 1e-7, 1000, nthreads=4)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

@@ -1,0 +1,70 @@
+"""world_size-2 (and 3) gloo tests of the batch-sharding layer on CPU tensors:
+shard -> per-rank solve -> all-gather must reproduce the single-process result.
+The per-rank solve here is the oracle (test infrastructure); on the GPU box the
+same `parallel` functions wrap the HIP ops over RCCL (bench.py --gpus N)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, B, q_out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import make_problem
+    from diffqcqp_amd import parallel
+    from oracle import oracle as O
+    d = make_problem("qp", B, 8, 99)
+    lo, hi = parallel.shard_bounds(B, rank, world)
+
+    def solve(P, q):
+        x, _ = O.qp_fwd_batch(P.numpy(), q.numpy(), 1e-7, 1000)
+        return torch.from_numpy(x)
+
+    x_full = parallel.solve_sharded(solve, (d["P"], d["q"]), B)
+    x_local = parallel.solve_sharded(solve, (d["P"], d["q"]), B, gather=False)
+    assert x_local.shape[0] == hi - lo
+    assert torch.equal(x_full[lo:hi], x_local)
+    assert torch.equal(parallel.shard(d["q"]), d["q"][lo:hi])
+    if rank == 0:
+        q_out.put(x_full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,B", [(2, 64), (2, 37), (3, 10)])
+def test_shard_solve_gather_matches_single_process(oracle, world, B):
+    from conftest import make_problem
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + world * 7 + B
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, q_out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q_out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    d = make_problem("qp", B, 8, 99)
+    ref, _ = oracle.qp_fwd_batch(d["P"].numpy(), d["q"].numpy(), 1e-7, 1000)
+    assert np.array_equal(got, ref)
+
+
+def test_shard_bounds_cover_batch():
+    from diffqcqp_amd.parallel import shard_bounds
+    for B in (0, 1, 7, 8, 65536, 262144 + 3):
+        for world in (1, 2, 4, 8):
+            edges = [shard_bounds(B, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == B
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in edges]
+            assert max(sizes) - min(sizes) <= 1
