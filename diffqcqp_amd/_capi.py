@@ -6,6 +6,11 @@ raises -- there is no CPU or PyTorch fallback behind it.
 import ctypes
 import os
 
+# torch ships its own libamdhip64.so; it must be the HIP runtime of the process.  Loading our library
+# first would pull in /opt/rocm's copy and give the two halves of the process different runtimes
+# (launches then fail with hipErrorNoDevice), so torch is imported before the library is opened.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdiffqcqp_hip.so")
 

@@ -18,7 +18,12 @@
 // inside the 1e-6 parity tolerance; the trajectory -- rho schedule, iteration
 // count -- is unchanged, tests/ check that): 1/M instead of (1/sqrt(M))/sqrt(M);
 // u*(1/rho) instead of u/rho; power-iteration normalisation by a reciprocal;
-// compiler FMA contraction; group (tree) sums when LPP > 1.
+// compiler FMA contraction; group (tree) sums when LPP > 1; 1-ulp reciprocal /
+// reciprocal-square-root (common.h fast_rcp / fast_rsqrt) in place of IEEE divide
+// and sqrt in the power iteration, the disk projection and the rho updates.
+// Failure signalling: the reference's LLT of a non-positive shifted diagonal
+// yields NaNs (Solver.cpp:76, never checked); here a non-positive M or a
+// non-finite rho poisons the output with NaN explicitly.
 #pragma once
 
 #include "common.h"
@@ -56,7 +61,7 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
         for (int e = 0; e < E; ++e) { v[e] = p[e] * v[e]; s += v[e] * v[e]; }
         s = G::sum(s);
         if (s > 0) {
-            const double inv = 1.0 / sqrt(s);
+            const double inv = fast_rsqrt(s);
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] = v[e] * inv;
         }
@@ -69,11 +74,13 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
     // ---- Solver.cpp:72-77 / 531-536
     double rho = sqrt(mu * L) * pow(L / mu, .4);
     double tau_inc = pow(L / mu, .15), tau_dec = tau_inc;
-    double inv_rho = 1.0 / rho;
+    double inv_rho = fast_rcp(rho);
+    bool bad = !(rho > 0.0) || !(rho < 1.79e308);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         M[e] = p[e] + (rho + mu);
-        Minv[e] = 1.0 / M[e];
+        bad = bad || !(M[e] > 0.0);
+        Minv[e] = fast_rcp(M[e]);
         qp[e] = q[e];
         l2[e] = 0.0;
         u[e] = 0.0;
@@ -95,15 +102,18 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
             }
             if (KIND == 0) {
 #pragma unroll
-                for (int e = 0; e < E; ++e) z[e] = z[e] < 0 ? 0 : z[e];       // cwiseMax(0), :82
+                for (int e = 0; e < E; ++e) z[e] = fmax(z[e], 0.0);           // cwiseMax(0), :82
             } else {
 #pragma unroll
                 for (int c = 0; c < E / 2; ++c) {                             // prox_circle, :505-519
                     const double a = z[2 * c], b = z[2 * c + 1];
-                    const double nrm = sqrt(a * a + b * b);
+                    const double n2 = a * a + b * b;
+                    const double rn = fast_rsqrt(n2);      // n2 == 0: inf -> nrm NaN -> no scaling
+                    const double nrm = n2 * rn;
                     if (nrm > rad[c]) {
-                        z[2 * c] = a * rad[c] / nrm;
-                        z[2 * c + 1] = b * rad[c] / nrm;
+                        const double sc = rad[c] * rn;
+                        z[2 * c] = a * sc;
+                        z[2 * c + 1] = b * sc;
                     }
                 }
             }
@@ -154,19 +164,21 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
                     cpt++;
                 }
                 if (upd) {   // the reference's llt() + solveInPlace(Identity), diagonal case
-                    inv_rho = 1.0 / rho;
+                    inv_rho = fast_rcp(rho);
 #pragma unroll
                     for (int e = 0; e < E; ++e) {
                         M[e] += delta;
-                        Minv[e] = 1.0 / M[e];
+                        bad = bad || !(M[e] > 0.0);
+                        Minv[e] = fast_rcp(M[e]);
                     }
                 }
             }
         }
         if (G::wave_all(done)) break;
     }
+    bad = G::max(bad ? 1.0 : 0.0) > 0.0;
 #pragma unroll
-    for (int e = 0; e < E; ++e) x[e] = l2[e];
+    for (int e = 0; e < E; ++e) x[e] = bad ? NAN : l2[e];
     return iters;
 }
 

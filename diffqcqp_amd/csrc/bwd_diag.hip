@@ -21,6 +21,7 @@
 // Compile with -ffp-contract=off (see kkt_core.h).
 #include "kkt_core.h"
 #include "launch.h"
+#include "stream_tile.h"
 
 namespace dqq {
 
@@ -54,26 +55,8 @@ __global__ __launch_bounds__(64 * WPB) void bwd_diag_kernel(
         pv = valid ? *reinterpret_cast<const double2*>(P + first * N + 2 * lane) : make_double2(1.0, 1.0);
     } else {
         const double* Pw = P + first * (long)(N * N);
-        unsigned nz = 0;
-        constexpr int U = N < 8 ? N : 8;
-        for (int k0 = 0; k0 < N; k0 += U) {
-            double2 v[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int f = (k0 + u) * 128 + 2 * lane;
-                v[u] = f < limit ? *reinterpret_cast<const double2*>(Pw + f) : make_double2(0.0, 0.0);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int f = (k0 + u) * 128 + 2 * lane;
-                const int row = f / N;           // == prob*N + r  (T*N == 128 rows in the tile)
-                const int r = row % N, c = f % N;
-                const unsigned b0 = nonzero_bits(v[u].x), b1 = nonzero_bits(v[u].y);
-                if (c == r) { pd[row] = v[u].x; nz |= b1; }
-                else if (c + 1 == r) { pd[row] = v[u].y; nz |= b0; }
-                else nz |= b0 | b1;
-            }
-        }
+        const unsigned nz = (nvalid == T) ? stream_tile_diag<N, N, false>(Pw, limit, pd, lane)
+                                          : stream_tile_diag<N, N, true>(Pw, limit, pd, lane);
         if (__any(nz != 0)) { // wave-uniform: hand the tile to the dense kernel
             int base = 0;
             if (lane == 0) base = atomicAdd(&ws[kWsCount], nvalid);

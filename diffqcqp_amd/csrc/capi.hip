@@ -67,6 +67,7 @@ int dqq_get_option(const char* name, int* value)
 static int fwd_dispatch(int kind, dqq::FwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t s)
 {
     if (a.B == 0) return 0;
+    (void)hipGetLastError(); // drop any stale error of the calling thread: ours are read after each launch
     const bool fast_ok = dqq::fwd_diag_supported(a.N);
     const bool dense_ok = a.N <= dqq::dense_max_n(kind);
     hipError_t e;
@@ -92,6 +93,7 @@ static int fwd_dispatch(int kind, dqq::FwdArgs& a, void* workspace, size_t works
 static int bwd_dispatch(int kind, dqq::BwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t s)
 {
     if (a.B == 0) return 0;
+    (void)hipGetLastError();
     const bool fast_ok = dqq::bwd_diag_supported(a.N);
     const bool dense_ok = a.N <= dqq::dense_max_n(kind == 0 ? 0 : 2);
     hipError_t e;

@@ -86,10 +86,13 @@ static DQQ_D void load_matrix(double* dst, int ld, const double* __restrict__ sr
     for (int idx = lane; idx < n * n; idx += 64) dst[(idx / n) * ld + idx % n] = src[idx];
 }
 
-// Last workgroup out re-zeroes the work-list header for the next call.
-static DQQ_D void worklist_release(int* ws, int lane)
+// Last workgroup out re-zeroes the work-list header for the next call.  With an
+// empty work-list (the common case: every tile was diagonal) there is nothing to
+// reset and no workgroup touches the ticket -- 1024 same-address atomics would
+// otherwise serialise into ~13 us of an otherwise empty launch.
+static DQQ_D void worklist_release(int* ws, int lane, long count)
 {
-    if (lane == 0) {
+    if (count > 0 && lane == 0) {
         const int t = atomicAdd(&ws[kWsTicket], 1);
         if (t == (int)gridDim.x - 1) {
             ws[kWsCount] = 0;
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(64) void fwd_dense_kernel(const double* __restrict_
         if (iters != nullptr && lane == 0) iters[prob] = it_done;
         DQQ_SYNC();
     }
-    if (use_worklist) worklist_release(ws, lane);
+    if (use_worklist) worklist_release(ws, lane, count);
 }
 
 // ----------------------------------------------------------------- backward
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(64) void bwd_dense_kernel(
         if (ir_steps != nullptr && lane == 0) ir_steps[prob] = steps;
         DQQ_SYNC();
     }
-    if (use_worklist) worklist_release(ws, lane);
+    if (use_worklist) worklist_release(ws, lane, count);
 }
 
 // ---------------------------------------------------------------- launchers

@@ -16,6 +16,7 @@
 // dense kernel (dense.hip) drains right after this launch.
 #include "admm_core.h"
 #include "launch.h"
+#include "stream_tile.h"
 
 namespace dqq {
 
@@ -55,26 +56,8 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
         const double* Pw = P + first * (long)(N * N);
         const int limit = nvalid * N * N; // doubles of P that belong to this tile
         double* sd = s_diag[wave];
-        unsigned nz = 0;
-        constexpr int U = NCH < 8 ? NCH : 8;
-        for (int k0 = 0; k0 < NCH; k0 += U) {
-            double2 v[U];
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const int f = (k0 + j) * 128 + 2 * lane;
-                v[j] = f < limit ? *reinterpret_cast<const double2*>(Pw + f) : make_double2(0.0, 0.0);
-            }
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const int f = (k0 + j) * 128 + 2 * lane;
-                const int prob = f / (N * N), rem = f % (N * N);
-                const int r = rem / N, c = rem % N; // c is even; (r,c) and (r,c+1) are this lane's entries
-                const unsigned b0 = nonzero_bits(v[j].x), b1 = nonzero_bits(v[j].y);
-                if (c == r) { sd[prob * N + r] = v[j].x; nz |= b1; }
-                else if (c + 1 == r) { sd[prob * N + r] = v[j].y; nz |= b0; }
-                else nz |= b0 | b1;
-            }
-        }
+        const unsigned nz = (nvalid == PPW) ? stream_tile_diag<N, NCH, false>(Pw, limit, sd, lane)
+                                            : stream_tile_diag<N, NCH, true>(Pw, limit, sd, lane);
         if (__any(nz != 0)) { // wave-uniform: hand the tile to the dense kernel
             int base = 0;
             if (lane == 0) base = atomicAdd(&ws[kWsCount], nvalid);
@@ -133,22 +116,38 @@ static hipError_t launch_wpb(const FwdArgs& a, int wpb, hipStream_t s)
     return launch_one<KIND, N, LPP, 4>(a, s);
 }
 
-// Built-in lanes-per-problem choice (E = N/LPP coordinates per lane); see
-// DESIGN.md for the measurements behind it.
-int fwd_diag_default_lpp(int N)
+// Lanes-per-problem choices the kernel is instantiated for (E = N/LPP coordinates per lane,
+// E even and <= 8), smallest first.
+static const int* lpp_choices(int N, int& count)
 {
+    static const int c2[] = {1}, c4[] = {1, 2}, c8[] = {1, 2, 4}, c16[] = {2, 4, 8}, c32[] = {4, 8, 16},
+                     c64[] = {8, 16, 32};
     switch (N) {
-    case 2: return 1;
-    case 4: return 1;
-    case 8: return 2;
-    case 16: return 4;
-    case 32: return 8;
-    case 64: return 16;
-    default: return 0;
+    case 2: count = 1; return c2;
+    case 4: count = 2; return c4;
+    case 8: count = 3; return c8;
+    case 16: count = 3; return c16;
+    case 32: count = 3; return c32;
+    case 64: count = 3; return c64;
+    default: count = 0; return nullptr;
     }
 }
 
-bool fwd_diag_supported(int N) { return fwd_diag_default_lpp(N) != 0; }
+// Built-in choice.  Fewer lanes per problem = fewer VALU instructions per problem (the scalar
+// rho/tau/stop logic and the pow() prologue are replicated on every lane of a problem), but the
+// kernel is latency-bound with a single wave per SIMD, so take the smallest LPP that still puts
+// about two waves on each of the chip's 1024 SIMDs (measurements: DESIGN.md).
+int fwd_diag_default_lpp(int N, long B)
+{
+    int count = 0;
+    const int* c = lpp_choices(N, count);
+    if (count == 0) return 0;
+    for (int i = 0; i < count; ++i)
+        if (B * c[i] / 64 >= 2048) return c[i];
+    return c[count - 1];
+}
+
+bool fwd_diag_supported(int N) { return fwd_diag_default_lpp(N, 1) != 0; }
 
 template <int KIND>
 static bool launch_kind(const FwdArgs& a, int lpp, int wpb, hipStream_t s, hipError_t& err)
@@ -170,11 +169,11 @@ static bool launch_kind(const FwdArgs& a, int lpp, int wpb, hipStream_t s, hipEr
 hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, hipStream_t s)
 {
     if (wpb != 1 && wpb != 4) wpb = 4;
-    if (lpp <= 0) lpp = fwd_diag_default_lpp(a.N);
+    if (lpp <= 0) lpp = fwd_diag_default_lpp(a.N, a.B);
     hipError_t e = hipErrorInvalidValue;
     bool found = kind == 0 ? launch_kind<0>(a, lpp, wpb, s, e) : launch_kind<1>(a, lpp, wpb, s, e);
     if (!found) {
-        lpp = fwd_diag_default_lpp(a.N);
+        lpp = fwd_diag_default_lpp(a.N, a.B);
         found = kind == 0 ? launch_kind<0>(a, lpp, wpb, s, e) : launch_kind<1>(a, lpp, wpb, s, e);
     }
     return found ? e : hipErrorInvalidValue;

@@ -48,7 +48,7 @@ struct BwdArgs {
 
 // diagonal fast paths (fwd_diag.hip, bwd_diag.hip)
 bool fwd_diag_supported(int N);
-int fwd_diag_default_lpp(int N);
+int fwd_diag_default_lpp(int N, long B);
 hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, hipStream_t s);
 bool bwd_diag_supported(int N);
 hipError_t launch_bwd_diag(int kind, const BwdArgs& a, int wpb, hipStream_t s);

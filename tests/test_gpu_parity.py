@@ -8,8 +8,14 @@ Tolerances (float64):
              trajectories coincide (same iteration count) and the difference is ~1e-13, which the
              tests also assert through the median and the iteration-count match rate;
   gradients  with IDENTICAL x fed to both sides the backward is required to be bit-exact on the
-             diagonal fast path and within 1e-9 relative on the dense path; end to end (x from the
-             HIP forward) within 1e-6 relative to the gradient scale.
+             diagonal fast path and within 1e-9 relative on the dense path.  End to end (x from the
+             HIP forward, ~1e-15 away from the oracle's x) the QP gradients must agree to 1e-6 of the
+             gradient scale.  For the QCQP the reference's refinement loop (Solver.cpp:32-41) exits
+             after 1 or 3 Tikhonov steps depending on whether a residual that is pure rounding noise
+             is below 1e-10; a 2e-16 relative perturbation of x flips that decision on ~3-4% of the
+             problems IN THE ORACLE ITSELF and changes those gradients by up to tens of percent
+             (the two exits differ by mu*K^-1 x).  So end to end the QCQP gradients are compared on
+             the problems whose step count agrees (1e-6) and the flip rate is bounded (<= 8%).
 """
 import glob
 import os
@@ -80,6 +86,18 @@ def check_forward(xh, ith, xo, ito, min_match=0.999):
     assert np.median(diff.max(axis=(1, 2))) < 1e-11
 
 
+def check_end_to_end(grads, steps, ref, max_flip=0.08):
+    """x came from the HIP forward: compare where the refinement exit agrees (see module docstring)."""
+    *gref, sref = ref
+    same = npy(steps) == sref
+    assert 1.0 - same.mean() <= max_flip, "refinement exit differs on %.1f%% of the problems" % (100 * (1 - same.mean()))
+    for a, b in zip(grads, gref):
+        a, b = npy(a)[same], b[same]
+        if a.size:
+            scale = np.maximum(1.0, np.abs(b).reshape(b.shape[0], -1).max(1)).reshape((-1,) + (1,) * (b.ndim - 1))
+            assert (np.abs(a - b) / scale).max() <= 1e-6
+
+
 def check_backward_exact(grads, steps, ref, exact=True, rtol=1e-9):
     *gref, sref = ref
     assert np.array_equal(npy(steps), sref), "refinement step counts differ"
@@ -104,9 +122,8 @@ def test_diag_fast_path_matches_oracle(oracle, ops, kind, N, B):
     grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda())
     check_backward_exact(grads, st, oracle_bwd(oracle, kind, d, xo), exact=True)
     # end to end
-    grads2, _ = hip_bwd(ops, kind, g, xh)
-    for a, b in zip(grads2, oracle_bwd(oracle, kind, d, xo)[:-1]):
-        assert np.abs(npy(a) - b).max() <= 1e-6 * max(1.0, np.abs(b).max())
+    grads2, st2 = hip_bwd(ops, kind, g, xh)
+    check_end_to_end(grads2, st2, oracle_bwd(oracle, kind, d, xo), max_flip=0.0 if kind == "qp" else 0.08)
 
 
 @pytest.mark.parametrize("kind", ["qp", "qcqp"])
@@ -274,7 +291,14 @@ def test_autograd_functions_match_reference_contract(oracle, ops):
     xo, _ = oracle_fwd(oracle, "qcqp", d)
     ref = oracle_bwd(oracle, "qcqp", d, xo)
     for t, r in zip((P, q, l_n, mu), ref[:-1]):
-        assert t.grad.shape == r.shape and np.abs(npy(t.grad) - r).max() <= 1e-6 * max(1.0, np.abs(r).max())
+        assert t.grad.shape == r.shape
+    # the autograd path is the ops path: same numbers as calling the backward op on the saved x
+    direct = ops.qcqp_backward(P.detach(), q.detach(), l_n.detach(), mu.detach(), x.detach(), d["grad_x"].cuda())
+    for t, r in zip((P, q, l_n, mu), direct):
+        assert torch.equal(t.grad, r)
+    _, _, _, _, st = ops.qcqp_backward(P.detach(), q.detach(), l_n.detach(), mu.detach(), x.detach(),
+                                       d["grad_x"].cuda(), return_steps=True)
+    check_end_to_end([P.grad, q.grad, l_n.grad, mu.grad], st, ref)
     # QP, only q requires grad, warm_start has no effect and gets no grad; CPU tensors are staged via the GPU
     dq = make_problem("qp", 10, 8, 902)
     Pc, qc = dq["P"], dq["q"].clone().requires_grad_(True)

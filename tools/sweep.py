@@ -34,7 +34,7 @@ def timeit(fn, reps=50):
 
 
 def main():
-    shapes = [(8, 65536), (32, 32768)]
+    shapes = [(8, 16384), (8, 65536), (8, 262144), (32, 32768)]
     if len(sys.argv) > 2:
         shapes = [(int(sys.argv[i]), int(sys.argv[i + 1])) for i in range(1, len(sys.argv) - 1, 2)]
     _capi.set_option("auto_fallback", 0)
