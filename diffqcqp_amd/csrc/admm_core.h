@@ -16,8 +16,9 @@
 //
 // Deliberate ulp-level departures from the dense reference arithmetic (all far
 // inside the 1e-6 parity tolerance; the trajectory -- rho schedule, iteration
-// count -- is unchanged, tests/ check that): 1/M instead of (1/sqrt(M))/sqrt(M);
-// u*(1/rho) instead of u/rho; power-iteration normalisation by a reciprocal;
+// count -- is unchanged, tests/ check that): closed-form power iteration (below);
+// 1/M instead of (1/sqrt(M))/sqrt(M);
+// u*(1/rho) instead of u/rho;
 // compiler FMA contraction; group (tree) sums when LPP > 1; 1-ulp reciprocal /
 // reciprocal-square-root (common.h fast_rcp / fast_rsqrt) in place of IEEE divide
 // and sqrt in the power iteration, the disk projection and the rho updates.
@@ -39,37 +40,44 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
                          double mu, int max_iter, int adaptive, bool valid, double (&x)[E])
 {
     static_assert(E % 2 == 0, "E must be even");
-    double v[E], M[E], Minv[E], qp[E], l2[E], u[E];
+    double M[E], Minv[E], qp[E], l2[E], u[E];
 
-    // ---- power_iteration, Solver.cpp:46-59 (10 steps for QP :71, 100 for QCQP :530)
-    const int pi_steps = (KIND == 0) ? 10 : 100;
+    // ---- power_iteration, Solver.cpp:46-59 (K = 10 steps for QP :71, 100 for QCQP :530).
+    // For a diagonal P the K normalised steps from the uniform start vector give v ~ p^K, so the
+    // Rayleigh quotient the reference returns is  L = sum p^(2K+1) / sum p^(2K)  (the per-step
+    // normalisations only rescale v).  Evaluated by repeated squaring on p scaled by an exact power
+    // of two so that nothing overflows; ~1e-15 relative to the iterated value.
+    double L;
     {
-        const double c = 1.0 / sqrt((double)n);
-        double s = 0.0;
+        double m = 0.0;
 #pragma unroll
-        for (int e = 0; e < E; ++e) { v[e] = c; s += c * c; }
-        s = G::sum(s);
-        if (s > 0) {
-            const double nn = sqrt(s);
+        for (int e = 0; e < E; ++e) m = fmax(m, fabs(p[e]));
+        m = G::max(m);
+        if (m > 0.0 && m < 1.79e308) {
+            int k;
+            (void)frexp(m, &k);
+            double num = 0.0, den = 0.0;
 #pragma unroll
-            for (int e = 0; e < E; ++e) v[e] = v[e] / nn;
+            for (int e = 0; e < E; ++e) {
+                const double s1 = ldexp(p[e], -k); // |s1| < 1, the largest is >= 0.5
+                const double s2 = s1 * s1, s4 = s2 * s2, s8 = s4 * s4, s16 = s8 * s8;
+                double a; // s1^(2K)
+                if (KIND == 0) {
+                    a = s16 * s4;                                   // ^20
+                } else {
+                    const double s32 = s16 * s16, s64 = s32 * s32, s128 = s64 * s64;
+                    a = (s128 * s64) * s8;                          // ^200
+                }
+                den += a;
+                num += a * s1;
+            }
+            num = G::sum(num);
+            den = G::sum(den);
+            L = ldexp(num / den, k);
+        } else {
+            L = (m > 0.0) ? NAN : 0.0; // P == 0 -> L = 0 (rho = 0 -> NaN, as in the reference); inf/NaN -> NaN
         }
     }
-    for (int k = 0; k < pi_steps; ++k) {
-        double s = 0.0;
-#pragma unroll
-        for (int e = 0; e < E; ++e) { v[e] = p[e] * v[e]; s += v[e] * v[e]; }
-        s = G::sum(s);
-        if (s > 0) {
-            const double inv = fast_rsqrt(s);
-#pragma unroll
-            for (int e = 0; e < E; ++e) v[e] = v[e] * inv;
-        }
-    }
-    double L = 0.0;
-#pragma unroll
-    for (int e = 0; e < E; ++e) L += v[e] * (p[e] * v[e]);
-    L = G::sum(L);
 
     // ---- Solver.cpp:72-77 / 531-536
     double rho = sqrt(mu * L) * pow(L / mu, .4);
@@ -133,38 +141,28 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
             if (KIND == 1) {
                 if (stop) stop = res_prim < eps + kEpsRel * sqrt(G::sum(nl)); // :548
             }
-            if (stop) {
-                done = true;
-            } else if (adaptive) {
-                bool upd = false;
-                double delta = 0.0;
-                if (res_prim > kMuThresh * res_dual) {                        // :92 / :552
-                    if (cpt % 5 == 0) {
-                        if (rho_up == -1) {
-                            tau_inc = 1 + .8 * (tau_inc - 1);
-                            if (KIND == 0) tau_dec = 1 + .8 * (tau_dec - 1);  // :94-97 (QP damps both)
-                        }
-                        delta = rho * (tau_inc - 1);                          // :98 / :557
-                        rho *= tau_inc;
-                        rho_up = 1;
-                        upd = true;
+            done = stop;
+            if (!stop && adaptive) {
+                // rho adaptation, Solver.cpp:90-120 / 550-580: increase when the primal residual dominates,
+                // decrease when the dual one does, at most once every 5 imbalanced iterations.
+                const bool inc = res_prim > kMuThresh * res_dual;             // :92 / :552
+                const bool dec = !inc && (res_dual > kMuThresh * res_prim);   // :106 / :566
+                const bool imb = inc || dec;
+                const bool fire = imb && (cpt == 0);                          // cpt % 5 == 0
+                cpt = imb ? (cpt == 4 ? 0 : cpt + 1) : cpt;                   // cpt++ (kept mod 5)
+                if (fire) {
+                    if (rho_up == (inc ? -1 : 1)) {                           // direction flipped: damp tau
+                        const double ti = 1 + .8 * (tau_inc - 1), td = 1 + .8 * (tau_dec - 1);
+                        if (KIND == 0) { tau_inc = ti; tau_dec = td; }        // :94-97, :108-111 (QP damps both)
+                        else if (inc) tau_inc = ti;                           // :554-556
+                        else tau_dec = td;                                    // :568-570
                     }
-                    cpt++;
-                } else if (res_dual > kMuThresh * res_prim) {                 // :106 / :566
-                    if (cpt % 5 == 0) {
-                        if (rho_up == 1) {
-                            if (KIND == 0) tau_inc = 1 + .8 * (tau_inc - 1);  // :108-111 (QP damps both)
-                            tau_dec = 1 + .8 * (tau_dec - 1);
-                        }
-                        delta = rho * (1. / tau_dec - 1);                     // :112 / :571
-                        rho /= tau_dec;
-                        rho_up = -1;
-                        upd = true;
-                    }
-                    cpt++;
-                }
-                if (upd) {   // the reference's llt() + solveInPlace(Identity), diagonal case
+                    const double f = inc ? tau_inc : fast_rcp(tau_dec);       // rho *= tau_inc | rho /= tau_dec
+                    const double delta = rho * (f - 1);                       // :98 / :112
+                    rho = rho * f;                                            // :99 / :113
+                    rho_up = inc ? 1 : -1;
                     inv_rho = fast_rcp(rho);
+                    // llt() + solveInPlace(Identity) of the shifted matrix, diagonal case (:100-101)
 #pragma unroll
                     for (int e = 0; e < E; ++e) {
                         M[e] += delta;
