@@ -455,7 +455,9 @@ static unsigned dense_grid(long B, bool use_worklist)
 {
     // persistent: enough single-wave workgroups to fill the chip, each loops over problems
     const long cap = 256L * 16;
-    if (use_worklist) return 1024;
+    // work-list mode: the size of the list is only known on the device; 512 single-wave workgroups loop
+    // over it (an empty list -- every tile was diagonal -- costs one short launch)
+    if (use_worklist) return 512;
     return (unsigned)(B < cap ? (B > 0 ? B : 1) : cap);
 }
 

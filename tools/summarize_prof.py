@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 output databases (rocpd sqlite) into the small summaries kept under profiles/.
+
+    python tools/summarize_prof.py <kernel_trace.db> <sq_pmc.db> <fetch_pmc.db> <write_pmc.db> <outdir> <tag>
+
+Writes  <outdir>/<tag>_kernel_stats.csv   per-kernel calls / mean / min / max duration (ns) and share
+        <outdir>/<tag>_pmc.json           per-kernel mean counter values per launch + derived HBM bytes
+        <outdir>/pmc_latest.json          the same HBM traffic keyed by bench.py's launch names
+HBM traffic per launch = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024: FETCH_SIZE/WRITE_SIZE are in KiB and,
+on gfx950 with this rocprofv3, FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane)
+coalesced streaming read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE matched the known store
+volume of these kernels without correction.
+"""
+import csv
+import json
+import os
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    m = re.search(r"dqq::(\w+)<([^>]*)>", name)
+    if m:
+        return "%s<%s>" % (m.group(1), m.group(2).replace(" ", ""))
+    return name.split("(")[0][:80]
+
+
+def bench_key(s):
+    for pat, key in (("fwd_diag_kernel<0", "qp_fwd"), ("fwd_diag_kernel<1", "qcqp_fwd"),
+                     ("bwd_diag_kernel<0", "qp_bwd"), ("bwd_diag_kernel<1", "qcqp_bwd")):
+        if s.startswith(pat):
+            return key
+    return None
+
+
+def main():
+    kt, sq, fe, wr, outdir, tag = sys.argv[1:7]
+    os.makedirs(outdir, exist_ok=True)
+    c = sqlite3.connect(kt)
+    rows = c.execute("select name, count(*), avg(end-start), min(end-start), max(end-start), sum(end-start) "
+                     "from kernels group by name order by 6 desc").fetchall()
+    tot = sum(r[5] for r in rows) or 1
+    with open(os.path.join(outdir, tag + "_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "mean_ns", "min_ns", "max_ns", "total_ns", "percent"])
+        for r in rows:
+            w.writerow([short(r[0]), r[1], "%.0f" % r[2], r[3], r[4], r[5], "%.2f" % (100.0 * r[5] / tot)])
+    pmc = {}
+    for db in (sq, fe, wr):
+        if not os.path.exists(db):
+            continue
+        c = sqlite3.connect(db)
+        for name, counter, val, n in c.execute("select kernel_name, counter_name, avg(value), count(*) "
+                                               "from counters_collection group by kernel_name, counter_name"):
+            pmc.setdefault(short(name), {})[counter] = val
+    latest = {}
+    for k, v in pmc.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            v["hbm_bytes_per_launch"] = 2.0 * v["FETCH_SIZE"] * 1024 + v["WRITE_SIZE"] * 1024
+            v["hbm_read_bytes_per_launch"] = 2.0 * v["FETCH_SIZE"] * 1024
+            v["hbm_write_bytes_per_launch"] = v["WRITE_SIZE"] * 1024
+        if "SQ_INSTS_VALU" in v and v.get("SQ_WAVES"):
+            v["valu_insts_per_wave"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"]
+        key = bench_key(k)
+        if key and "hbm_bytes_per_launch" in v:
+            latest[key] = {"kernel": k, "hbm_bytes_per_launch": v["hbm_bytes_per_launch"]}
+    json.dump(pmc, open(os.path.join(outdir, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
+    json.dump(latest, open(os.path.join(outdir, "pmc_latest.json"), "w"), indent=1, sort_keys=True)
+    for r in rows[:10]:
+        print("%-46s calls %5d mean %9.2f us  %5.1f%%" % (short(r[0]), r[1], r[2] / 1e3, 100.0 * r[5] / tot))
+
+
+if __name__ == "__main__":
+    main()
