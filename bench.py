@@ -167,6 +167,12 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     args = ap.parse_args()
 
+    # Everything the native libraries print on stdout (RCCL prints its version banner there) goes to
+    # stderr; the one JSON line is written to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -179,14 +185,19 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
-    if world > 1:
+    # DQQ_BENCH_FORCE_DIST=1 exercises the RCCL path (init, barrier, all-gather) with a single rank
+    use_dist = world > 1 or os.environ.get("DQQ_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)  # RCCL
 
     from diffqcqp_amd import build, _capi, parallel
     if rank == 0:
         build.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     _capi.lib()
 
@@ -197,14 +208,14 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     # ---- warm-up (also warms RCCL's all-gather)
     for _ in range(max(args.warmup, 1)):
         plan.step(sh)
-    if world > 1:
+    if use_dist:
         parallel.gather_batch(plan.x_qcqp, B_PER_GPU * world)
     graph = None
     if args.graph:
@@ -226,7 +237,7 @@ def main():
         for _ in range(args.steps):
             plan.step(sh)
     gather_ms = None
-    if world > 1:
+    if use_dist:
         torch.cuda.synchronize()
         tg = time.perf_counter()
         x_all = parallel.gather_batch(plan.x_qcqp, B_PER_GPU * world)
@@ -235,7 +246,7 @@ def main():
         assert x_all.shape[0] == B_PER_GPU * world
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -280,9 +291,8 @@ def main():
     }
 
     if rank != 0:
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()
         return
 
     solves = 2 * B_PER_GPU * world * args.steps
@@ -310,8 +320,8 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(host)
         out["gpu_over_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["value"]
-    print(json.dumps(out), flush=True)
-    if world > 1:
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -16,16 +16,17 @@
 //            entry order, so the loop exit is bit-identical to a dense solve;
 //   phase C  stream grad_P = -dl x^T back with the access pattern of phase A
 //            (dl and x are picked out of LDS).
-// Tiles with a non-zero off-diagonal are queued for the general dense kernel.
+// Tiles with a non-zero off-diagonal: N <= 8 -> solved in place by the general per-problem routine
+// (dense_core.h); larger N -> queued for the general dense kernel.
 //
 // Compile with -ffp-contract=off (see kkt_core.h).
-#include "kkt_core.h"
+#include "dense_core.h"
 #include "launch.h"
 #include "stream_tile.h"
 
 namespace dqq {
 
-template <int KIND, int N, int WPB>
+template <int KIND, int N, int WPB, bool FUSE>
 __global__ __launch_bounds__(64 * WPB) void bwd_diag_kernel(
     const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ l_n,
     const double* __restrict__ mu_c, const double* __restrict__ x, const double* __restrict__ grad_x,
@@ -37,7 +38,9 @@ __global__ __launch_bounds__(64 * WPB) void bwd_diag_kernel(
     constexpr int NC = N / 2;          // contacts per problem
     constexpr int RS = (KIND == 0) ? N : N + NC; // residual entries per problem
     static_assert(N >= 2 && (N & (N - 1)) == 0 && N <= 128, "N must be a power of two");
-    __shared__ double s_pd[WPB][128], s_dl[WPB][128], s_x[WPB][128], s_rs[WPB][T * RS];
+    __shared__ __attribute__((aligned(16))) double s_pd[WPB][128], s_dl[WPB][128], s_x[WPB][128], s_rs[WPB][T * RS];
+    // FUSE (small N, small batches): a non-diagonal tile is handled right here by the general routine.
+    __shared__ __attribute__((aligned(16))) double s_dense[WPB][FUSE ? dense_bwd_lds_doubles(KIND, N) : 1];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long tile = (long)blockIdx.x * WPB + wave;
@@ -57,7 +60,13 @@ __global__ __launch_bounds__(64 * WPB) void bwd_diag_kernel(
         const double* Pw = P + first * (long)(N * N);
         const unsigned nz = (nvalid == T) ? stream_tile_diag<N, N, false>(Pw, limit, pd, lane)
                                           : stream_tile_diag<N, N, true>(Pw, limit, pd, lane);
-        if (__any(nz != 0)) { // wave-uniform: hand the tile to the dense kernel
+        if (__any(nz != 0)) { // wave-uniform
+            if constexpr (FUSE) {
+                for (int jj = 0; jj < nvalid; ++jj)
+                    dense_bwd_problem<KIND>(P, q, l_n, mu_c, x, grad_x, grad_P, grad_q, grad_l_n, grad_mu, ir_steps,
+                                            first + jj, N, s_dense[wave], lane);
+                return;
+            }
             int base = 0;
             if (lane == 0) base = atomicAdd(&ws[kWsCount], nvalid);
             base = __shfl(base, 0, 64);
@@ -161,45 +170,58 @@ __global__ __launch_bounds__(64 * WPB) void bwd_diag_kernel(
     }
 }
 
-template <int KIND, int N, int WPB>
+template <int KIND, int N, int WPB, bool FUSE>
 static hipError_t launch_one(const BwdArgs& a, hipStream_t s)
 {
     constexpr int T = 128 / N;
     const long ntiles = (a.B + T - 1) / T;
     const long nblocks = (ntiles + WPB - 1) / WPB;
     if (nblocks == 0) return hipSuccess;
-    hipLaunchKernelGGL((bwd_diag_kernel<KIND, N, WPB>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q, a.l_n,
+    hipLaunchKernelGGL((bwd_diag_kernel<KIND, N, WPB, FUSE>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q, a.l_n,
                        a.mu, a.x, a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.B, a.layout, a.ir_steps, a.ws);
     return hipGetLastError();
 }
 
 template <int KIND, int N>
-static hipError_t launch_wpb(const BwdArgs& a, int wpb, hipStream_t s)
+static hipError_t launch_wpb(const BwdArgs& a, int wpb, bool fuse, hipStream_t s)
 {
-    if (wpb == 1) return launch_one<KIND, N, 1>(a, s);
-    return launch_one<KIND, N, 4>(a, s);
+    if constexpr (bwd_diag_fuses(N)) {
+        if (fuse) return wpb == 1 ? launch_one<KIND, N, 1, true>(a, s) : launch_one<KIND, N, 4, true>(a, s);
+    }
+    return wpb == 1 ? launch_one<KIND, N, 1, false>(a, s) : launch_one<KIND, N, 4, false>(a, s);
 }
+
 
 bool bwd_diag_supported(int N) { return N == 2 || N == 4 || N == 8 || N == 16 || N == 32 || N == 64; }
 
+bool bwd_diag_fuses_fallback(int N, long B)
+{
+    (void)N;
+    (void)B;
+    return false; // see launch.h: not worth the occupancy of the streaming kernel
+}
+
 template <int KIND>
-static hipError_t launch_kind(const BwdArgs& a, int wpb, hipStream_t s)
+static hipError_t launch_kind(const BwdArgs& a, int wpb, bool fuse, hipStream_t s)
 {
     switch (a.N) {
-    case 2: return launch_wpb<KIND, 2>(a, wpb, s);
-    case 4: return launch_wpb<KIND, 4>(a, wpb, s);
-    case 8: return launch_wpb<KIND, 8>(a, wpb, s);
-    case 16: return launch_wpb<KIND, 16>(a, wpb, s);
-    case 32: return launch_wpb<KIND, 32>(a, wpb, s);
-    case 64: return launch_wpb<KIND, 64>(a, wpb, s);
+    case 2: return launch_wpb<KIND, 2>(a, wpb, fuse, s);
+    case 4: return launch_wpb<KIND, 4>(a, wpb, fuse, s);
+    case 8: return launch_wpb<KIND, 8>(a, wpb, fuse, s);
+    case 16: return launch_wpb<KIND, 16>(a, wpb, fuse, s);
+    case 32: return launch_wpb<KIND, 32>(a, wpb, fuse, s);
+    case 64: return launch_wpb<KIND, 64>(a, wpb, fuse, s);
     default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_bwd_diag(int kind, const BwdArgs& a, int wpb, hipStream_t s)
+hipError_t launch_bwd_diag(int kind, const BwdArgs& a, int wpb, int fuse_opt, hipStream_t s, bool* needs_fallback)
 {
     if (wpb != 1 && wpb != 4) wpb = 4;
-    return kind == 0 ? launch_kind<0>(a, wpb, s) : launch_kind<1>(a, wpb, s);
+    const bool fuse = a.layout != DQQ_P_DIAG && bwd_diag_fuses(a.N) &&
+                      (fuse_opt < 0 ? bwd_diag_fuses_fallback(a.N, a.B) : fuse_opt != 0);
+    if (needs_fallback) *needs_fallback = (a.layout == DQQ_P_AUTO) && !fuse;
+    return kind == 0 ? launch_kind<0>(a, wpb, fuse, s) : launch_kind<1>(a, wpb, fuse, s);
 }
 
 } // namespace dqq

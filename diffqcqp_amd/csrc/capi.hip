@@ -11,12 +11,14 @@ namespace {
 std::atomic<int> g_fwd_lpp{0};      // 0 = built-in choice
 std::atomic<int> g_wpb{0};          // 0 = built-in choice
 std::atomic<int> g_auto_fallback{1}; // 0 = skip the dense fallback launch of DQQ_P_AUTO (measurement only)
+std::atomic<int> g_fuse{-1};         // in-kernel dense fallback of the fast paths: -1 built-in, 0 off, 1 on
 
 struct Option {
     const char* name;
     std::atomic<int>* slot;
 };
-Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback", &g_auto_fallback}};
+Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback", &g_auto_fallback},
+                      {"fuse_fallback", &g_fuse}};
 
 int check_common(int64_t B, int N, int p_layout, bool qcqp)
 {
@@ -73,7 +75,7 @@ static int fwd_dispatch(int kind, dqq::FwdArgs& a, void* workspace, size_t works
     hipError_t e;
     if (a.layout == DQQ_P_DIAG) {
         if (!fast_ok) return DQQ_E_UNSUPPORTED_N;
-        e = dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), s);
+        e = dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), g_fuse.load(), s, nullptr);
         return (int)e;
     }
     if (a.layout == DQQ_P_DENSE || !fast_ok) {
@@ -81,12 +83,14 @@ static int fwd_dispatch(int kind, dqq::FwdArgs& a, void* workspace, size_t works
         e = dqq::launch_fwd_dense(kind, a, false, s);
         return (int)e;
     }
-    // DQQ_P_AUTO: fast path over every tile, dense kernel over the tiles it queued
+    // DQQ_P_AUTO: fast path over every tile; non-diagonal tiles are solved inside it (small N) or
+    // queued for the dense kernel launched right behind it
     if (int rc = check_ws(workspace, workspace_bytes, a.B)) return rc;
     a.ws = static_cast<int*>(workspace);
-    e = dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), s);
+    bool needs_fallback = true;
+    e = dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), g_fuse.load(), s, &needs_fallback);
     if (e != hipSuccess) return (int)e;
-    if (dense_ok && g_auto_fallback.load() != 0) e = dqq::launch_fwd_dense(kind, a, true, s);
+    if (needs_fallback && dense_ok && g_auto_fallback.load() != 0) e = dqq::launch_fwd_dense(kind, a, true, s);
     return (int)e;
 }
 
@@ -99,7 +103,7 @@ static int bwd_dispatch(int kind, dqq::BwdArgs& a, void* workspace, size_t works
     hipError_t e;
     if (a.layout == DQQ_P_DIAG) {
         if (!fast_ok) return DQQ_E_UNSUPPORTED_N;
-        return (int)dqq::launch_bwd_diag(kind, a, g_wpb.load(), s);
+        return (int)dqq::launch_bwd_diag(kind, a, g_wpb.load(), g_fuse.load(), s, nullptr);
     }
     if (a.layout == DQQ_P_DENSE || !fast_ok) {
         if (!dense_ok) return DQQ_E_UNSUPPORTED_N;
@@ -107,9 +111,10 @@ static int bwd_dispatch(int kind, dqq::BwdArgs& a, void* workspace, size_t works
     }
     if (int rc = check_ws(workspace, workspace_bytes, a.B)) return rc;
     a.ws = static_cast<int*>(workspace);
-    e = dqq::launch_bwd_diag(kind, a, g_wpb.load(), s);
+    bool needs_fallback = true;
+    e = dqq::launch_bwd_diag(kind, a, g_wpb.load(), g_fuse.load(), s, &needs_fallback);
     if (e != hipSuccess) return (int)e;
-    if (dense_ok && g_auto_fallback.load() != 0) e = dqq::launch_bwd_dense(kind, a, true, s);
+    if (needs_fallback && dense_ok && g_auto_fallback.load() != 0) e = dqq::launch_bwd_dense(kind, a, true, s);
     return (int)e;
 }
 

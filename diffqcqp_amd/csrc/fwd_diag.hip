@@ -11,16 +11,20 @@
 // fully coalesced 16-byte loads (1 KiB per wave instruction), checks on the fly
 // that every off-diagonal entry is exactly +-0, and drops the diagonal entries
 // into LDS in [problem][coordinate] order, from where each lane picks up its E
-// values.  A tile with any non-zero off-diagonal is NOT solved here: its
-// problem indices are appended to the fallback work-list that the general
-// dense kernel (dense.hip) drains right after this launch.
+// values.  A tile with any non-zero off-diagonal does not take the fast path:
+// for N <= 16 the same wave solves its problems one by one with the general
+// per-problem routine (dense_core.h); for larger N (where that routine's LDS
+// footprint would cost the fast path its occupancy) the problem indices are
+// appended to the fallback work-list that the general dense kernel (dense.hip)
+// drains right after this launch.
 #include "admm_core.h"
+#include "dense_core.h"
 #include "launch.h"
 #include "stream_tile.h"
 
 namespace dqq {
 
-template <int KIND, int N, int LPP, int WPB>
+template <int KIND, int N, int LPP, int WPB, bool FUSE>
 __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __restrict__ P,
                                                             const double* __restrict__ q,
                                                             const double* __restrict__ l_n,
@@ -33,7 +37,11 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
     constexpr int PPW = 64 / LPP;    // problems per wave tile
     constexpr int NCH = N * E / 2;   // 16-byte-per-lane chunks in a tile of P
     static_assert(E >= 2 && E % 2 == 0 && E * LPP == N, "bad N/LPP");
-    __shared__ double s_diag[WPB][64 * E];
+    // FUSE (small N, small batches): a non-diagonal tile is solved right here by the general per-problem
+    // routine (its LDS scratch aliases the diagonal staging buffer); otherwise the tile is queued for
+    // the dense kernel launched behind this one.
+    constexpr int SMEM = (FUSE && dense_fwd_lds_doubles(N) > 64 * E) ? dense_fwd_lds_doubles(N) : 64 * E;
+    __shared__ __attribute__((aligned(16))) double s_diag[WPB][SMEM];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long tile = (long)blockIdx.x * WPB + wave;
@@ -58,7 +66,13 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
         double* sd = s_diag[wave];
         const unsigned nz = (nvalid == PPW) ? stream_tile_diag<N, NCH, false>(Pw, limit, sd, lane)
                                             : stream_tile_diag<N, NCH, true>(Pw, limit, sd, lane);
-        if (__any(nz != 0)) { // wave-uniform: hand the tile to the dense kernel
+        if (__any(nz != 0)) { // wave-uniform
+            if constexpr (FUSE) {
+                for (int j = 0; j < nvalid; ++j)
+                    dense_fwd_problem<KIND>(P, q, l_n, mu_c, x, iters, first + j, N, eps, mu_prox, max_iter, adaptive,
+                                            sd, lane);
+                return;
+            }
             int base = 0;
             if (lane == 0) base = atomicAdd(&ws[kWsCount], nvalid);
             base = __shfl(base, 0, 64);
@@ -97,23 +111,25 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
     }
 }
 
-template <int KIND, int N, int LPP, int WPB>
+template <int KIND, int N, int LPP, int WPB, bool FUSE>
 static hipError_t launch_one(const FwdArgs& a, hipStream_t s)
 {
     constexpr int PPW = 64 / LPP;
     const long ntiles = (a.B + PPW - 1) / PPW;
     const long nblocks = (ntiles + WPB - 1) / WPB;
     if (nblocks == 0) return hipSuccess;
-    hipLaunchKernelGGL((fwd_diag_kernel<KIND, N, LPP, WPB>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q,
+    hipLaunchKernelGGL((fwd_diag_kernel<KIND, N, LPP, WPB, FUSE>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q,
                        a.l_n, a.mu, a.x, a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.layout, a.iters, a.ws);
     return hipGetLastError();
 }
 
 template <int KIND, int N, int LPP>
-static hipError_t launch_wpb(const FwdArgs& a, int wpb, hipStream_t s)
+static hipError_t launch_wpb(const FwdArgs& a, int wpb, bool fuse, hipStream_t s)
 {
-    if (wpb == 1) return launch_one<KIND, N, LPP, 1>(a, s);
-    return launch_one<KIND, N, LPP, 4>(a, s);
+    if constexpr (fwd_diag_fuses(N)) {
+        if (fuse) return wpb == 1 ? launch_one<KIND, N, LPP, 1, true>(a, s) : launch_one<KIND, N, LPP, 4, true>(a, s);
+    }
+    return wpb == 1 ? launch_one<KIND, N, LPP, 1, false>(a, s) : launch_one<KIND, N, LPP, 4, false>(a, s);
 }
 
 // Lanes-per-problem choices the kernel is instantiated for (E = N/LPP coordinates per lane,
@@ -149,11 +165,12 @@ int fwd_diag_default_lpp(int N, long B)
 
 bool fwd_diag_supported(int N) { return fwd_diag_default_lpp(N, 1) != 0; }
 
+
 template <int KIND>
-static bool launch_kind(const FwdArgs& a, int lpp, int wpb, hipStream_t s, hipError_t& err)
+static bool launch_kind(const FwdArgs& a, int lpp, int wpb, bool fuse, hipStream_t s, hipError_t& err)
 {
 #define DQQ_CASE(NN, LL) \
-    if (a.N == NN && lpp == LL) { err = launch_wpb<KIND, NN, LL>(a, wpb, s); return true; }
+    if (a.N == NN && lpp == LL) { err = launch_wpb<KIND, NN, LL>(a, wpb, fuse, s); return true; }
     DQQ_CASE(2, 1)
     DQQ_CASE(4, 1) DQQ_CASE(4, 2)
     DQQ_CASE(8, 1) DQQ_CASE(8, 2) DQQ_CASE(8, 4)
@@ -164,17 +181,25 @@ static bool launch_kind(const FwdArgs& a, int lpp, int wpb, hipStream_t s, hipEr
     return false;
 }
 
-// lpp / wpb == 0 -> built-in choice; an lpp the kernel is not instantiated for
-// falls back to the built-in one.
-hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, hipStream_t s)
+// The in-kernel dense fallback costs the fast path registers (occupancy), which only matters once the
+// batch is large enough to want more than two waves per SIMD; below that it saves the extra launch.
+bool fwd_diag_fuses_fallback(int N, long B) { return fwd_diag_supported(N) && fwd_diag_fuses(N) && B <= 131072; }
+
+// lpp / wpb == 0 -> built-in choice; an lpp the kernel is not instantiated for falls back to the
+// built-in one.  *needs_fallback: the caller must launch the dense kernel in work-list mode next.
+hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fuse_opt, hipStream_t s,
+                           bool* needs_fallback)
 {
     if (wpb != 1 && wpb != 4) wpb = 4;
     if (lpp <= 0) lpp = fwd_diag_default_lpp(a.N, a.B);
+    const bool fuse = a.layout != DQQ_P_DIAG && fwd_diag_fuses(a.N) &&
+                      (fuse_opt < 0 ? fwd_diag_fuses_fallback(a.N, a.B) : fuse_opt != 0);
+    if (needs_fallback) *needs_fallback = (a.layout == DQQ_P_AUTO) && !fuse;
     hipError_t e = hipErrorInvalidValue;
-    bool found = kind == 0 ? launch_kind<0>(a, lpp, wpb, s, e) : launch_kind<1>(a, lpp, wpb, s, e);
+    bool found = kind == 0 ? launch_kind<0>(a, lpp, wpb, fuse, s, e) : launch_kind<1>(a, lpp, wpb, fuse, s, e);
     if (!found) {
         lpp = fwd_diag_default_lpp(a.N, a.B);
-        found = kind == 0 ? launch_kind<0>(a, lpp, wpb, s, e) : launch_kind<1>(a, lpp, wpb, s, e);
+        found = kind == 0 ? launch_kind<0>(a, lpp, wpb, fuse, s, e) : launch_kind<1>(a, lpp, wpb, fuse, s, e);
     }
     return found ? e : hipErrorInvalidValue;
 }

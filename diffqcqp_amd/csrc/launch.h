@@ -46,12 +46,25 @@ struct BwdArgs {
     int* ws;
 };
 
+// Which N can solve their non-diagonal tiles inside the fast kernel (no fallback launch needed).
+// Forward: N <= 16.  Backward: never by default -- the general routine triples the VGPR count of the
+// streaming backward kernel (58 -> 134, occupancy 8 -> 3 waves/SIMD), which costs more (+2 us at
+// B=65536) than the empty fallback launch it saves; the instantiation is kept behind
+// dqq_set_option("fuse_fallback", 1) for N <= 8.
+constexpr bool fwd_diag_fuses(int N) { return N <= 16; }
+constexpr bool bwd_diag_fuses(int N) { return N <= 8; }
+
 // diagonal fast paths (fwd_diag.hip, bwd_diag.hip)
 bool fwd_diag_supported(int N);
+bool fwd_diag_fuses_fallback(int N, long B);
+bool bwd_diag_fuses_fallback(int N, long B);
 int fwd_diag_default_lpp(int N, long B);
-hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, hipStream_t s);
+// fuse_opt: -1 built-in choice, 0 never, 1 whenever instantiated.  *needs_fallback: launch the dense kernel
+// in work-list mode behind this one.
+hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fuse_opt, hipStream_t s,
+                           bool* needs_fallback);
 bool bwd_diag_supported(int N);
-hipError_t launch_bwd_diag(int kind, const BwdArgs& a, int wpb, hipStream_t s);
+hipError_t launch_bwd_diag(int kind, const BwdArgs& a, int wpb, int fuse_opt, hipStream_t s, bool* needs_fallback);
 
 // general dense kernels (dense.hip).  use_worklist: solve only the problems the
 // fast path queued in a.ws, then re-zero the work-list header.

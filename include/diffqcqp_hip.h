@@ -95,8 +95,12 @@ int dqq_qcqp_bwd_f64(const double* P, const double* q, const double* l_n, const 
                      void* stream);
 
 /* Tuning knobs (process-wide, read at launch time).  Unknown name -> DQQ_E_BAD_OPTION.
- *   "fwd_lpp"   lanes per problem of the diagonal forward kernel (0 = built-in choice)
- *   "wpb"       waves per workgroup of the diagonal kernels (1, 2 or 4; 0 = built-in) */
+ *   "fwd_lpp"        lanes per problem of the diagonal forward kernel (0 = built-in choice from B)
+ *   "wpb"            waves per workgroup of the diagonal kernels (1 or 4; 0 = built-in)
+ *   "fuse_fallback"  DQQ_P_AUTO, small N: solve non-diagonal tiles inside the fast kernel (1), queue them
+ *                    for the dense kernel launched behind it (0), or decide from B (-1, default)
+ *   "auto_fallback"  0 skips the dense-kernel launch of DQQ_P_AUTO -- measurement only: non-diagonal
+ *                    tiles are then left unsolved (default 1) */
 int dqq_set_option(const char* name, int value);
 int dqq_get_option(const char* name, int* value);
 

@@ -40,6 +40,7 @@ def ops():
     yield _ops
     _capi.set_option("fwd_lpp", 0)
     _capi.set_option("wpb", 0)
+    _capi.set_option("fuse_fallback", -1)
 
 
 def dev(d):
@@ -229,11 +230,15 @@ def test_dense_n64_config5_shape(oracle, ops):
 def test_auto_layout_mixed_batch_uses_fallback(oracle, ops, kind, N):
     """Diagonal and dense problems interleaved: tiles with a non-zero off-diagonal go through the
     work-list to the dense kernel, the rest through the fast path; the work-list is left zeroed."""
+    from diffqcqp_amd import _capi
     B = 500 if N == 8 else 61
     d = make_problem(kind, B, N, 700 + N, "mixed")
     g = dev(d)
     xo, ito = oracle_fwd(oracle, kind, d)
-    for _ in range(2):  # twice: the second call relies on the first having re-zeroed the workspace
+    # fuse_fallback: 1 = non-diagonal tiles solved inside the fast kernel (small N), 0 = work-list + dense
+    # kernel, -1 = built-in choice.  Twice each: the second call relies on the work-list being re-zeroed.
+    for fuse in (0, 0, 1, -1):
+        _capi.set_option("fuse_fallback", fuse)
         xh, ith = hip_fwd(ops, kind, g)
         check_forward(xh, ith, xo, ito, min_match=0.99)
         grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda())
