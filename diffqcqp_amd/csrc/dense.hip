@@ -6,54 +6,61 @@
 
 namespace dqq {
 
-// Last workgroup out re-zeroes the work-list header for the next call.  With an
-// empty work-list (the common case: every tile was diagonal) there is nothing to
-// reset and no workgroup touches the ticket -- 1024 same-address atomics would
-// otherwise serialise into ~13 us of an otherwise empty launch.
-static DQQ_D void worklist_release(int* ws, int lane, long count)
+// Last wave out re-zeroes the work-list header for the next call.  With an empty work-list (the
+// common case: every tile was diagonal) there is nothing to reset and nobody touches the ticket --
+// hundreds of same-address atomics would otherwise serialise into ~13 us of an otherwise empty launch.
+static DQQ_D void worklist_release(int* ws, int lane, long count, int nwaves)
 {
     if (count > 0 && lane == 0) {
         const int t = atomicAdd(&ws[kWsTicket], 1);
-        if (t == (int)gridDim.x - 1) {
+        if (t == nwaves - 1) {
             ws[kWsCount] = 0;
             ws[kWsTicket] = 0;
         }
     }
 }
 
+// Workgroups hold `wpb` independent waves (wave-private LDS slices, no workgroup barrier): more waves
+// per dispatched workgroup keeps the launch cheap when the work-list turns out to be empty.
 template <int KIND>
-__global__ __launch_bounds__(64) void fwd_dense_kernel(const double* __restrict__ P, const double* __restrict__ q,
-                                                       const double* __restrict__ l_n,
-                                                       const double* __restrict__ mu_c, double* __restrict__ x, long B,
-                                                       int n, double eps, double mu, int max_iter, int adaptive,
-                                                       int* __restrict__ iters, int* __restrict__ ws, int use_worklist)
+__global__ __launch_bounds__(256) void fwd_dense_kernel(const double* __restrict__ P, const double* __restrict__ q,
+                                                        const double* __restrict__ l_n,
+                                                        const double* __restrict__ mu_c, double* __restrict__ x, long B,
+                                                        int n, double eps, double mu, int max_iter, int adaptive,
+                                                        int* __restrict__ iters, int* __restrict__ ws, int use_worklist,
+                                                        int lds_per_wave)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    double* sw = smem + wave * lds_per_wave;
     const long count = use_worklist ? (long)ws[kWsCount] : B;
-    for (long w = blockIdx.x; w < count; w += gridDim.x) {
+    const long nwaves = (long)gridDim.x * wpb;
+    for (long w = (long)blockIdx.x * wpb + wave; w < count; w += nwaves) {
         const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
-        dense_fwd_problem<KIND>(P, q, l_n, mu_c, x, iters, prob, n, eps, mu, max_iter, adaptive, smem, lane);
+        dense_fwd_problem<KIND>(P, q, l_n, mu_c, x, iters, prob, n, eps, mu, max_iter, adaptive, sw, lane);
     }
-    if (use_worklist) worklist_release(ws, lane, count);
+    if (use_worklist) worklist_release(ws, lane, count, (int)nwaves);
 }
 
 template <int KIND>
-__global__ __launch_bounds__(64) void bwd_dense_kernel(
+__global__ __launch_bounds__(256) void bwd_dense_kernel(
     const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ l_n,
     const double* __restrict__ mu_c, const double* __restrict__ x, const double* __restrict__ grad_x,
     double* __restrict__ grad_P, double* __restrict__ grad_q, double* __restrict__ grad_l_n,
-    double* __restrict__ grad_mu, long B, int n, int* __restrict__ ir_steps, int* __restrict__ ws, int use_worklist)
+    double* __restrict__ grad_mu, long B, int n, int* __restrict__ ir_steps, int* __restrict__ ws, int use_worklist,
+    int lds_per_wave)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    double* sw = smem + wave * lds_per_wave;
     const long count = use_worklist ? (long)ws[kWsCount] : B;
-    for (long w = blockIdx.x; w < count; w += gridDim.x) {
+    const long nwaves = (long)gridDim.x * wpb;
+    for (long w = (long)blockIdx.x * wpb + wave; w < count; w += nwaves) {
         const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
-        dense_bwd_problem<KIND>(P, q, l_n, mu_c, x, grad_x, grad_P, grad_q, grad_l_n, grad_mu, ir_steps, prob, n, smem,
+        dense_bwd_problem<KIND>(P, q, l_n, mu_c, x, grad_x, grad_P, grad_q, grad_l_n, grad_mu, ir_steps, prob, n, sw,
                                 lane);
     }
-    if (use_worklist) worklist_release(ws, lane, count);
+    if (use_worklist) worklist_release(ws, lane, count, (int)nwaves);
 }
 
 // ---------------------------------------------------------------- launchers
@@ -63,9 +70,6 @@ int dense_max_n(int kind)
     return kDenseMaxRows;
 }
 
-static size_t fwd_dense_lds(int n) { return sizeof(double) * (size_t)dense_fwd_lds_doubles(n); }
-static size_t bwd_dense_lds(int kind, int n) { return sizeof(double) * (size_t)dense_bwd_lds_doubles(kind, n); }
-
 template <typename K>
 static hipError_t set_lds(K kernel, size_t bytes)
 {
@@ -74,30 +78,44 @@ static hipError_t set_lds(K kernel, size_t bytes)
                                (int)bytes);
 }
 
-static unsigned dense_grid(long B, bool use_worklist)
+// waves per workgroup: as many (<= 4) as fit in 64 KiB of LDS; doubles per wave rounded to 16 B
+struct DenseGeom {
+    int wpb, lds_per_wave;
+    size_t lds_bytes;
+    unsigned grid;
+};
+static DenseGeom dense_geom(int lds_doubles, long B, bool use_worklist)
 {
-    // persistent: enough single-wave workgroups to fill the chip, each loops over problems
-    const long cap = 256L * 16;
-    // work-list mode: the size of the list is only known on the device; 512 single-wave workgroups loop
-    // over it (an empty list -- every tile was diagonal -- costs one short launch)
-    if (use_worklist) return 512;
-    return (unsigned)(B < cap ? (B > 0 ? B : 1) : cap);
+    DenseGeom g;
+    g.lds_per_wave = (lds_doubles + 1) & ~1;
+    const size_t per_wave = sizeof(double) * (size_t)g.lds_per_wave;
+    g.wpb = (int)((64 * 1024) / per_wave);
+    if (g.wpb > 4) g.wpb = 4;
+    if (g.wpb < 1) g.wpb = 1;
+    g.lds_bytes = per_wave * g.wpb;
+    // persistent waves loop over the problems; in work-list mode the size of the list is only known on
+    // the device, so a fixed 512 workgroups are dispatched (an empty list costs one short launch)
+    const long cap = 256L * 16 / g.wpb * (g.wpb > 1 ? 2 : 1);
+    const long need = (B + g.wpb - 1) / g.wpb;
+    g.grid = use_worklist ? 512u : (unsigned)(need < cap ? (need > 0 ? need : 1) : cap);
+    return g;
 }
 
 hipError_t launch_fwd_dense(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
-    const size_t lds = fwd_dense_lds(a.N);
-    const unsigned grid = dense_grid(a.B, use_worklist);
+    const DenseGeom g = dense_geom(dense_fwd_lds_doubles(a.N), a.B, use_worklist);
     hipError_t e;
     if (kind == 0) {
-        if ((e = set_lds(fwd_dense_kernel<0>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(fwd_dense_kernel<0>, dim3(grid), dim3(64), lds, s, a.P, a.q, a.l_n, a.mu, a.x, a.B, a.N,
-                           a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0);
+        if ((e = set_lds(fwd_dense_kernel<0>, g.lds_bytes)) != hipSuccess) return e;
+        hipLaunchKernelGGL(fwd_dense_kernel<0>, dim3(g.grid), dim3(64 * g.wpb), g.lds_bytes, s, a.P, a.q, a.l_n, a.mu,
+                           a.x, a.B, a.N, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws,
+                           use_worklist ? 1 : 0, g.lds_per_wave);
     } else {
-        if ((e = set_lds(fwd_dense_kernel<1>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(fwd_dense_kernel<1>, dim3(grid), dim3(64), lds, s, a.P, a.q, a.l_n, a.mu, a.x, a.B, a.N,
-                           a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0);
+        if ((e = set_lds(fwd_dense_kernel<1>, g.lds_bytes)) != hipSuccess) return e;
+        hipLaunchKernelGGL(fwd_dense_kernel<1>, dim3(g.grid), dim3(64 * g.wpb), g.lds_bytes, s, a.P, a.q, a.l_n, a.mu,
+                           a.x, a.B, a.N, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws,
+                           use_worklist ? 1 : 0, g.lds_per_wave);
     }
     return hipGetLastError();
 }
@@ -105,19 +123,18 @@ hipError_t launch_fwd_dense(int kind, const FwdArgs& a, bool use_worklist, hipSt
 hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
-    const size_t lds = bwd_dense_lds(kind, a.N);
-    const unsigned grid = dense_grid(a.B, use_worklist);
+    const DenseGeom g = dense_geom(dense_bwd_lds_doubles(kind, a.N), a.B, use_worklist);
     hipError_t e;
     if (kind == 0) {
-        if ((e = set_lds(bwd_dense_kernel<0>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(bwd_dense_kernel<0>, dim3(grid), dim3(64), lds, s, a.P, a.q, a.l_n, a.mu, a.x, a.grad_x,
-                           a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.B, a.N, a.ir_steps, a.ws,
-                           use_worklist ? 1 : 0);
+        if ((e = set_lds(bwd_dense_kernel<0>, g.lds_bytes)) != hipSuccess) return e;
+        hipLaunchKernelGGL(bwd_dense_kernel<0>, dim3(g.grid), dim3(64 * g.wpb), g.lds_bytes, s, a.P, a.q, a.l_n, a.mu,
+                           a.x, a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.B, a.N, a.ir_steps, a.ws,
+                           use_worklist ? 1 : 0, g.lds_per_wave);
     } else {
-        if ((e = set_lds(bwd_dense_kernel<1>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(bwd_dense_kernel<1>, dim3(grid), dim3(64), lds, s, a.P, a.q, a.l_n, a.mu, a.x, a.grad_x,
-                           a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.B, a.N, a.ir_steps, a.ws,
-                           use_worklist ? 1 : 0);
+        if ((e = set_lds(bwd_dense_kernel<1>, g.lds_bytes)) != hipSuccess) return e;
+        hipLaunchKernelGGL(bwd_dense_kernel<1>, dim3(g.grid), dim3(64 * g.wpb), g.lds_bytes, s, a.P, a.q, a.l_n, a.mu,
+                           a.x, a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.B, a.N, a.ir_steps, a.ws,
+                           use_worklist ? 1 : 0, g.lds_per_wave);
     }
     return hipGetLastError();
 }
