@@ -6,6 +6,10 @@
 
 #include "launch.h"
 
+namespace dqq {
+extern std::atomic<int> g_dense_block;
+}
+
 namespace {
 
 std::atomic<int> g_fwd_lpp{0};      // 0 = built-in choice
@@ -18,7 +22,8 @@ struct Option {
     std::atomic<int>* slot;
 };
 Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback", &g_auto_fallback},
-                      {"fuse_fallback", &g_fuse}};
+                      {"fuse_fallback", &g_fuse},
+                      {"dense_block", &dqq::g_dense_block}};
 
 int check_common(int64_t B, int N, int p_layout, bool qcqp)
 {

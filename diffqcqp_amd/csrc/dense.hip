@@ -1,10 +1,14 @@
 // dense.hip -- stand-alone kernels of the general (non-diagonal P) path: one wave64 per problem
 // (dense_core.h), persistent over the batch or over the fallback work-list the diagonal fast paths
 // fill for the tiles they cannot take.
+#include <atomic>
+
 #include "dense_core.h"
 #include "launch.h"
 
 namespace dqq {
+
+std::atomic<int> g_dense_block{1}; // 0: always the wave-per-problem kernel (option "dense_block")
 
 // Last wave out re-zeroes the work-list header for the next call.  With an empty work-list (the
 // common case: every tile was diagonal) there is nothing to reset and nobody touches the ticket --
@@ -104,6 +108,8 @@ static DenseGeom dense_geom(int lds_doubles, long B, bool use_worklist)
 hipError_t launch_fwd_dense(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
+    if (fwd_dense_block_supported(a.N) && g_dense_block.load() != 0)
+        return launch_fwd_dense_block(kind, a, use_worklist, s);
     const DenseGeom g = dense_geom(dense_fwd_lds_doubles(a.N), a.B, use_worklist);
     hipError_t e;
     if (kind == 0) {

@@ -41,6 +41,7 @@ def ops():
     _capi.set_option("fwd_lpp", 0)
     _capi.set_option("wpb", 0)
     _capi.set_option("fuse_fallback", -1)
+    _capi.set_option("dense_block", 1)
 
 
 def dev(d):
@@ -201,6 +202,24 @@ def test_dense_kernel_matches_oracle(oracle, ops, kind, N, B, structure):
     check_forward(xh, ith, xo, ito, min_match=0.99)
     grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
     check_backward_exact(grads, st, oracle_bwd(oracle, kind, d, xo), exact=False)
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("N,B", [(32, 40), (64, 12)])
+def test_block_and_wave_dense_forward_agree(oracle, ops, kind, N, B):
+    """N = 32 / 64 forward has two general kernels: workgroup-per-problem (default) and wave-per-problem.
+    Both follow the oracle's trajectory; they differ only in summation order."""
+    from diffqcqp_amd import _capi
+    d = make_problem(kind, B, N, 650 + N, "dense")
+    g = dev(d)
+    xo, ito = oracle_fwd(oracle, kind, d)
+    out = {}
+    for blk in (1, 0):
+        _capi.set_option("dense_block", blk)
+        out[blk] = hip_fwd(ops, kind, g, layout=_capi.P_DENSE)
+        check_forward(out[blk][0], out[blk][1], xo, ito, min_match=0.9)
+    _capi.set_option("dense_block", 1)
+    assert (out[0][0] - out[1][0]).abs().max() < 1e-8
 
 
 @pytest.mark.parametrize("N", [3, 5, 7])
