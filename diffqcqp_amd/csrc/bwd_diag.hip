@@ -27,7 +27,7 @@
 namespace dqq {
 
 template <int KIND, int N, int WPB, bool FUSE>
-__global__ __launch_bounds__(64 * WPB) void bwd_diag_kernel(
+__global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : 4) : 1)) void bwd_diag_kernel(
     const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ l_n,
     const double* __restrict__ mu_c, const double* __restrict__ x, const double* __restrict__ grad_x,
     double* __restrict__ grad_P, double* __restrict__ grad_q, double* __restrict__ grad_l_n,
@@ -39,7 +39,9 @@ __global__ __launch_bounds__(64 * WPB) void bwd_diag_kernel(
     constexpr int RS = (KIND == 0) ? N : N + NC; // residual entries per problem
     static_assert(N >= 2 && (N & (N - 1)) == 0 && N <= 128, "N must be a power of two");
     __shared__ __attribute__((aligned(16))) double s_pd[WPB][128], s_dl[WPB][128], s_x[WPB][128], s_rs[WPB][T * RS];
-    // FUSE (small N, small batches): a non-diagonal tile is handled right here by the general routine.
+    // FUSE (small N, small batches): a non-diagonal tile is handled right here by the general routine.  The
+    // launch bound keeps the register budget of this streaming kernel at 5 (QP) / 4 (QCQP) waves per SIMD:
+    // uncapped, the general routine would take it from 58 to 134 VGPRs.
     __shared__ __attribute__((aligned(16))) double s_dense[WPB][FUSE ? dense_bwd_lds_doubles(KIND, N) : 1];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -194,12 +196,7 @@ static hipError_t launch_wpb(const BwdArgs& a, int wpb, bool fuse, hipStream_t s
 
 bool bwd_diag_supported(int N) { return N == 2 || N == 4 || N == 8 || N == 16 || N == 32 || N == 64; }
 
-bool bwd_diag_fuses_fallback(int N, long B)
-{
-    (void)N;
-    (void)B;
-    return false; // see launch.h: not worth the occupancy of the streaming kernel
-}
+bool bwd_diag_fuses_fallback(int N, long B) { return bwd_diag_fuses(N) && bwd_diag_supported(N) && B <= 131072; }
 
 template <int KIND>
 static hipError_t launch_kind(const BwdArgs& a, int wpb, bool fuse, hipStream_t s)

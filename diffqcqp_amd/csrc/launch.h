@@ -46,11 +46,10 @@ struct BwdArgs {
     int* ws;
 };
 
-// Which N can solve their non-diagonal tiles inside the fast kernel (no fallback launch needed).
-// Forward: N <= 16.  Backward: never by default -- the general routine triples the VGPR count of the
-// streaming backward kernel (58 -> 134, occupancy 8 -> 3 waves/SIMD), which costs more (+2 us at
-// B=65536) than the empty fallback launch it saves; the instantiation is kept behind
-// dqq_set_option("fuse_fallback", 1) for N <= 8.
+// Which N can solve their non-diagonal tiles inside the fast kernel (no fallback launch: an empty
+// work-list launch still costs ~4.6 us behind a 13-35 us kernel).  Chosen at launch from the batch size
+// (fwd/bwd_diag_fuses_fallback): the in-kernel general routine costs registers, which only pays while
+// the batch is too small to want more waves per SIMD anyway.
 constexpr bool fwd_diag_fuses(int N) { return N <= 16; }
 constexpr bool bwd_diag_fuses(int N) { return N <= 8; }
 
