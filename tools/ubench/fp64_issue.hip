@@ -28,22 +28,22 @@ void run(int waves_per_simd)
     const int iters = 2000;
     const int blocks = 256 * waves_per_simd; // 256-thread blocks: one wave on each SIMD of a CU
     double* out;
-    hipMalloc(&out, sizeof(double) * blocks * 256);
+    (void)hipMalloc(&out, sizeof(double) * blocks * 256);
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     k<NCHAIN><<<blocks, 256>>>(out, 10, 1.0000001, 1e-9);
-    hipDeviceSynchronize();
-    hipEventRecord(e0);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
     k<NCHAIN><<<blocks, 256>>>(out, iters, 1.0000001, 1e-9);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
     float ms;
-    hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
     const double fmas_per_wave = (double)iters * 8 * NCHAIN;
     const double ns_per_fma_per_simd = ms * 1e6 / (fmas_per_wave * waves_per_simd);
     printf("chains %2d waves/SIMD %d: %.3f ms, %.2f ns per wave-FMA per SIMD (= %.2f cycles at 2.1 GHz, %.2f at 2.4)\n", NCHAIN,
            waves_per_simd, ms, ns_per_fma_per_simd, ns_per_fma_per_simd * 2.1, ns_per_fma_per_simd * 2.4);
-    hipFree(out);
+    (void)hipFree(out);
 }
 
 int main()
