@@ -81,14 +81,14 @@ class Plan:
                                   p(self.ws), self.wsb, stream)
         elif which == 1:
             rc = L.dqq_qp_bwd_f64(p(d["P"]), p(d["q"]), p(self.x_qp), p(d["g_qp"]), p(self.gP_qp), p(self.gq_qp), B, N,
-                                  0, None, p(self.ws), self.wsb, stream)
+                                  1e-10, 0, None, p(self.ws), self.wsb, stream)
         elif which == 2:
             rc = L.dqq_qcqp_fwd_f64(p(d["P"]), p(d["q"]), p(d["l_n"]), p(d["mu"]), p(self.x_qcqp), B, N, EPS, MU_PROX,
                                     MAX_ITER, 1, 0, None, p(self.ws), self.wsb, stream)
         else:
             rc = L.dqq_qcqp_bwd_f64(p(d["P"]), p(d["q"]), p(d["l_n"]), p(d["mu"]), p(self.x_qcqp), p(d["g_qcqp"]),
-                                    p(self.gP_qc), p(self.gq_qc), p(self.gl_qc), p(self.gm_qc), B, N, 0, None,
-                                    p(self.ws), self.wsb, stream)
+                                    p(self.gP_qc), p(self.gq_qc), p(self.gl_qc), p(self.gm_qc), None, None, B, N, 1e-10,
+                                    0, None, p(self.ws), self.wsb, stream)
         if rc != 0:
             raise RuntimeError("launch %s failed with %d" % (self.names[which], rc))
 

@@ -31,7 +31,8 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : 4) : 1)) void bw
     const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ l_n,
     const double* __restrict__ mu_c, const double* __restrict__ x, const double* __restrict__ grad_x,
     double* __restrict__ grad_P, double* __restrict__ grad_q, double* __restrict__ grad_l_n,
-    double* __restrict__ grad_mu, long B, int layout, int* __restrict__ ir_steps, int* __restrict__ ws)
+    double* __restrict__ grad_mu, double* __restrict__ gamma_out, double* __restrict__ dgamma_out, long B,
+    double dual_eps, int layout, int* __restrict__ ir_steps, int* __restrict__ ws)
 {
     constexpr int HL = N / 2;          // lanes per problem
     constexpr int T = 64 / HL;         // problems per wave tile (T*N == 128)
@@ -65,8 +66,8 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : 4) : 1)) void bw
         if (__any(nz != 0)) { // wave-uniform
             if constexpr (FUSE) {
                 for (int jj = 0; jj < nvalid; ++jj)
-                    dense_bwd_problem<KIND>(P, q, l_n, mu_c, x, grad_x, grad_P, grad_q, grad_l_n, grad_mu, ir_steps,
-                                            first + jj, N, s_dense[wave], lane);
+                    dense_bwd_problem<KIND>(P, q, l_n, mu_c, x, grad_x, grad_P, grad_q, grad_l_n, grad_mu, gamma_out,
+                                            dgamma_out, ir_steps, first + jj, N, dual_eps, s_dense[wave], lane);
                 return;
             }
             int base = 0;
@@ -93,8 +94,8 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : 4) : 1)) void bw
 
     if (KIND == 0) {
         QpCoord c0, c1;
-        c0.setup(pv.x, qv.x, xv.x, gv.x);
-        c1.setup(pv.y, qv.y, xv.y, gv.y);
+        c0.setup(pv.x, qv.x, xv.x, gv.x, dual_eps);
+        c1.setup(pv.y, qv.y, xv.y, gv.y, dual_eps);
         for (int it = 0; it < kIrMaxIter; ++it) {
             if (!done) {
                 rs[pl * RS + 2 * j] = c0.step();
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : 4) : 1)) void bw
         const long cc = first * NC + lane;
         const double ln = valid ? l_n[cc] : 1.0, mc = valid ? mu_c[cc] : 1.0;
         QcqpContact ct;
-        ct.setup(pv.x, pv.y, qv.x, qv.y, xv.x, xv.y, gv.x, gv.y, ln, mc);
+        ct.setup(pv.x, pv.y, qv.x, qv.y, xv.x, xv.y, gv.x, gv.y, ln, mc, dual_eps);
         for (int it = 0; it < kIrMaxIter; ++it) {
             if (!done) {
                 double dsq[3];
@@ -141,6 +142,8 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : 4) : 1)) void bw
             const double dg = ct.dgamma();
             if (grad_l_n != nullptr) grad_l_n[cc] = QcqpContact::e2(ct.gamma, ln, mc) * dg; // qcqp.py:178
             if (grad_mu != nullptr) grad_mu[cc] = QcqpContact::e1(ct.gamma, ln, mc) * dg;   // qcqp.py:180
+            if (gamma_out != nullptr) gamma_out[cc] = ct.gamma;
+            if (dgamma_out != nullptr) dgamma_out[cc] = dg;
         }
     }
     if (valid) {
@@ -180,7 +183,8 @@ static hipError_t launch_one(const BwdArgs& a, hipStream_t s)
     const long nblocks = (ntiles + WPB - 1) / WPB;
     if (nblocks == 0) return hipSuccess;
     hipLaunchKernelGGL((bwd_diag_kernel<KIND, N, WPB, FUSE>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q, a.l_n,
-                       a.mu, a.x, a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.B, a.layout, a.ir_steps, a.ws);
+                       a.mu, a.x, a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.epsilon, a.layout,
+                       a.ir_steps, a.ws);
     return hipGetLastError();
 }
 

@@ -147,27 +147,27 @@ int dqq_qcqp_fwd_f64(const double* P, const double* q, const double* l_n, const 
 }
 
 int dqq_qp_bwd_f64(const double* P, const double* q, const double* x, const double* grad_x, double* grad_P,
-                   double* grad_q, int64_t B, int N, int p_layout, int* ir_steps, void* workspace,
+                   double* grad_q, int64_t B, int N, double epsilon, int p_layout, int* ir_steps, void* workspace,
                    size_t workspace_bytes, void* stream)
 {
     if (int rc = check_common(B, N, p_layout, false)) return rc;
     if (B > 0 && (P == nullptr || q == nullptr || x == nullptr || grad_x == nullptr)) return DQQ_E_NULLPTR;
-    dqq::BwdArgs a{P, q, nullptr, nullptr, x, grad_x, grad_P, grad_q, nullptr, nullptr, (long)B, N, p_layout,
-                   ir_steps, nullptr};
+    dqq::BwdArgs a{P,       q,       nullptr, nullptr, x, grad_x,  grad_P,   grad_q,   nullptr, nullptr,
+                   nullptr, nullptr, (long)B, N,       epsilon, p_layout, ir_steps, nullptr};
     return bwd_dispatch(0, a, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 int dqq_qcqp_bwd_f64(const double* P, const double* q, const double* l_n, const double* mu, const double* x,
                      const double* grad_x, double* grad_P, double* grad_q, double* grad_l_n, double* grad_mu,
-                     int64_t B, int N, int p_layout, int* ir_steps, void* workspace, size_t workspace_bytes,
-                     void* stream)
+                     double* gamma, double* dgamma, int64_t B, int N, double epsilon, int p_layout, int* ir_steps,
+                     void* workspace, size_t workspace_bytes, void* stream)
 {
     if (int rc = check_common(B, N, p_layout, true)) return rc;
     if (B > 0 && (P == nullptr || q == nullptr || l_n == nullptr || mu == nullptr || x == nullptr ||
                   grad_x == nullptr))
         return DQQ_E_NULLPTR;
-    dqq::BwdArgs a{P, q, l_n, mu, x, grad_x, grad_P, grad_q, grad_l_n, grad_mu, (long)B, N, p_layout, ir_steps,
-                   nullptr};
+    dqq::BwdArgs a{P,     q,      l_n,     mu, x,       grad_x,   grad_P,   grad_q, grad_l_n, grad_mu,
+                   gamma, dgamma, (long)B, N,  epsilon, p_layout, ir_steps, nullptr};
     return bwd_dispatch(1, a, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 

@@ -51,8 +51,8 @@ __global__ __launch_bounds__(256) void bwd_dense_kernel(
     const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ l_n,
     const double* __restrict__ mu_c, const double* __restrict__ x, const double* __restrict__ grad_x,
     double* __restrict__ grad_P, double* __restrict__ grad_q, double* __restrict__ grad_l_n,
-    double* __restrict__ grad_mu, long B, int n, int* __restrict__ ir_steps, int* __restrict__ ws, int use_worklist,
-    int lds_per_wave)
+    double* __restrict__ grad_mu, double* __restrict__ gamma_out, double* __restrict__ dgamma_out, long B, int n,
+    double dual_eps, int* __restrict__ ir_steps, int* __restrict__ ws, int use_worklist, int lds_per_wave)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256) void bwd_dense_kernel(
     const long nwaves = (long)gridDim.x * wpb;
     for (long w = (long)blockIdx.x * wpb + wave; w < count; w += nwaves) {
         const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
-        dense_bwd_problem<KIND>(P, q, l_n, mu_c, x, grad_x, grad_P, grad_q, grad_l_n, grad_mu, ir_steps, prob, n, sw,
-                                lane);
+        dense_bwd_problem<KIND>(P, q, l_n, mu_c, x, grad_x, grad_P, grad_q, grad_l_n, grad_mu, gamma_out, dgamma_out,
+                                ir_steps, prob, n, dual_eps, sw, lane);
     }
     if (use_worklist) worklist_release(ws, lane, count, (int)nwaves);
 }
@@ -134,13 +134,13 @@ hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipSt
     if (kind == 0) {
         if ((e = set_lds(bwd_dense_kernel<0>, g.lds_bytes)) != hipSuccess) return e;
         hipLaunchKernelGGL(bwd_dense_kernel<0>, dim3(g.grid), dim3(64 * g.wpb), g.lds_bytes, s, a.P, a.q, a.l_n, a.mu,
-                           a.x, a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.B, a.N, a.ir_steps, a.ws,
-                           use_worklist ? 1 : 0, g.lds_per_wave);
+                           a.x, a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.N, a.epsilon,
+                           a.ir_steps, a.ws, use_worklist ? 1 : 0, g.lds_per_wave);
     } else {
         if ((e = set_lds(bwd_dense_kernel<1>, g.lds_bytes)) != hipSuccess) return e;
         hipLaunchKernelGGL(bwd_dense_kernel<1>, dim3(g.grid), dim3(64 * g.wpb), g.lds_bytes, s, a.P, a.q, a.l_n, a.mu,
-                           a.x, a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.B, a.N, a.ir_steps, a.ws,
-                           use_worklist ? 1 : 0, g.lds_per_wave);
+                           a.x, a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.N, a.epsilon,
+                           a.ir_steps, a.ws, use_worklist ? 1 : 0, g.lds_per_wave);
     }
     return hipGetLastError();
 }

@@ -288,7 +288,9 @@ static DQQ_D void dense_bwd_problem(const double* __restrict__ P, const double* 
                                     const double* __restrict__ x, const double* __restrict__ grad_x,
                                     double* __restrict__ grad_P, double* __restrict__ grad_q,
                                     double* __restrict__ grad_l_n, double* __restrict__ grad_mu,
-                                    int* __restrict__ ir_steps, long prob, int n, double* smem, int lane)
+                                    double* __restrict__ gamma_out, double* __restrict__ dgamma_out,
+                                    int* __restrict__ ir_steps, long prob, int n, double dual_eps, double* smem,
+                                    int lane)
 {
 #pragma clang fp contract(off)
     const int nc = n / 2;
@@ -322,7 +324,7 @@ static DQQ_D void dense_bwd_problem(const double* __restrict__ P, const double* 
     if (KIND == 0) {
         // dualFromPrimalQP, Solver.cpp:125-134
         double gamma = actn ? -(row_dot(Pl, ld, lane, vx, n) + qi) : 0.0;
-        if (xi > kActiveEps) gamma = 0;
+        if (xi > dual_eps) gamma = 0;
         const bool is_act = actn && gamma < -kActiveEps;                  // :139-147
         const unsigned long long am = __ballot(is_act);
         const unsigned long long im = __ballot(actn && !is_act);
@@ -356,7 +358,7 @@ static DQQ_D void dense_bwd_problem(const double* __restrict__ P, const double* 
         double gamma = 0.0;
         {
             const double slack = r + -sqrt(xa * xa + xb * xb);
-            if (actc && !(slack > kActiveEps || r < kActiveEps)) {
+            if (actc && !(slack > dual_eps || r < dual_eps)) {
                 const double ca = 2 * xa, cb = 2 * xb;
                 const double G = ca * ca + cb * cb;
                 const double rhs = ca * va[2 * lane] + cb * va[2 * lane + 1];
@@ -402,6 +404,8 @@ static DQQ_D void dense_bwd_problem(const double* __restrict__ P, const double* 
             const double dg = is_act ? vb[lane] : 0.0;
             if (grad_l_n != nullptr) grad_l_n[prob * nc + lane] = QcqpContact::e2(gamma, ln, mc) * dg;
             if (grad_mu != nullptr) grad_mu[prob * nc + lane] = QcqpContact::e1(gamma, ln, mc) * dg;
+            if (gamma_out != nullptr) gamma_out[prob * nc + lane] = gamma;
+            if (dgamma_out != nullptr) dgamma_out[prob * nc + lane] = dg;
         }
     }
     if (actn && grad_q != nullptr) grad_q[prob * n + lane] = -vdl[lane];

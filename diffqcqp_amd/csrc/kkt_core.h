@@ -52,10 +52,10 @@ struct QpCoord {
     bool act;
     double K, Kinv, Ab, KinvAb, xs;
 
-    DQQ_HD void setup(double p, double q, double x, double g)
+    DQQ_HD void setup(double p, double q, double x, double g, double eps = kActiveEps)
     {
         double gamma = -(p * x + q);               // dualFromPrimalQP, :127
-        if (x > kActiveEps) gamma = 0;             // :128-131 (epsilon = 1e-10, pybindings.cpp:24)
+        if (x > eps) gamma = 0;                    // :128-131 (epsilon: pybindings.cpp:24, default 1e-10)
         act = gamma < -kActiveEps;                 // :139-141
         xs = 0.0;
         if (act) { K = Kinv = Ab = KinvAb = 0.0; return; }
@@ -85,14 +85,14 @@ struct QcqpContact {
     double K[3][3], Kinv[3][3], Ab[3], KinvAb[3], xs[3]; // order: gamma, a, b
 
     DQQ_HD void setup(double pa, double pb, double qa, double qb, double xa, double xb, double ga, double gb,
-                      double l_n, double mu)
+                      double l_n, double mu, double eps = kActiveEps)
     {
         const double r = l_n * mu;                             // pybindings.cpp:65
-        // ---- dualFromPrimalQCQP, Solver.cpp:584-617 (epsilon = 1e-10)
+        // ---- dualFromPrimalQCQP, Solver.cpp:584-617 (epsilon: pybindings.cpp:62, default 1e-10)
         {
             const double slack = r + -sqrt(xa * xa + xb * xb); // :594-597
             gamma = 0.0;
-            if (!(slack > kActiveEps || r < kActiveEps)) {     // :598-604
+            if (!(slack > eps || r < eps)) {                   // :598-604
                 const double ca = 2 * xa, cb = 2 * xb;         // A(2i,i), A(2i+1,i), :589-592
                 const double G = ca * ca + cb * cb;            // A~^T A~ (diagonal)
                 const double pla = pa * xa + qa, plb = pb * xb + qb; // P l + q

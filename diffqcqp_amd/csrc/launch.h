@@ -39,8 +39,11 @@ struct BwdArgs {
     double* grad_q;
     double* grad_l_n;
     double* grad_mu;
+    double* gamma;   // QCQP only, optional
+    double* dgamma;  // QCQP only, optional
     long B;
     int N;
+    double epsilon;  // dual-recovery threshold (reference default 1e-10)
     int layout;
     int* ir_steps;
     int* ws;

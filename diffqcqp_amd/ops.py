@@ -78,7 +78,8 @@ def qcqp_forward(P, q, l_n, mu, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, 
     return (x, iters) if return_iters else x
 
 
-def qp_backward(P, q, x, grad_x, need_P=True, need_q=True, layout=_capi.P_AUTO, return_steps=False, out=None):
+def qp_backward(P, q, x, grad_x, need_P=True, need_q=True, layout=_capi.P_AUTO, return_steps=False, out=None,
+                epsilon=1e-10):
     """Implicit-function backward of the QP (reference qcqp.py:36-52). -> (grad_P|None, grad_q|None)"""
     B, N, pshape = _dims(P, q, layout)
     P, q = _prep(P, "P", pshape), _prep(q, "q", (B, N, 1))
@@ -92,17 +93,18 @@ def qp_backward(P, q, x, grad_x, need_P=True, need_q=True, layout=_capi.P_AUTO, 
     steps = torch.empty(B, dtype=torch.int32, device=dev) if return_steps else None
     ws = _workspace(dev, B)
     with torch.cuda.device(dev):
-        rc = _capi.lib().dqq_qp_bwd_f64(_ptr(P), _ptr(q), _ptr(x), _ptr(grad_x), _ptr(gP), _ptr(gq), B, N, layout,
-                                        _ptr(steps), _ptr(ws), ws.numel() * 4,
+        rc = _capi.lib().dqq_qp_bwd_f64(_ptr(P), _ptr(q), _ptr(x), _ptr(grad_x), _ptr(gP), _ptr(gq), B, N,
+                                        float(epsilon), layout, _ptr(steps), _ptr(ws), ws.numel() * 4,
                                         torch.cuda.current_stream().cuda_stream)
     _capi.check(rc, "dqq_qp_bwd_f64")
     return (gP, gq, steps) if return_steps else (gP, gq)
 
 
 def qcqp_backward(P, q, l_n, mu, x, grad_x, need=(True, True, True, True), layout=_capi.P_AUTO, return_steps=False,
-                  out=None):
+                  out=None, epsilon=1e-10, duals=None):
     """Implicit-function backward of the QCQP (reference qcqp.py:156-181).
-    -> (grad_P, grad_q, grad_l_n, grad_mu), None where not needed."""
+    -> (grad_P, grad_q, grad_l_n, grad_mu), None where not needed.  duals: optional pair of (B,N/2,1)
+    tensors that receive the contact duals gamma and their derivative terms dgamma."""
     B, N, pshape = _dims(P, q, layout)
     P, q = _prep(P, "P", pshape), _prep(q, "q", (B, N, 1))
     l_n, mu = _prep(l_n, "l_n", (B, N // 2, 1)), _prep(mu, "mu", (B, N // 2, 1))
@@ -118,8 +120,10 @@ def qcqp_backward(P, q, l_n, mu, x, grad_x, need=(True, True, True, True), layou
     steps = torch.empty(B, dtype=torch.int32, device=dev) if return_steps else None
     ws = _workspace(dev, B)
     with torch.cuda.device(dev):
+        gam, dgam = duals if duals is not None else (None, None)
         rc = _capi.lib().dqq_qcqp_bwd_f64(_ptr(P), _ptr(q), _ptr(l_n), _ptr(mu), _ptr(x), _ptr(grad_x), _ptr(gP),
-                                          _ptr(gq), _ptr(gl), _ptr(gm), B, N, layout, _ptr(steps), _ptr(ws),
-                                          ws.numel() * 4, torch.cuda.current_stream().cuda_stream)
+                                          _ptr(gq), _ptr(gl), _ptr(gm), _ptr(gam), _ptr(dgam), B, N, float(epsilon),
+                                          layout, _ptr(steps), _ptr(ws), ws.numel() * 4,
+                                          torch.cuda.current_stream().cuda_stream)
     _capi.check(rc, "dqq_qcqp_bwd_f64")
     return (gP, gq, gl, gm, steps) if return_steps else (gP, gq, gl, gm)

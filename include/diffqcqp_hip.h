@@ -73,10 +73,12 @@ int dqq_qp_fwd_f64(const double* P, const double* q, double* x, int64_t B, int N
  * (QPFn2.backward -> diffqcqp.solveDerivativesQP, pybindings.cpp:24-30 ->
  * Solver::dualFromPrimalQP / solveDerivativesQP, Solver.cpp:125-196):
  *   grad_P = -dl x^T (B,N,N), grad_q = -dl (B,N,1).  Either may be NULL
- * (ctx.needs_input_grad).  ir_steps (B ints) may be NULL. */
+ * (ctx.needs_input_grad).  epsilon is the dual-recovery threshold of
+ * solveDerivativesQP (pybindings.cpp:24, default 1e-10; qcqp.py never overrides
+ * it).  ir_steps (B ints) may be NULL. */
 int dqq_qp_bwd_f64(const double* P, const double* q, const double* x, const double* grad_x, double* grad_P,
-                   double* grad_q, int64_t B, int N, int p_layout, int* ir_steps, void* workspace,
-                   size_t workspace_bytes, void* stream);
+                   double* grad_q, int64_t B, int N, double epsilon, int p_layout, int* ir_steps,
+                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* Replaces the loop qcqp.py:149-151 (QCQPFn2.forward -> diffqcqp.solveQCQP,
  * pybindings.cpp:54-60 -> Solver::solveQCQP, Solver.cpp:521-582).  l_n and mu
@@ -88,11 +90,15 @@ int dqq_qcqp_fwd_f64(const double* P, const double* q, const double* l_n, const 
 /* Replaces the loop qcqp.py:167-172 + the assembly qcqp.py:173-180
  * (QCQPFn2.backward -> diffqcqp.solveDerivativesQCQP, pybindings.cpp:62-71 ->
  * Solver.cpp:584-691):  grad_P = -dl x^T, grad_q = -dl, grad_l_n = E2 dgamma,
- * grad_mu = E1 dgamma.  Any output may be NULL. */
+ * grad_mu = E1 dgamma.  Any output may be NULL.  gamma / dgamma (B,N/2,1, may be
+ * NULL) expose the contact duals and their derivative terms, from which the
+ * reference's per-problem return value (E1, E2, blgamma) can be rebuilt:
+ * E1 = diag(2 gamma l_n^2 mu), E2 = diag(2 gamma l_n mu^2), blgamma = [dgamma; -grad_q].
+ * epsilon: dual-recovery threshold (pybindings.cpp:62, default 1e-10). */
 int dqq_qcqp_bwd_f64(const double* P, const double* q, const double* l_n, const double* mu, const double* x,
                      const double* grad_x, double* grad_P, double* grad_q, double* grad_l_n, double* grad_mu,
-                     int64_t B, int N, int p_layout, int* ir_steps, void* workspace, size_t workspace_bytes,
-                     void* stream);
+                     double* gamma, double* dgamma, int64_t B, int N, double epsilon, int p_layout,
+                     int* ir_steps, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Tuning knobs (process-wide, read at launch time).  Unknown name -> DQQ_E_BAD_OPTION.
  *   "fwd_lpp"        lanes per problem of the diagonal forward kernel (0 = built-in choice from B)

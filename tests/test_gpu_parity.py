@@ -338,6 +338,46 @@ def test_autograd_functions_match_reference_contract(oracle, ops):
     assert len(out) == 6 and out[0] is None and out[2:] == (None, None, None, None)
 
 
+def test_unbatched_twins_and_module_level_api(oracle, ops):
+    """qcqp_no_batch.py shapes and the `diffqcqp` module-level numpy functions
+    (same names / kwargs / return shapes as pybindings.cpp:74-83), checked against the oracle's twins."""
+    from diffqcqp_amd import diffqcqp as M
+    from diffqcqp_amd import qcqp_no_batch as NB
+    for structure in ("diag", "dense"):
+        d = make_problem("qcqp", 3, 8, 950, structure)
+        for b in range(3):
+            P, q, g = d["P"][b].numpy(), d["q"][b].numpy(), d["grad_x"][b, :, 0].numpy()
+            ln, mu = d["l_n"][b].numpy(), d["mu"][b].numpy()
+            x = M.solveQP(P, q, np.zeros(8), 1e-7, 1e-7, 1000, True)
+            xo = oracle.solveQP(P, q, None, 1e-7, 1e-7, 1000, True)
+            assert x.shape == (8,) and np.abs(x - xo).max() < 1e-9
+            bl = M.solveDerivativesQP(P, q, xo, g)
+            assert bl.shape == (8,) and np.allclose(bl, oracle.solveDerivativesQP(P, q, xo, g), rtol=1e-9, atol=1e-12)
+            assert np.allclose(M.solveDerivativesQP(P, q, xo, g, epsilon=1e-3), oracle.solveDerivativesQP(P, q, xo, g, 1e-3),
+                               rtol=1e-9, atol=1e-12)
+            xq = M.solveQCQP(P, q, ln, mu, np.zeros(8), epsilon=1e-7, max_iter=1000)
+            xqo = oracle.solveQCQP(P, q, ln, mu, None, 1e-7, 1e-7, 1000)
+            assert np.abs(xq - xqo).max() < 1e-9
+            E1, E2, blg = M.solveDerivativesQCQP(P, q, ln, mu, xqo, g)
+            E1o, E2o, blgo = oracle.solveDerivativesQCQP(P, q, ln, mu, xqo, g)
+            assert E1.shape == (4, 4) and blg.shape == (12,)
+            assert np.allclose(E1, E1o, rtol=1e-9, atol=1e-13) and np.allclose(E2, E2o, rtol=1e-9, atol=1e-13)
+            assert np.allclose(blg, blgo, rtol=1e-9, atol=1e-12)
+    # unbatched autograd twins
+    d = make_problem("qcqp", 1, 8, 951, "dense")
+    P = d["P"][0].clone().requires_grad_(True)
+    q = d["q"][0].clone().requires_grad_(True)
+    l_n, mu = d["l_n"][0].clone().requires_grad_(True), d["mu"][0].clone().requires_grad_(True)
+    x = NB.QCQPFn2.apply(P, q, l_n, mu, torch.zeros(8, 1), 1e-7, 1000)
+    assert x.shape == (8,)
+    (x * d["grad_x"][0, :, 0]).sum().backward()
+    assert P.grad.shape == (8, 8) and q.grad.shape == (8, 1) and l_n.grad.shape == (4, 1) and mu.grad.shape == (4, 1)
+    xo, _ = oracle_fwd(oracle, "qcqp", d)
+    assert np.abs(x.detach().numpy() - xo[0, :, 0]).max() < 1e-9
+    xq = NB.QPFn2.apply(d["P"][0], q, torch.zeros(8, 1), 1e-7, 1000)
+    assert xq.shape == (8,)
+
+
 def test_runs_on_a_non_default_stream(oracle, ops):
     d = make_problem("qp", 300, 8, 903)
     g = dev(d)
