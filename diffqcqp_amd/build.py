@@ -25,6 +25,7 @@ UNITS = {
     "bwd_diag.hip": ["-ffp-contract=off"],
     "dense.hip": ["-ffp-contract=off"],
     "dense_block.hip": ["-ffp-contract=off"],
+    "fwd_lane_dense.hip": ["-ffp-contract=fast"],
     "capi.hip": ["-ffp-contract=off", "-fvisibility=default"],
 }
 

@@ -8,6 +8,7 @@
 
 namespace dqq {
 extern std::atomic<int> g_dense_block;
+extern std::atomic<int> g_lane_dense;
 }
 
 namespace {
@@ -23,7 +24,8 @@ struct Option {
 };
 Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback", &g_auto_fallback},
                       {"fuse_fallback", &g_fuse},
-                      {"dense_block", &dqq::g_dense_block}};
+                      {"dense_block", &dqq::g_dense_block},
+                      {"lane_dense", &dqq::g_lane_dense}};
 
 int check_common(int64_t B, int N, int p_layout, bool qcqp)
 {

@@ -9,6 +9,7 @@
 namespace dqq {
 
 std::atomic<int> g_dense_block{1}; // 0: always the wave-per-problem kernel (option "dense_block")
+std::atomic<int> g_lane_dense{1};  // 0: never the lane-per-problem kernel of N <= 8 (option "lane_dense")
 
 // Last wave out re-zeroes the work-list header for the next call.  With an empty work-list (the
 // common case: every tile was diagonal) there is nothing to reset and nobody touches the ticket --
@@ -108,6 +109,8 @@ static DenseGeom dense_geom(int lds_doubles, long B, bool use_worklist)
 hipError_t launch_fwd_dense(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
+    if (fwd_lane_dense_supported(a.N) && g_lane_dense.load() != 0)
+        return launch_fwd_lane_dense(kind, a, use_worklist, s);
     if (fwd_dense_block_supported(a.N) && g_dense_block.load() != 0)
         return launch_fwd_dense_block(kind, a, use_worklist, s);
     const DenseGeom g = dense_geom(dense_fwd_lds_doubles(a.N), a.B, use_worklist);

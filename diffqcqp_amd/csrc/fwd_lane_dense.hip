@@ -1,0 +1,289 @@
+// fwd_lane_dense.hip -- general (dense P) forward solve for small N (2, 4, 6, 8): ONE LANE PER
+// PROBLEM, everything in VGPRs, no LDS, no barriers.
+//
+// A contact problem with 4 contacts has a dense 8x8 Delassus matrix P; one wave64 per problem
+// (dense_core.h) leaves 56 of 64 lanes idle on it.  Here each lane holds its problem's whole state --
+// the 8x8 explicit inverse of P + (rho+mu) I (64 doubles), the lower triangle of P (36), the ADMM
+// vectors -- in registers (one wave per SIMD, ~400 VGPRs), every loop is fully unrolled with static
+// register indices, and a wave advances 64 problems per instruction.
+//
+// Algorithm and operation order are the reference's (Solver::solveQP / solveQCQP, Solver.cpp:61-123,
+// 521-582; power_iteration :46-59; left-looking LLT and column-wise substitutions for the explicit
+// inverse, :76-77): same rho / tau / cpt state machine and stopping tests as admm_core.h, which this
+// file mirrors with a dense mat-vec in place of the diagonal scale.  Ulp-level departures as in the
+// diagonal fast path: FMA contraction, reciprocal-multiply instead of divide (1-ulp rcp / rsqrt).
+// The rho-update branch (refactorisation, ~700 instructions) runs under the exec mask of the lanes
+// that fire in that iteration.
+#include "admm_core.h"
+#include "launch.h"
+
+namespace dqq {
+
+// Explicit inverse of the symmetric matrix whose strict lower triangle is Plow and whose diagonal is
+// d: lower Cholesky (left-looking, as Eigen's unblocked LLT), then per column L y = e_c, L^T x = y.
+template <int N>
+DQQ_D void lane_chol_inverse(const double (&Plow)[N][N], const double (&d)[N], double (&Minv)[N][N], bool& bad)
+{
+    double L[N][N], rinv[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < k; ++j) s += L[k][j] * L[k][j];
+        const double piv = d[k] - s;
+        bad = bad || !(piv > 0.0);
+        const double rs = fast_rsqrt(piv);
+        L[k][k] = piv * rs;
+        rinv[k] = rs;
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < k; ++j) t += L[i][j] * L[k][j];
+            L[i][k] = (Plow[i][k] - t) * rs;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+        double y[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (i < c) { y[i] = 0.0; continue; }
+            double t = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int j = c; j < i; ++j) t -= L[i][j] * y[j];
+            y[i] = t * rinv[i];
+        }
+#pragma unroll
+        for (int i = N - 1; i >= 0; --i) {
+            double t = y[i];
+#pragma unroll
+            for (int j = i + 1; j < N; ++j) t -= L[j][i] * y[j];
+            y[i] = t * rinv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) Minv[i][c] = y[i];
+    }
+}
+
+template <int KIND, int N>
+__global__ __launch_bounds__(64, 1) void fwd_lane_dense_kernel(const double* __restrict__ P,
+                                                               const double* __restrict__ q,
+                                                               const double* __restrict__ l_n,
+                                                               const double* __restrict__ mu_c, double* __restrict__ x,
+                                                               long B, double eps, double mu, int max_iter,
+                                                               int adaptive, int* __restrict__ iters,
+                                                               int* __restrict__ ws, int use_worklist)
+{
+    static_assert(N % 2 == 0, "even N");
+    const long count = use_worklist ? (long)ws[kWsCount] : B;
+    const long slot = (long)blockIdx.x * 64 + threadIdx.x;
+    const bool valid = slot < count;
+    if ((long)blockIdx.x * 64 >= count) { // a wave beyond the end of the work-list: only the reset ticket
+        if (use_worklist && count > 0 && threadIdx.x == 0) {
+            const int tk = atomicAdd(&ws[kWsTicket], 1);
+            if (tk == (int)gridDim.x - 1) {
+                ws[kWsCount] = 0;
+                ws[kWsTicket] = 0;
+            }
+        }
+        return;
+    }
+    const long prob = valid ? (use_worklist ? (long)ws[kWsEntries + slot] : slot) : 0;
+
+    // ---- load: P (lower triangle kept, full matrix used by the power iteration), q, radius
+    double Pm[N][N];
+    {
+        const double* Pg = P + prob * (long)(N * N);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; j += 2) {
+                const double2 t = valid ? *reinterpret_cast<const double2*>(Pg + i * N + j) : make_double2(0.0, 0.0);
+                Pm[i][j] = t.x;
+                Pm[i][j + 1] = t.y;
+            }
+        if (!valid) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) Pm[i][i] = 1.0;
+        }
+    }
+    double qv[N], rad[N / 2];
+#pragma unroll
+    for (int i = 0; i < N; i += 2) {
+        const double2 t = valid ? *reinterpret_cast<const double2*>(q + prob * N + i) : make_double2(0.0, 0.0);
+        qv[i] = t.x;
+        qv[i + 1] = t.y;
+    }
+#pragma unroll
+    for (int c = 0; c < N / 2; ++c)
+        rad[c] = (KIND == 1 && valid) ? l_n[prob * (N / 2) + c] * mu_c[prob * (N / 2) + c] : 1.0;
+
+    // ---- power_iteration, Solver.cpp:46-59
+    double Lmax;
+    {
+        double v[N];
+        const double c0 = 1.0 / sqrt((double)N);
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) { v[i] = c0; s += c0 * c0; }
+        if (s > 0) {
+            const double nn = sqrt(s);
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = v[i] / nn;
+        }
+        const int pi_steps = (KIND == 0) ? 10 : 100;
+        for (int k = 0; k < pi_steps; ++k) {
+            double Av[N];
+            s = 0.0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                double t = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) t += Pm[i][j] * v[j];
+                Av[i] = t;
+                s += t * t;
+            }
+            const double inv = (s > 0) ? fast_rsqrt(s) : 1.0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) v[i] = Av[i] * inv;
+        }
+        Lmax = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) t += Pm[i][j] * v[j];
+            Lmax += v[i] * t;
+        }
+    }
+
+    // ---- Solver.cpp:72-77 / 531-536
+    double rho = sqrt(mu * Lmax) * pow(Lmax / mu, .4);
+    double tau_inc = pow(Lmax / mu, .15), tau_dec = tau_inc;
+    double inv_rho = fast_rcp(rho);
+    bool bad = !(rho > 0.0) || !(rho < 1.79e308);
+    double md[N], Minv[N][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) md[i] = Pm[i][i] + (rho + mu);   // the accumulated shifted diagonal
+    lane_chol_inverse<N>(Pm, md, Minv, bad);                       // only the lower triangle of Pm is read
+
+    double qp[N], l2[N], u[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { qp[i] = qv[i]; l2[i] = 0.0; u[i] = 0.0; }
+
+    int rho_up = 0, cpt = 0, it_done = 0;
+    bool done = !valid;
+    for (int it = 0; it < max_iter; ++it) {
+        if (!done) {
+            double rhs[N], w[N], z[N];
+            double rd = 0.0, rp = 0.0, nl = 0.0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) rhs[i] = rho * l2[i] - u[i] - qp[i];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                double l = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) l += Minv[i][j] * rhs[j];             // :80 / :539
+                qp[i] = qv[i] - mu * l;                                           // :81 / :540
+                w[i] = kAlpha * l + (1 - kAlpha) * l2[i];
+                z[i] = w[i] + u[i] * inv_rho;                                     // :82 / :541
+                if (KIND == 1) nl += l * l;
+            }
+            if (KIND == 0) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) z[i] = fmax(z[i], 0.0);
+            } else {
+#pragma unroll
+                for (int c = 0; c < N / 2; ++c) {                                 // prox_circle, :505-519
+                    const double a = z[2 * c], b = z[2 * c + 1];
+                    const double n2 = a * a + b * b;
+                    const double rn = fast_rsqrt(n2);
+                    const double nrm = n2 * rn;
+                    if (nrm > rad[c]) {
+                        const double sc = rad[c] * rn;
+                        z[2 * c] = a * sc;
+                        z[2 * c + 1] = b * sc;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                u[i] += rho * (w[i] - z[i]);                                      // :83 / :543
+                rd = fmax(rd, fabs(z[i] - l2[i]));
+                rp = fmax(rp, fabs(z[i] - w[i]));
+                l2[i] = z[i];
+            }
+            const double res_dual = rho * rd, res_prim = rp;
+            it_done = it + 1;
+            bool stop = res_dual < eps;                                           // :88
+            if (KIND == 1) {
+                if (stop) stop = res_prim < eps + kEpsRel * sqrt(nl);             // :548
+            }
+            done = stop;
+            if (!stop && adaptive) {
+                const bool inc = res_prim > kMuThresh * res_dual;                 // :92 / :552
+                const bool dec = !inc && (res_dual > kMuThresh * res_prim);       // :106 / :566
+                const bool imb = inc || dec;
+                const bool fire = imb && (cpt == 0);
+                cpt = imb ? (cpt == 4 ? 0 : cpt + 1) : cpt;
+                if (fire) {
+                    if (rho_up == (inc ? -1 : 1)) {
+                        const double ti = 1 + .8 * (tau_inc - 1), td = 1 + .8 * (tau_dec - 1);
+                        if (KIND == 0) { tau_inc = ti; tau_dec = td; }
+                        else if (inc) tau_inc = ti;
+                        else tau_dec = td;
+                    }
+                    const double f = inc ? tau_inc : fast_rcp(tau_dec);
+                    const double delta = rho * (f - 1);
+                    rho = rho * f;
+                    rho_up = inc ? 1 : -1;
+                    inv_rho = fast_rcp(rho);
+#pragma unroll
+                    for (int i = 0; i < N; ++i) md[i] += delta;
+                    lane_chol_inverse<N>(Pm, md, Minv, bad);                      // llt() + solveInPlace(Identity)
+                }
+            }
+        }
+        if (__all(done)) break;
+    }
+
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < N; i += 2)
+            *reinterpret_cast<double2*>(x + prob * N + i) =
+                make_double2(bad ? NAN : l2[i], bad ? NAN : l2[i + 1]);
+        if (iters != nullptr) iters[prob] = it_done;
+    }
+    // work-list mode: the last wave out re-zeroes the header (nothing to do for an empty list)
+    if (use_worklist && count > 0 && threadIdx.x == 0) {
+        const int tk = atomicAdd(&ws[kWsTicket], 1);
+        if (tk == (int)gridDim.x - 1) {
+            ws[kWsCount] = 0;
+            ws[kWsTicket] = 0;
+        }
+    }
+}
+
+template <int KIND, int N>
+static hipError_t launch_lane(const FwdArgs& a, bool use_worklist, hipStream_t s)
+{
+    const long nw = (a.B + 63) / 64;
+    if (nw == 0) return hipSuccess;
+    hipLaunchKernelGGL((fwd_lane_dense_kernel<KIND, N>), dim3((unsigned)nw), dim3(64), 0, s, a.P, a.q, a.l_n, a.mu, a.x,
+                       a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0);
+    return hipGetLastError();
+}
+
+bool fwd_lane_dense_supported(int N) { return N == 2 || N == 4 || N == 6 || N == 8; }
+
+hipError_t launch_fwd_lane_dense(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s)
+{
+#define DQQ_CASE(NN) \
+    if (a.N == NN) return kind == 0 ? launch_lane<0, NN>(a, use_worklist, s) : launch_lane<1, NN>(a, use_worklist, s);
+    DQQ_CASE(2) DQQ_CASE(4) DQQ_CASE(6) DQQ_CASE(8)
+#undef DQQ_CASE
+    return hipErrorInvalidValue;
+}
+
+} // namespace dqq

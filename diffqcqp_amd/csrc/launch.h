@@ -72,6 +72,9 @@ hipError_t launch_bwd_diag(int kind, const BwdArgs& a, int wpb, int fuse_opt, hi
 // fast path queued in a.ws, then re-zero the work-list header.
 int dense_max_n(int kind); // 0 QP fwd/bwd, 1 QCQP fwd, 2 QCQP bwd
 hipError_t launch_fwd_dense(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s);
+// lane-per-problem forward for N = 2, 4, 6, 8 (fwd_lane_dense.hip); launch_fwd_dense routes to it
+bool fwd_lane_dense_supported(int N);
+hipError_t launch_fwd_lane_dense(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s);
 // workgroup-per-problem forward for N = 32, 64 (dense_block.hip); launch_fwd_dense routes to it
 bool fwd_dense_block_supported(int N);
 hipError_t launch_fwd_dense_block(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s);

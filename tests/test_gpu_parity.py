@@ -42,6 +42,7 @@ def ops():
     _capi.set_option("wpb", 0)
     _capi.set_option("fuse_fallback", -1)
     _capi.set_option("dense_block", 1)
+    _capi.set_option("lane_dense", 1)
 
 
 def dev(d):
@@ -219,6 +220,31 @@ def test_block_and_wave_dense_forward_agree(oracle, ops, kind, N, B):
         out[blk] = hip_fwd(ops, kind, g, layout=_capi.P_DENSE)
         check_forward(out[blk][0], out[blk][1], xo, ito, min_match=0.9)
     _capi.set_option("dense_block", 1)
+    assert (out[0][0] - out[1][0]).abs().max() < 1e-8
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("N,B", [(8, 1000), (6, 130), (4, 300), (2, 65)])
+def test_lane_and_wave_dense_forward_agree(oracle, ops, kind, N, B):
+    """N <= 8 forward has two general kernels: lane-per-problem (default) and wave-per-problem."""
+    from diffqcqp_amd import _capi
+    d = make_problem(kind, B, N, 660 + N, "dense")
+    g = dev(d)
+    xo, ito = oracle_fwd(oracle, kind, d)
+    out = {}
+    for lane in (1, 0):
+        _capi.set_option("lane_dense", lane)
+        out[lane] = hip_fwd(ops, kind, g, layout=_capi.P_DENSE)
+        check_forward(out[lane][0], out[lane][1], xo, ito, min_match=0.99)
+    # AUTO with the in-kernel fallback switched off: fast path -> work-list -> lane kernel
+    _capi.set_option("lane_dense", 1)
+    _capi.set_option("fuse_fallback", 0)
+    dm = make_problem(kind, B, N, 670 + N, "mixed")
+    xm, im = oracle_fwd(oracle, kind, dm)
+    for _ in range(2):
+        xh, ih = hip_fwd(ops, kind, dev(dm))
+        check_forward(xh, ih, xm, im, min_match=0.99)
+    _capi.set_option("fuse_fallback", -1)
     assert (out[0][0] - out[1][0]).abs().max() < 1e-8
 
 
