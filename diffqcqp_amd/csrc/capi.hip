@@ -27,6 +27,49 @@ Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback"
                       {"dense_block", &dqq::g_dense_block},
                       {"lane_dense", &dqq::g_lane_dense}};
 
+// Performance hint of the AUTO layout (never affects results): a host-mapped word into which the
+// forward fast path stores the generation number of its launch when it meets a non-diagonal tile.  If
+// the previous AUTO call left its generation there, this batch is probably dense as well, and queueing
+// its tiles for the lane-per-problem kernel (~0.1 ms per 65536 dense 8x8 problems) beats solving them
+// one wave at a time inside the fast kernel (~1.2 ms); otherwise the in-kernel fallback saves a launch.
+// Read without synchronisation: it lags when calls are enqueued faster than the GPU runs them.
+std::atomic<int*> g_hint_host{nullptr};
+std::atomic<int*> g_hint_dev{nullptr};
+std::atomic<int> g_hint_gen{0};
+
+int* hint_device_pointer()
+{
+    int* d = g_hint_dev.load();
+    if (d != nullptr) return d;
+    int* h = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&h), 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    *h = 0;
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipHostFree(h);
+        return nullptr;
+    }
+    int* expected = nullptr;
+    if (!g_hint_dev.compare_exchange_strong(expected, d)) { // another thread won the race
+        (void)hipHostFree(h);
+        return expected;
+    }
+    g_hint_host.store(h);
+    return d;
+}
+
+// Returns this launch's generation; *dense_before = the previous launch reported non-diagonal tiles.
+int hint_next_generation(bool* dense_before)
+{
+    const int gen = g_hint_gen.fetch_add(1) + 1;
+    int* h = g_hint_host.load();
+    *dense_before = h != nullptr && gen > 1 && *reinterpret_cast<volatile int*>(h) == gen - 1;
+    return gen;
+}
+
 int check_common(int64_t B, int N, int p_layout, bool qcqp)
 {
     if (B < 0 || N < 1 || B > 0x7fffffffLL) return DQQ_E_BAD_SIZE;
@@ -95,7 +138,16 @@ static int fwd_dispatch(int kind, dqq::FwdArgs& a, void* workspace, size_t works
     if (int rc = check_ws(workspace, workspace_bytes, a.B)) return rc;
     a.ws = static_cast<int*>(workspace);
     bool needs_fallback = true;
-    e = dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), g_fuse.load(), s, &needs_fallback);
+    int fuse = g_fuse.load();
+    if (fuse < 0 && dqq::fwd_lane_dense_supported(a.N)) {
+        a.hint = hint_device_pointer();
+        if (a.hint != nullptr) {
+            bool dense_before = false;
+            a.hint_gen = hint_next_generation(&dense_before);
+            if (dense_before) fuse = 0; // dense batch: queue the tiles for the lane-per-problem kernel
+        }
+    }
+    e = dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), fuse, s, &needs_fallback);
     if (e != hipSuccess) return (int)e;
     if (needs_fallback && dense_ok && g_auto_fallback.load() != 0) e = dqq::launch_fwd_dense(kind, a, true, s);
     return (int)e;
@@ -132,7 +184,7 @@ int dqq_qp_fwd_f64(const double* P, const double* q, double* x, int64_t B, int N
     if (int rc = check_common(B, N, p_layout, false)) return rc;
     if (B > 0 && (P == nullptr || q == nullptr || x == nullptr)) return DQQ_E_NULLPTR;
     dqq::FwdArgs a{P, q, nullptr, nullptr, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0,
-                   p_layout, iters, nullptr};
+                   p_layout, iters, nullptr, nullptr, 0};
     return fwd_dispatch(0, a, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
@@ -144,7 +196,7 @@ int dqq_qcqp_fwd_f64(const double* P, const double* q, const double* l_n, const 
     if (B > 0 && (P == nullptr || q == nullptr || l_n == nullptr || mu == nullptr || x == nullptr))
         return DQQ_E_NULLPTR;
     dqq::FwdArgs a{P, q, l_n, mu, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0, p_layout, iters,
-                   nullptr};
+                   nullptr, nullptr, 0};
     return fwd_dispatch(1, a, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
                                                             const double* __restrict__ mu_c, double* __restrict__ x,
                                                             long B, double eps, double mu_prox, int max_iter,
                                                             int adaptive, int layout, int* __restrict__ iters,
-                                                            int* __restrict__ ws)
+                                                            int* __restrict__ ws, int* __restrict__ hint, int hint_gen)
 {
     constexpr int E = N / LPP;       // coordinates per lane
     constexpr int PPW = 64 / LPP;    // problems per wave tile
@@ -67,6 +67,10 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
         const unsigned nz = (nvalid == PPW) ? stream_tile_diag<N, NCH, false>(Pw, limit, sd, lane)
                                             : stream_tile_diag<N, NCH, true>(Pw, limit, sd, lane);
         if (__any(nz != 0)) { // wave-uniform
+            // tell the host (performance hint only, read without synchronisation before the NEXT call) that
+            // this launch met a non-diagonal tile: one posted store per launch, de-duplicated in L2
+            if (hint != nullptr && lane == 0 && atomicMax(&ws[kWsHintGen], hint_gen) < hint_gen)
+                __hip_atomic_store(hint, hint_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if constexpr (FUSE) {
                 for (int j = 0; j < nvalid; ++j)
                     dense_fwd_problem<KIND>(P, q, l_n, mu_c, x, iters, first + j, N, eps, mu_prox, max_iter, adaptive,
@@ -119,7 +123,7 @@ static hipError_t launch_one(const FwdArgs& a, hipStream_t s)
     const long nblocks = (ntiles + WPB - 1) / WPB;
     if (nblocks == 0) return hipSuccess;
     hipLaunchKernelGGL((fwd_diag_kernel<KIND, N, LPP, WPB, FUSE>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q,
-                       a.l_n, a.mu, a.x, a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.layout, a.iters, a.ws);
+                       a.l_n, a.mu, a.x, a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.layout, a.iters, a.ws, a.hint, a.hint_gen);
     return hipGetLastError();
 }
 

@@ -12,6 +12,7 @@ namespace dqq {
 // re-zeroes both), entries from [kWsEntries].
 constexpr int kWsCount = 0;
 constexpr int kWsTicket = 1;
+constexpr int kWsHintGen = 2; // generation of the last launch that already reported a non-diagonal tile
 constexpr int kWsEntries = 4;
 
 struct FwdArgs {
@@ -26,6 +27,8 @@ struct FwdArgs {
     int max_iter, adaptive, layout;
     int* iters;
     int* ws;
+    int* hint;    // host-mapped word: generation of the last launch that met a non-diagonal tile (may be null)
+    int hint_gen; // generation of this launch
 };
 
 struct BwdArgs {

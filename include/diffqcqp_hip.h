@@ -17,8 +17,9 @@
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL =
  *     the default stream) and the call returns without synchronising;
  *   - return value: 0 on success, <0 for an invalid argument (DQQ_E_*), >0 a
- *     hipError_t from the launch.  Nothing throws, there is no global state
- *     besides the tuning knobs of dqq_set_option();
+ *     hipError_t from the launch.  Nothing throws; the only process-wide state is
+ *     the tuning knobs of dqq_set_option() and one host-mapped counter used as a
+ *     performance hint by DQQ_P_AUTO (it never changes a result);
  *   - like the reference (Solver.cpp:76, :100), numerical failure is not
  *     signalled: a non-PD P or L=0 yields NaNs in the output;
  *   - `warm_start` does not appear: the reference accepts it and overwrites it
@@ -55,8 +56,9 @@ extern "C" {
 
 /* Bytes of device workspace the calls below need for a batch of B problems
  * (fallback work-list of the AUTO layout).  The workspace must be zero-filled
- * ONCE when it is allocated; every call leaves it zeroed again.  One workspace
- * must not be shared by calls that may run concurrently on different streams. */
+ * ONCE when it is allocated; every call leaves its work-list empty again.  One
+ * workspace must not be shared by calls that may run concurrently on different
+ * streams. */
 size_t dqq_workspace_bytes(int64_t B);
 
 /* Largest N accepted: kind 0 = QP forward/backward, 1 = QCQP forward, 2 = QCQP backward. */

@@ -289,7 +289,7 @@ def test_auto_layout_mixed_batch_uses_fallback(oracle, ops, kind, N):
         grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda())
         check_backward_exact(grads, st, oracle_bwd(oracle, kind, d, xo), exact=False)
     for ws in ops._workspaces.values():
-        assert int(ws[:4].abs().sum()) == 0
+        assert int(ws[:2].abs().sum()) == 0  # work-list count and exit ticket are left zeroed
 
 
 def test_single_nonzero_offdiagonal_is_detected(oracle, ops):
