@@ -9,6 +9,7 @@
 namespace dqq {
 extern std::atomic<int> g_dense_block;
 extern std::atomic<int> g_lane_dense;
+extern std::atomic<int> g_dense_teams;
 }
 
 namespace {
@@ -25,7 +26,8 @@ struct Option {
 Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback", &g_auto_fallback},
                       {"fuse_fallback", &g_fuse},
                       {"dense_block", &dqq::g_dense_block},
-                      {"lane_dense", &dqq::g_lane_dense}};
+                      {"lane_dense", &dqq::g_lane_dense},
+                      {"dense_teams", &dqq::g_dense_teams}};
 
 // Performance hint of the AUTO layout (never affects results): a host-mapped word into which the
 // forward fast path stores the generation number of its launch when it meets a non-diagonal tile.  If
@@ -36,6 +38,7 @@ Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback"
 std::atomic<int*> g_hint_host{nullptr};
 std::atomic<int*> g_hint_dev{nullptr};
 std::atomic<int> g_hint_gen{0};
+std::atomic<int> g_last_auto_dense{0}; // decision of the most recent AUTO forward, reused by the backward
 
 int* hint_device_pointer()
 {
@@ -145,6 +148,7 @@ static int fwd_dispatch(int kind, dqq::FwdArgs& a, void* workspace, size_t works
             bool dense_before = false;
             a.hint_gen = hint_next_generation(&dense_before);
             if (dense_before) fuse = 0; // dense batch: queue the tiles for the lane-per-problem kernel
+            g_last_auto_dense.store(dense_before ? 1 : 0);
         }
     }
     e = dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), fuse, s, &needs_fallback);
@@ -171,7 +175,9 @@ static int bwd_dispatch(int kind, dqq::BwdArgs& a, void* workspace, size_t works
     if (int rc = check_ws(workspace, workspace_bytes, a.B)) return rc;
     a.ws = static_cast<int*>(workspace);
     bool needs_fallback = true;
-    e = dqq::launch_bwd_diag(kind, a, g_wpb.load(), g_fuse.load(), s, &needs_fallback);
+    int fuse = g_fuse.load();
+    if (fuse < 0 && g_last_auto_dense.load() != 0) fuse = 0; // the forward found a dense batch: packed general kernel
+    e = dqq::launch_bwd_diag(kind, a, g_wpb.load(), fuse, s, &needs_fallback);
     if (e != hipSuccess) return (int)e;
     if (needs_fallback && dense_ok && g_auto_fallback.load() != 0) e = dqq::launch_bwd_dense(kind, a, true, s);
     return (int)e;

@@ -10,6 +10,7 @@ namespace dqq {
 
 std::atomic<int> g_dense_block{1}; // 0: always the wave-per-problem kernel (option "dense_block")
 std::atomic<int> g_lane_dense{1};  // 0: never the lane-per-problem kernel of N <= 8 (option "lane_dense")
+std::atomic<int> g_dense_teams{1}; // 0: backward always one problem per wave (option "dense_teams")
 
 // Last wave out re-zeroes the work-list header for the next call.  With an empty work-list (the
 // common case: every tile was diagonal) there is nothing to reset and nobody touches the ticket --
@@ -47,25 +48,28 @@ __global__ __launch_bounds__(256) void fwd_dense_kernel(const double* __restrict
     if (use_worklist) worklist_release(ws, lane, count, (int)nwaves);
 }
 
-template <int KIND>
+// Backward: 64/T problems per wave (dense_core.h: team width T), each team in its own LDS slice.
+template <int KIND, int T>
 __global__ __launch_bounds__(256) void bwd_dense_kernel(
     const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ l_n,
     const double* __restrict__ mu_c, const double* __restrict__ x, const double* __restrict__ grad_x,
     double* __restrict__ grad_P, double* __restrict__ grad_q, double* __restrict__ grad_l_n,
     double* __restrict__ grad_mu, double* __restrict__ gamma_out, double* __restrict__ dgamma_out, long B, int n,
-    double dual_eps, int* __restrict__ ir_steps, int* __restrict__ ws, int use_worklist, int lds_per_wave)
+    double dual_eps, int* __restrict__ ir_steps, int* __restrict__ ws, int use_worklist, int lds_per_team)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int TP = 64 / T; // teams per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    double* sw = smem + wave * lds_per_wave;
+    const int team = lane / T, tl = lane % T;
+    double* sw = smem + (wave * TP + team) * lds_per_team;
     const long count = use_worklist ? (long)ws[kWsCount] : B;
-    const long nwaves = (long)gridDim.x * wpb;
-    for (long w = (long)blockIdx.x * wpb + wave; w < count; w += nwaves) {
+    const long nteams = (long)gridDim.x * wpb * TP;
+    for (long w = ((long)blockIdx.x * wpb + wave) * TP + team; w < count; w += nteams) {
         const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
-        dense_bwd_problem<KIND>(P, q, l_n, mu_c, x, grad_x, grad_P, grad_q, grad_l_n, grad_mu, gamma_out, dgamma_out,
-                                ir_steps, prob, n, dual_eps, sw, lane);
+        dense_bwd_problem<KIND, T>(P, q, l_n, mu_c, x, grad_x, grad_P, grad_q, grad_l_n, grad_mu, gamma_out, dgamma_out,
+                                   ir_steps, prob, n, dual_eps, sw, tl);
     }
-    if (use_worklist) worklist_release(ws, lane, count, (int)nwaves);
+    if (use_worklist) worklist_release(ws, lane, count, (int)(gridDim.x * wpb));
 }
 
 // ---------------------------------------------------------------- launchers
@@ -129,23 +133,44 @@ hipError_t launch_fwd_dense(int kind, const FwdArgs& a, bool use_worklist, hipSt
     return hipGetLastError();
 }
 
+template <int KIND, int T>
+static hipError_t launch_bwd_team(const BwdArgs& a, bool use_worklist, hipStream_t s)
+{
+    constexpr int TP = 64 / T;
+    const int lds_per_team = (dense_bwd_lds_doubles(KIND, a.N) + 1) & ~1;
+    const size_t per_wave = sizeof(double) * (size_t)lds_per_team * TP;
+    int wpb = (int)((64 * 1024) / per_wave);
+    wpb = wpb > 4 ? 4 : (wpb < 1 ? 1 : wpb);
+    const size_t lds_bytes = per_wave * wpb;
+    const long per_block = (long)wpb * TP;
+    const long need = (a.B + per_block - 1) / per_block;
+    const long cap = 256L * 8;
+    const unsigned grid = use_worklist ? 512u : (unsigned)(need < cap ? (need > 0 ? need : 1) : cap);
+    auto kernel = bwd_dense_kernel<KIND, T>;
+    hipError_t e = set_lds(kernel, lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * wpb), lds_bytes, s, a.P, a.q, a.l_n, a.mu, a.x, a.grad_x, a.grad_P,
+                       a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.N, a.epsilon, a.ir_steps, a.ws,
+                       use_worklist ? 1 : 0, lds_per_team);
+    return hipGetLastError();
+}
+
+template <int KIND>
+static hipError_t launch_bwd_kind(const BwdArgs& a, bool use_worklist, hipStream_t s)
+{
+    const int rows = dense_bwd_rows(KIND, a.N); // lanes a problem needs
+    if (g_dense_teams.load() != 0) {
+        if (rows <= 8) return launch_bwd_team<KIND, 8>(a, use_worklist, s);
+        if (rows <= 16) return launch_bwd_team<KIND, 16>(a, use_worklist, s);
+        if (rows <= 32) return launch_bwd_team<KIND, 32>(a, use_worklist, s);
+    }
+    return launch_bwd_team<KIND, 64>(a, use_worklist, s);
+}
+
 hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
-    const DenseGeom g = dense_geom(dense_bwd_lds_doubles(kind, a.N), a.B, use_worklist);
-    hipError_t e;
-    if (kind == 0) {
-        if ((e = set_lds(bwd_dense_kernel<0>, g.lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(bwd_dense_kernel<0>, dim3(g.grid), dim3(64 * g.wpb), g.lds_bytes, s, a.P, a.q, a.l_n, a.mu,
-                           a.x, a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.N, a.epsilon,
-                           a.ir_steps, a.ws, use_worklist ? 1 : 0, g.lds_per_wave);
-    } else {
-        if ((e = set_lds(bwd_dense_kernel<1>, g.lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(bwd_dense_kernel<1>, dim3(g.grid), dim3(64 * g.wpb), g.lds_bytes, s, a.P, a.q, a.l_n, a.mu,
-                           a.x, a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.N, a.epsilon,
-                           a.ir_steps, a.ws, use_worklist ? 1 : 0, g.lds_per_wave);
-    }
-    return hipGetLastError();
+    return kind == 0 ? launch_bwd_kind<0>(a, use_worklist, s) : launch_bwd_kind<1>(a, use_worklist, s);
 }
 
 } // namespace dqq

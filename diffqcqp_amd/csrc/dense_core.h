@@ -13,11 +13,23 @@
 //
 // Row stride in LDS is odd (ld = n | 1): "lane i reads row i" is bank-conflict free and "all lanes
 // read the same element" is a broadcast.  One lane per row limits N to 64 (QCQP backward: N + N/2 <= 64).
+// The backward routine is templated on a TEAM width T (8, 16, 32 or 64 lanes): 64/T problems share a
+// wave, each team working in its own LDS slice with team-local lane indices; teams never interact, so
+// their loops may have different trip counts.  T = 64 is the one-problem-per-wave case.
 #pragma once
 
 #include "kkt_core.h"
 
 namespace dqq {
+
+// ballot restricted to the T-lane team of the calling lane (bit i = team-local lane i)
+template <int T>
+DQQ_D unsigned long long team_ballot(bool pred)
+{
+    const unsigned long long b = __ballot(pred);
+    if constexpr (T == 64) return b;
+    else return (b >> (((threadIdx.x & 63) / T) * T)) & ((1ull << T) - 1ull);
+}
 
 constexpr int kDenseMaxRows = 64;
 
@@ -78,10 +90,11 @@ static DQQ_D double seq_sumsq(const double* vec, int n)
     return s;
 }
 
+template <int T = 64>
 static DQQ_D void load_matrix(double* dst, int ld, const double* __restrict__ src, int n, int lane)
 {
 #pragma clang fp contract(off)
-    for (int idx = lane; idx < n * n; idx += 64) dst[(idx / n) * ld + idx % n] = src[idx];
+    for (int idx = lane; idx < n * n; idx += T) dst[(idx / n) * ld + idx % n] = src[idx];
 }
 
 
@@ -235,6 +248,7 @@ static DQQ_D void dense_fwd_problem(const double* __restrict__ P, const double* 
 // Solver::iterative_refinement (Solver.cpp:15-44) for the m x m system whose
 // TRANSPOSED matrix A_t sits in At and right-hand side in dd (LDS).  Lane i
 // returns entry i of the solution.  At is overwritten (Cholesky workspace).
+template <int T = 64>
 static DQQ_D double ir_wave(double* At, double* K, double* Kinv, const double* dd, double* va, double* vb, int m,
                             int ld, int lane, int& steps)
 {
@@ -251,7 +265,7 @@ static DQQ_D double ir_wave(double* At, double* K, double* Kinv, const double* d
         K[lane * ld + lane] += kMuIr;                                         // :21
     }
     DQQ_SYNC();
-    for (int idx = lane; idx < m * m; idx += 64) At[(idx / m) * ld + idx % m] = K[(idx / m) * ld + idx % m];
+    for (int idx = lane; idx < m * m; idx += T) At[(idx / m) * ld + idx % m] = K[(idx / m) * ld + idx % m];
     if (act) va[lane] = Ab;
     DQQ_SYNC();
     chol_inverse_wave(At, Kinv, m, ld, lane);                                 // :22-23
@@ -282,7 +296,7 @@ static DQQ_D double ir_wave(double* At, double* K, double* Kinv, const double* d
 
 // One problem, backward: the composition of pybindings.cpp:24-30 (KIND 0) / :62-71 (KIND 1) plus the
 // gradient assembly of qcqp.py:48-51 / :173-180, executed by one wave.  smem: dense_bwd_lds_doubles(KIND,n).
-template <int KIND>
+template <int KIND, int T = 64>
 static DQQ_D void dense_bwd_problem(const double* __restrict__ P, const double* __restrict__ q,
                                     const double* __restrict__ l_n, const double* __restrict__ mu_c,
                                     const double* __restrict__ x, const double* __restrict__ grad_x,
@@ -308,10 +322,10 @@ static DQQ_D void dense_bwd_problem(const double* __restrict__ P, const double* 
     double* vS = vgam + n;           // nc
     double* vdl = vS + n;            // n
     int* perm = reinterpret_cast<int*>(vdl + n); // mmax ints: QP position -> coordinate, QCQP active slot -> contact
-    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const unsigned long long below = (1ull << lane) - 1ull; // lane is team-local: 0 <= lane < T
     const double* Pg = P + prob * (long)n * n;
     double* Pl = K; // P in LDS, row stride ld
-    load_matrix(Pl, ld, Pg, n, lane);
+    load_matrix<T>(Pl, ld, Pg, n, lane);
     const bool actn = lane < n;
     const double xi = actn ? x[prob * n + lane] : 0.0;
     const double gi = actn ? grad_x[prob * n + lane] : 0.0;
@@ -326,15 +340,15 @@ static DQQ_D void dense_bwd_problem(const double* __restrict__ P, const double* 
         double gamma = actn ? -(row_dot(Pl, ld, lane, vx, n) + qi) : 0.0;
         if (xi > dual_eps) gamma = 0;
         const bool is_act = actn && gamma < -kActiveEps;                  // :139-147
-        const unsigned long long am = __ballot(is_act);
-        const unsigned long long im = __ballot(actn && !is_act);
+        const unsigned long long am = team_ballot<T>(is_act);
+        const unsigned long long im = team_ballot<T>(actn && !is_act);
         na = __popcll(am);
         m = n;
         const int pos = is_act ? __popcll(am & below) : na + __popcll(im & below);
         if (actn) perm[pos] = lane;
         DQQ_SYNC();
         // A = [[diag(l_A), 0],[0, P_II]] in the order (active..., inactive...); At = A^T, :148-174
-        for (int idx = lane; idx < m * m; idx += 64) {
+        for (int idx = lane; idx < m * m; idx += T) {
             const int r = idx / m, c = idx % m; // At[r][c] = A[c][r]
             double val;
             if (c < na || r < na) val = (c == r) ? vx[perm[c]] : 0.0;
@@ -343,7 +357,7 @@ static DQQ_D void dense_bwd_problem(const double* __restrict__ P, const double* 
         }
         if (actn) vdd[pos] = (pos < na) ? 0.0 : gi;                       // :175-184
         DQQ_SYNC();
-        bsol = ir_wave(At, K, Kinv, vdd, va, vb, m, ld, lane, steps);     // :186
+        bsol = ir_wave<T>(At, K, Kinv, vdd, va, vb, m, ld, lane, steps);     // :186
         if (actn) vdl[perm[lane]] = (lane < na) ? 0.0 : bsol;             // :187-191
         DQQ_SYNC();
     } else {
@@ -369,7 +383,7 @@ static DQQ_D void dense_bwd_problem(const double* __restrict__ P, const double* 
         double S = -(r * r);                                              // Solver.cpp:622-629
         S = S + (xa * xa + xb * xb);
         const bool is_act = actc && S > -kActiveEps && r > kActiveEps;    // :637-641
-        const unsigned long long am = __ballot(is_act);
+        const unsigned long long am = team_ballot<T>(is_act);
         na = __popcll(am);
         m = n + na;
         const int slot = __popcll(am & below);
@@ -378,7 +392,7 @@ static DQQ_D void dense_bwd_problem(const double* __restrict__ P, const double* 
         if (is_act) perm[slot] = lane;
         DQQ_SYNC();
         // A = [[diag(S_act), (diag(gamma) C^T)_act],[C_act, P + blkdiag(2 gamma_i I2)]]; At = A^T, :643-657
-        for (int idx = lane; idx < m * m; idx += 64) {
+        for (int idx = lane; idx < m * m; idx += T) {
             const int rr = idx / m, cc = idx % m; // At[rr][cc] = A[cc][rr]: row = cc, col = rr
             const int row = cc, col = rr;
             double val;
@@ -395,7 +409,7 @@ static DQQ_D void dense_bwd_problem(const double* __restrict__ P, const double* 
         }
         if (lane < m) vdd[lane] = (lane < na) ? 0.0 : vg[lane - na];      // :659-667
         DQQ_SYNC();
-        bsol = ir_wave(At, K, Kinv, vdd, va, vb, m, ld, lane, steps);     // :669
+        bsol = ir_wave<T>(At, K, Kinv, vdd, va, vb, m, ld, lane, steps);     // :669
         // blgamma scatter, :670-679
         if (lane < na) vb[perm[lane]] = bsol;        // dgamma of active contacts
         else if (lane < m) vdl[lane - na] = bsol;    // dl
@@ -411,7 +425,7 @@ static DQQ_D void dense_bwd_problem(const double* __restrict__ P, const double* 
     if (actn && grad_q != nullptr) grad_q[prob * n + lane] = -vdl[lane];
     if (grad_P != nullptr) {
         double* Gp = grad_P + prob * (long)n * n;
-        for (int idx = lane; idx < n * n; idx += 64) Gp[idx] = -(vdl[idx / n] * vx[idx % n]);
+        for (int idx = lane; idx < n * n; idx += T) Gp[idx] = -(vdl[idx / n] * vx[idx % n]);
     }
     if (ir_steps != nullptr && lane == 0) ir_steps[prob] = steps;
     DQQ_SYNC();

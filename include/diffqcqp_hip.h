@@ -107,6 +107,8 @@ int dqq_qcqp_bwd_f64(const double* P, const double* q, const double* l_n, const 
  *   "wpb"            waves per workgroup of the diagonal kernels (1 or 4; 0 = built-in)
  *   "fuse_fallback"  DQQ_P_AUTO, small N: solve non-diagonal tiles inside the fast kernel (1), queue them
  *                    for the dense kernel launched behind it (0), or decide from B (-1, default)
+ *   "dense_teams"    general path, backward: pack 64/T problems per wave for small N (1, default) or one
+ *                    problem per wave (0)
  *   "lane_dense"     general path, N = 2..8 forward: lane-per-problem kernel (1, default) or the
  *                    wave-per-problem kernel (0)
  *   "dense_block"    general path, N = 32 / 64 forward: workgroup-per-problem kernel (1, default) or the

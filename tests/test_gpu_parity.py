@@ -43,6 +43,7 @@ def ops():
     _capi.set_option("fuse_fallback", -1)
     _capi.set_option("dense_block", 1)
     _capi.set_option("lane_dense", 1)
+    _capi.set_option("dense_teams", 1)
 
 
 def dev(d):
@@ -246,6 +247,25 @@ def test_lane_and_wave_dense_forward_agree(oracle, ops, kind, N, B):
         check_forward(xh, ih, xm, im, min_match=0.99)
     _capi.set_option("fuse_fallback", -1)
     assert (out[0][0] - out[1][0]).abs().max() < 1e-8
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("N,B", [(8, 333), (4, 100), (6, 77), (12, 50), (16, 41), (32, 9)])
+def test_dense_backward_teams_agree_with_one_problem_per_wave(oracle, ops, kind, N, B):
+    """The general backward packs 64/T problems per wave for small N; same arithmetic as T = 64."""
+    from diffqcqp_amd import _capi
+    d = make_problem(kind, B, N, 680 + N, "dense")
+    g = dev(d)
+    xo, _ = oracle_fwd(oracle, kind, d)
+    ref = oracle_bwd(oracle, kind, d, xo)
+    out = {}
+    for teams in (1, 0):
+        _capi.set_option("dense_teams", teams)
+        out[teams] = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
+        check_backward_exact(out[teams][0], out[teams][1], ref, exact=False)
+    _capi.set_option("dense_teams", 1)
+    for a, b in zip(out[0][0], out[1][0]):
+        assert torch.equal(a, b)  # identical operation order -> identical bits
 
 
 @pytest.mark.parametrize("N", [3, 5, 7])
