@@ -10,15 +10,38 @@ from . import _capi
 
 _workspaces = {}
 
+try:  # raw stream handle of torch's current stream without building a Stream object (private but stable)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:  # pragma: no cover
+    def _raw_stream(index):
+        return torch.cuda.current_stream(index).cuda_stream
 
-def _workspace(device, B):
-    """Zero-initialised fallback work-list, cached per (device, stream); the
-    kernels leave it zeroed (include/diffqcqp_hip.h: dqq_workspace_bytes)."""
-    stream = torch.cuda.current_stream(device)
-    key = (device.index, stream.cuda_stream)
-    need = _capi.lib().dqq_workspace_bytes(int(B))
+
+class _device_guard:
+    """`with torch.cuda.device(dev)` only when dev is not already current (the context manager costs
+    several microseconds per call, the hot path is tens of microseconds)."""
+
+    def __init__(self, dev):
+        self.ctx = None if dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+
+
+def _workspace(device, B, stream=None):
+    """Zero-initialised fallback work-list, cached per (device, stream); the kernels leave it empty again
+    (include/diffqcqp_hip.h: dqq_workspace_bytes)."""
+    if stream is None:
+        stream = _raw_stream(device.index)
+    key = (device.index, stream)
     ws = _workspaces.get(key)
-    if ws is None or ws.numel() * 4 < need:
+    if ws is None or ws.numel() < B + 64:
+        need = _capi.lib().dqq_workspace_bytes(int(B))
         ws = torch.zeros(max(need // 4, 1024), dtype=torch.int32, device=device)
         _workspaces[key] = ws
     return ws
@@ -29,6 +52,8 @@ def _ptr(t):
 
 
 def _prep(t, name, shape=None):
+    if t.is_cuda and t.dtype is torch.float64 and t.is_contiguous() and (shape is None or t.shape == shape):
+        return t  # the common case: nothing to do (data_ptr() ignores autograd state)
     if not t.is_cuda:
         raise ValueError("%s must live on the GPU (got %s)" % (name, t.device))
     if t.dtype != torch.float64:
@@ -52,11 +77,11 @@ def qp_forward(P, q, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, layout=_cap
     P, q = _prep(P, "P", pshape), _prep(q, "q", (B, N, 1))
     x = out if out is not None else torch.empty((B, N, 1), dtype=torch.float64, device=q.device)
     iters = torch.empty(B, dtype=torch.int32, device=q.device) if return_iters else None
-    ws = _workspace(q.device, B)
-    with torch.cuda.device(q.device):
+    stream = _raw_stream(q.device.index)
+    ws = _workspace(q.device, B, stream)
+    with _device_guard(q.device):
         rc = _capi.lib().dqq_qp_fwd_f64(_ptr(P), _ptr(q), _ptr(x), B, N, float(eps), float(mu_prox), int(max_iter),
-                                        int(bool(adaptive_rho)), layout, _ptr(iters), _ptr(ws), ws.numel() * 4,
-                                        torch.cuda.current_stream().cuda_stream)
+                                        int(bool(adaptive_rho)), layout, _ptr(iters), _ptr(ws), ws.numel() * 4, stream)
     _capi.check(rc, "dqq_qp_fwd_f64")
     return (x, iters) if return_iters else x
 
@@ -69,11 +94,12 @@ def qcqp_forward(P, q, l_n, mu, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, 
     l_n, mu = _prep(l_n, "l_n", (B, N // 2, 1)), _prep(mu, "mu", (B, N // 2, 1))
     x = out if out is not None else torch.empty((B, N, 1), dtype=torch.float64, device=q.device)
     iters = torch.empty(B, dtype=torch.int32, device=q.device) if return_iters else None
-    ws = _workspace(q.device, B)
-    with torch.cuda.device(q.device):
+    stream = _raw_stream(q.device.index)
+    ws = _workspace(q.device, B, stream)
+    with _device_guard(q.device):
         rc = _capi.lib().dqq_qcqp_fwd_f64(_ptr(P), _ptr(q), _ptr(l_n), _ptr(mu), _ptr(x), B, N, float(eps),
                                           float(mu_prox), int(max_iter), int(bool(adaptive_rho)), layout, _ptr(iters),
-                                          _ptr(ws), ws.numel() * 4, torch.cuda.current_stream().cuda_stream)
+                                          _ptr(ws), ws.numel() * 4, stream)
     _capi.check(rc, "dqq_qcqp_fwd_f64")
     return (x, iters) if return_iters else x
 
@@ -91,11 +117,11 @@ def qp_backward(P, q, x, grad_x, need_P=True, need_q=True, layout=_capi.P_AUTO, 
         gP = torch.empty(pshape, dtype=torch.float64, device=dev) if need_P else None
         gq = torch.empty((B, N, 1), dtype=torch.float64, device=dev) if need_q else None
     steps = torch.empty(B, dtype=torch.int32, device=dev) if return_steps else None
-    ws = _workspace(dev, B)
-    with torch.cuda.device(dev):
+    stream = _raw_stream(dev.index)
+    ws = _workspace(dev, B, stream)
+    with _device_guard(dev):
         rc = _capi.lib().dqq_qp_bwd_f64(_ptr(P), _ptr(q), _ptr(x), _ptr(grad_x), _ptr(gP), _ptr(gq), B, N,
-                                        float(epsilon), layout, _ptr(steps), _ptr(ws), ws.numel() * 4,
-                                        torch.cuda.current_stream().cuda_stream)
+                                        float(epsilon), layout, _ptr(steps), _ptr(ws), ws.numel() * 4, stream)
     _capi.check(rc, "dqq_qp_bwd_f64")
     return (gP, gq, steps) if return_steps else (gP, gq)
 
@@ -118,12 +144,12 @@ def qcqp_backward(P, q, l_n, mu, x, grad_x, need=(True, True, True, True), layou
         gl = torch.empty((B, N // 2, 1), dtype=torch.float64, device=dev) if need[2] else None
         gm = torch.empty((B, N // 2, 1), dtype=torch.float64, device=dev) if need[3] else None
     steps = torch.empty(B, dtype=torch.int32, device=dev) if return_steps else None
-    ws = _workspace(dev, B)
-    with torch.cuda.device(dev):
+    stream = _raw_stream(dev.index)
+    ws = _workspace(dev, B, stream)
+    with _device_guard(dev):
         gam, dgam = duals if duals is not None else (None, None)
         rc = _capi.lib().dqq_qcqp_bwd_f64(_ptr(P), _ptr(q), _ptr(l_n), _ptr(mu), _ptr(x), _ptr(grad_x), _ptr(gP),
                                           _ptr(gq), _ptr(gl), _ptr(gm), _ptr(gam), _ptr(dgam), B, N, float(epsilon),
-                                          layout, _ptr(steps), _ptr(ws), ws.numel() * 4,
-                                          torch.cuda.current_stream().cuda_stream)
+                                          layout, _ptr(steps), _ptr(ws), ws.numel() * 4, stream)
     _capi.check(rc, "dqq_qcqp_bwd_f64")
     return (gP, gq, gl, gm, steps) if return_steps else (gP, gq, gl, gm)

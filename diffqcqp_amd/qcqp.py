@@ -38,12 +38,15 @@ def _device_for(t):
 class QPFn2(Function):
     @staticmethod
     def forward(ctx, P, q, warm_start, eps, max_iter, mu_prox=1e-7):
-        dev = _device_for(q)
-        Pd, qd = P.detach().to(dev), q.detach().to(dev)
+        if q.is_cuda:  # resident tensors: no staging, no copies
+            Pd, qd = P.detach(), q.detach()
+        else:
+            dev = _device_for(q)
+            Pd, qd = P.detach().to(dev), q.detach().to(dev)
         l_2 = ops.qp_forward(Pd, qd, eps, max_iter, mu_prox, adaptive_rho=True)
         ctx.save_for_backward(Pd, qd, l_2)
         ctx.home = q.device
-        return l_2.to(q.device)
+        return l_2 if q.is_cuda else l_2.to(q.device)
 
     @staticmethod
     def backward(ctx, grad_l):
@@ -52,23 +55,25 @@ class QPFn2(Function):
         grad_P, grad_q = None, None
         if need_P or need_q:
             grad_P, grad_q = ops.qp_backward(P, q, l, grad_l.to(l.device), need_P, need_q)
-            if grad_P is not None:
-                grad_P = grad_P.to(ctx.home)
-            if grad_q is not None:
-                grad_q = grad_q.to(ctx.home)
+            if ctx.home != l.device:
+                grad_P = None if grad_P is None else grad_P.to(ctx.home)
+                grad_q = None if grad_q is None else grad_q.to(ctx.home)
         return grad_P, grad_q, None, None, None, None
 
 
 class QCQPFn2(Function):
     @staticmethod
     def forward(ctx, P, q, l_n, mu, warm_start, eps, max_iter, mu_prox=1e-7):
-        dev = _device_for(q)
-        Pd, qd = P.detach().to(dev), q.detach().to(dev)
-        lnd, mud = l_n.detach().to(dev), mu.detach().to(dev)
+        if q.is_cuda:
+            Pd, qd, lnd, mud = P.detach(), q.detach(), l_n.detach(), mu.detach()
+        else:
+            dev = _device_for(q)
+            Pd, qd = P.detach().to(dev), q.detach().to(dev)
+            lnd, mud = l_n.detach().to(dev), mu.detach().to(dev)
         l_2 = ops.qcqp_forward(Pd, qd, lnd, mud, eps, max_iter, mu_prox, adaptive_rho=True)
         ctx.save_for_backward(Pd, qd, lnd, mud, l_2)
         ctx.home = q.device
-        return l_2.to(q.device)
+        return l_2 if q.is_cuda else l_2.to(q.device)
 
     @staticmethod
     def backward(ctx, grad_l):
@@ -77,5 +82,6 @@ class QCQPFn2(Function):
         grads = (None, None, None, None)
         if any(need):
             grads = ops.qcqp_backward(P, q, l_n, mu, l, grad_l.to(l.device), need)
-            grads = tuple(None if g is None else g.to(ctx.home) for g in grads)
+            if ctx.home != l.device:
+                grads = tuple(None if g is None else g.to(ctx.home) for g in grads)
         return grads + (None, None, None, None)
