@@ -331,6 +331,43 @@ def test_single_nonzero_offdiagonal_is_detected(oracle, ops):
     assert (xd[0] - xh[0]).abs().max() > 1e-6
 
 
+def test_bad_inputs_terminate_and_poison_only_their_own_problem(oracle, ops):
+    """The reference signals nothing on bad input (LLT success is never checked, Solver.cpp:76): the result
+    is NaN.  Here: every launch terminates (max_iter bounds the loop), a bad problem yields NaN, and its
+    neighbours in the same tile are unaffected."""
+    from diffqcqp_amd import _capi
+    N, B = 8, 300
+    d = make_problem("qcqp", B, N, 990)
+    xo, _ = oracle_fwd(oracle, "qcqp", d)
+    bad = {5: "zero", 70: "negative", 131: "nan", 299: "inf"}
+    for b, what in bad.items():
+        if what == "zero":
+            d["P"][b] = 0.0
+        elif what == "negative":
+            d["P"][b, 3, 3] = -50.0
+        elif what == "nan":
+            d["P"][b, 2, 2] = float("nan")
+        else:
+            d["P"][b, 1, 1] = float("inf")
+    g = dev(d)
+    for layout in (_capi.P_AUTO, _capi.P_DENSE):
+        for kind in ("qp", "qcqp"):
+            x, it = hip_fwd(ops, kind, g, layout=layout, max_iter=200)
+            torch.cuda.synchronize()
+            assert int(it.max()) <= 200
+            xn = npy(x)
+            for b in bad:
+                assert not np.isfinite(xn[b]).all(), (layout, kind, b, xn[b].ravel())
+            good = np.array([b not in bad for b in range(B)])
+            assert np.isfinite(xn[good]).all()
+            if kind == "qcqp":
+                assert np.abs(xn[good] - xo[good]).max() <= X_TOL
+    # the backward must terminate on non-finite input as well
+    grads, st = hip_bwd(ops, "qcqp", g, torch.from_numpy(xo).cuda())
+    torch.cuda.synchronize()
+    assert int(st.max()) <= 10
+
+
 # ---------------------------------------------------------------- golden fixtures
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))), ids=os.path.basename)
 def test_hip_reproduces_golden(ops, path):
