@@ -170,7 +170,9 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : 4) : 1)) void bw
             const int row = f / N, col = (row / N) * N + f % N;
             const double d = dlv[row];
             const double2 xx = *reinterpret_cast<const double2*>(xs + col);
-            *reinterpret_cast<double2*>(Gw + f) = make_double2(-(d * xx.x), -(d * xx.y));
+            // grad_P is written once and not read again by this launch: non-temporal, keep it out of L2
+            __builtin_nontemporal_store(-(d * xx.x), Gw + f);
+            __builtin_nontemporal_store(-(d * xx.y), Gw + f + 1);
         }
     }
 }
