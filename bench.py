@@ -69,6 +69,7 @@ class Plan:
         self.x_qp, self.x_qcqp = e(B, N, 1), e(B, N, 1)
         self.gP_qp, self.gq_qp = e(B, N, N), e(B, N, 1)
         self.gP_qc, self.gq_qc, self.gl_qc, self.gm_qc = e(B, N, N), e(B, N, 1), e(B, N // 2, 1), e(B, N // 2, 1)
+        self.cache_qp, self.cache_qc = ops.diag_cache(d["q"]), ops.diag_cache(d["q"])
         self.ws = ops._workspace(dev, B)
         self.wsb = self.ws.numel() * 4
         self.names = ["qp_fwd", "qp_bwd", "qcqp_fwd", "qcqp_bwd"]
@@ -78,17 +79,18 @@ class Plan:
         B = B_PER_GPU
         if which == 0:
             rc = L.dqq_qp_fwd_f64(p(d["P"]), p(d["q"]), p(self.x_qp), B, N, EPS, MU_PROX, MAX_ITER, 1, 0, None,
-                                  p(self.ws), self.wsb, stream)
+                                  p(self.cache_qp[0]), p(self.cache_qp[1]), p(self.ws), self.wsb, stream)
         elif which == 1:
             rc = L.dqq_qp_bwd_f64(p(d["P"]), p(d["q"]), p(self.x_qp), p(d["g_qp"]), p(self.gP_qp), p(self.gq_qp), B, N,
-                                  1e-10, 0, None, p(self.ws), self.wsb, stream)
+                                  1e-10, 0, None, p(self.cache_qp[0]), p(self.cache_qp[1]), p(self.ws), self.wsb, stream)
         elif which == 2:
             rc = L.dqq_qcqp_fwd_f64(p(d["P"]), p(d["q"]), p(d["l_n"]), p(d["mu"]), p(self.x_qcqp), B, N, EPS, MU_PROX,
-                                    MAX_ITER, 1, 0, None, p(self.ws), self.wsb, stream)
+                                    MAX_ITER, 1, 0, None, p(self.cache_qc[0]), p(self.cache_qc[1]), p(self.ws), self.wsb,
+                                    stream)
         else:
             rc = L.dqq_qcqp_bwd_f64(p(d["P"]), p(d["q"]), p(d["l_n"]), p(d["mu"]), p(self.x_qcqp), p(d["g_qcqp"]),
                                     p(self.gP_qc), p(self.gq_qc), p(self.gl_qc), p(self.gm_qc), None, None, B, N, 1e-10,
-                                    0, None, p(self.ws), self.wsb, stream)
+                                    0, None, p(self.cache_qc[0]), p(self.cache_qc[1]), p(self.ws), self.wsb, stream)
         if rc != 0:
             raise RuntimeError("launch %s failed with %d" % (self.names[which], rc))
 

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : 4) : 1)) void bw
     const double* __restrict__ mu_c, const double* __restrict__ x, const double* __restrict__ grad_x,
     double* __restrict__ grad_P, double* __restrict__ grad_q, double* __restrict__ grad_l_n,
     double* __restrict__ grad_mu, double* __restrict__ gamma_out, double* __restrict__ dgamma_out, long B,
-    double dual_eps, int layout, int* __restrict__ ir_steps, int* __restrict__ ws)
+    double dual_eps, int layout, int* __restrict__ ir_steps, int* __restrict__ ws,
+    const double* __restrict__ pdiag, const unsigned char* __restrict__ flags)
 {
     constexpr int HL = N / 2;          // lanes per problem
     constexpr int T = 64 / HL;         // problems per wave tile (T*N == 128)
@@ -57,8 +58,16 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : 4) : 1)) void bw
 
     // ---------------- phase A: P -> diagonal (LDS), off-diagonal zero check
     double2 pv;
+    // The forward of these problems may have left their verified diagonal behind (pdiag, flags): a tile all
+    // of whose problems are flagged diagonal skips the stream of P -- 512 of its 1280 bytes per problem at
+    // N=8 -- and is handled exactly like the stream would have ended.
+    bool have_diag = false;
+    if (pdiag != nullptr && flags != nullptr && layout == DQQ_P_AUTO)
+        have_diag = __all(!valid || flags[first + pl] != 0);
     if (layout == DQQ_P_DIAG) {
         pv = valid ? *reinterpret_cast<const double2*>(P + first * N + 2 * lane) : make_double2(1.0, 1.0);
+    } else if (have_diag) {
+        pv = valid ? *reinterpret_cast<const double2*>(pdiag + first * N + 2 * lane) : make_double2(1.0, 1.0);
     } else {
         const double* Pw = P + first * (long)(N * N);
         const unsigned nz = (nvalid == T) ? stream_tile_diag<N, N, false>(Pw, limit, pd, lane)
@@ -186,7 +195,7 @@ static hipError_t launch_one(const BwdArgs& a, hipStream_t s)
     if (nblocks == 0) return hipSuccess;
     hipLaunchKernelGGL((bwd_diag_kernel<KIND, N, WPB, FUSE>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q, a.l_n,
                        a.mu, a.x, a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.epsilon, a.layout,
-                       a.ir_steps, a.ws);
+                       a.ir_steps, a.ws, a.pdiag, a.flags);
     return hipGetLastError();
 }
 

@@ -184,50 +184,62 @@ static int bwd_dispatch(int kind, dqq::BwdArgs& a, void* workspace, size_t works
 }
 
 int dqq_qp_fwd_f64(const double* P, const double* q, double* x, int64_t B, int N, double eps, double mu_prox,
-                   int max_iter, int adaptive_rho, int p_layout, int* iters, void* workspace,
-                   size_t workspace_bytes, void* stream)
+                   int max_iter, int adaptive_rho, int p_layout, int* iters, double* pdiag_out,
+                   unsigned char* diag_flags_out, void* workspace, size_t workspace_bytes, void* stream)
 {
     if (int rc = check_common(B, N, p_layout, false)) return rc;
     if (B > 0 && (P == nullptr || q == nullptr || x == nullptr)) return DQQ_E_NULLPTR;
-    dqq::FwdArgs a{P, q, nullptr, nullptr, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0,
-                   p_layout, iters, nullptr, nullptr, 0};
+    const bool keep = p_layout == DQQ_P_AUTO && dqq::fwd_diag_supported(N);
+    dqq::FwdArgs a{P,        q,     nullptr, nullptr, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0,
+                   p_layout, iters, nullptr, keep ? pdiag_out : nullptr, keep ? diag_flags_out : nullptr, nullptr, 0};
+    if (!keep && diag_flags_out != nullptr && B > 0) { // nothing will be verified: flag every problem 0
+        hipError_t e = hipMemsetAsync(diag_flags_out, 0, (size_t)B, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return (int)e;
+    }
     return fwd_dispatch(0, a, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 int dqq_qcqp_fwd_f64(const double* P, const double* q, const double* l_n, const double* mu, double* x, int64_t B,
                      int N, double eps, double mu_prox, int max_iter, int adaptive_rho, int p_layout, int* iters,
-                     void* workspace, size_t workspace_bytes, void* stream)
+                     double* pdiag_out, unsigned char* diag_flags_out, void* workspace, size_t workspace_bytes,
+                     void* stream)
 {
     if (int rc = check_common(B, N, p_layout, true)) return rc;
     if (B > 0 && (P == nullptr || q == nullptr || l_n == nullptr || mu == nullptr || x == nullptr))
         return DQQ_E_NULLPTR;
-    dqq::FwdArgs a{P, q, l_n, mu, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0, p_layout, iters,
-                   nullptr, nullptr, 0};
+    const bool keep = p_layout == DQQ_P_AUTO && dqq::fwd_diag_supported(N);
+    dqq::FwdArgs a{P,     q,       l_n, mu, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0, p_layout,
+                   iters, nullptr, keep ? pdiag_out : nullptr, keep ? diag_flags_out : nullptr, nullptr, 0};
+    if (!keep && diag_flags_out != nullptr && B > 0) {
+        hipError_t e = hipMemsetAsync(diag_flags_out, 0, (size_t)B, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return (int)e;
+    }
     return fwd_dispatch(1, a, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 int dqq_qp_bwd_f64(const double* P, const double* q, const double* x, const double* grad_x, double* grad_P,
-                   double* grad_q, int64_t B, int N, double epsilon, int p_layout, int* ir_steps, void* workspace,
-                   size_t workspace_bytes, void* stream)
+                   double* grad_q, int64_t B, int N, double epsilon, int p_layout, int* ir_steps, const double* pdiag,
+                   const unsigned char* diag_flags, void* workspace, size_t workspace_bytes, void* stream)
 {
     if (int rc = check_common(B, N, p_layout, false)) return rc;
     if (B > 0 && (P == nullptr || q == nullptr || x == nullptr || grad_x == nullptr)) return DQQ_E_NULLPTR;
-    dqq::BwdArgs a{P,       q,       nullptr, nullptr, x, grad_x,  grad_P,   grad_q,   nullptr, nullptr,
-                   nullptr, nullptr, (long)B, N,       epsilon, p_layout, ir_steps, nullptr};
+    dqq::BwdArgs a{P,     q,          nullptr, nullptr, x,       grad_x, grad_P,  grad_q,   nullptr,  nullptr,
+                   pdiag, diag_flags, nullptr, nullptr, (long)B, N,      epsilon, p_layout, ir_steps, nullptr};
     return bwd_dispatch(0, a, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 int dqq_qcqp_bwd_f64(const double* P, const double* q, const double* l_n, const double* mu, const double* x,
                      const double* grad_x, double* grad_P, double* grad_q, double* grad_l_n, double* grad_mu,
                      double* gamma, double* dgamma, int64_t B, int N, double epsilon, int p_layout, int* ir_steps,
-                     void* workspace, size_t workspace_bytes, void* stream)
+                     const double* pdiag, const unsigned char* diag_flags, void* workspace, size_t workspace_bytes,
+                     void* stream)
 {
     if (int rc = check_common(B, N, p_layout, true)) return rc;
     if (B > 0 && (P == nullptr || q == nullptr || l_n == nullptr || mu == nullptr || x == nullptr ||
                   grad_x == nullptr))
         return DQQ_E_NULLPTR;
-    dqq::BwdArgs a{P,     q,      l_n,     mu, x,       grad_x,   grad_P,   grad_q, grad_l_n, grad_mu,
-                   gamma, dgamma, (long)B, N,  epsilon, p_layout, ir_steps, nullptr};
+    dqq::BwdArgs a{P,     q,          l_n,   mu,     x,       grad_x, grad_P,  grad_q,   grad_l_n, grad_mu,
+                   pdiag, diag_flags, gamma, dgamma, (long)B, N,      epsilon, p_layout, ir_steps, nullptr};
     return bwd_dispatch(1, a, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 

@@ -31,7 +31,9 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
                                                             const double* __restrict__ mu_c, double* __restrict__ x,
                                                             long B, double eps, double mu_prox, int max_iter,
                                                             int adaptive, int layout, int* __restrict__ iters,
-                                                            int* __restrict__ ws, int* __restrict__ hint, int hint_gen)
+                                                            int* __restrict__ ws, int* __restrict__ hint, int hint_gen,
+                                                            double* __restrict__ pdiag_out,
+                                                            unsigned char* __restrict__ flags_out)
 {
     constexpr int E = N / LPP;       // coordinates per lane
     constexpr int PPW = 64 / LPP;    // problems per wave tile
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
         const unsigned nz = (nvalid == PPW) ? stream_tile_diag<N, NCH, false>(Pw, limit, sd, lane)
                                             : stream_tile_diag<N, NCH, true>(Pw, limit, sd, lane);
         if (__any(nz != 0)) { // wave-uniform
+            if (flags_out != nullptr && valid && (lane % LPP) == 0) flags_out[first + pl] = 0;
             // tell the host (performance hint only, read without synchronisation before the NEXT call) that
             // this launch met a non-diagonal tile: one posted store per launch, de-duplicated in L2
             if (hint != nullptr && lane == 0 && atomicMax(&ws[kWsHintGen], hint_gen) < hint_gen)
@@ -112,6 +115,13 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
 #pragma unroll
         for (int e = 0; e < E; e += 2) *reinterpret_cast<double2*>(xx + e) = make_double2(xv[e], xv[e + 1]);
         if (iters != nullptr && (lane % LPP) == 0) iters[first + pl] = it;
+        // hand the verified diagonal to the backward of the same problems (it then skips the P stream)
+        if (flags_out != nullptr && (lane % LPP) == 0) flags_out[first + pl] = 1;
+        if (pdiag_out != nullptr) {
+            double* pp = pdiag_out + first * N + lane * E;
+#pragma unroll
+            for (int e = 0; e < E; e += 2) *reinterpret_cast<double2*>(pp + e) = make_double2(p[e], p[e + 1]);
+        }
     }
 }
 
@@ -123,7 +133,8 @@ static hipError_t launch_one(const FwdArgs& a, hipStream_t s)
     const long nblocks = (ntiles + WPB - 1) / WPB;
     if (nblocks == 0) return hipSuccess;
     hipLaunchKernelGGL((fwd_diag_kernel<KIND, N, LPP, WPB, FUSE>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q,
-                       a.l_n, a.mu, a.x, a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.layout, a.iters, a.ws, a.hint, a.hint_gen);
+                       a.l_n, a.mu, a.x, a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.layout, a.iters, a.ws, a.hint, a.hint_gen,
+                       a.pdiag_out, a.flags_out);
     return hipGetLastError();
 }
 

@@ -27,6 +27,8 @@ struct FwdArgs {
     int max_iter, adaptive, layout;
     int* iters;
     int* ws;
+    double* pdiag_out;         // optional (B,N): the diagonal of P, for the backward of the same problems
+    unsigned char* flags_out;  // optional (B): 1 = the problem's tile was verified diagonal
     int* hint;    // host-mapped word: generation of the last launch that met a non-diagonal tile (may be null)
     int hint_gen; // generation of this launch
 };
@@ -42,6 +44,8 @@ struct BwdArgs {
     double* grad_q;
     double* grad_l_n;
     double* grad_mu;
+    const double* pdiag;        // optional: what the forward stored (see FwdArgs)
+    const unsigned char* flags; // optional
     double* gamma;   // QCQP only, optional
     double* dgamma;  // QCQP only, optional
     long B;

@@ -70,9 +70,17 @@ def _dims(P, q, layout):
     return B, N, pshape
 
 
+def diag_cache(q):
+    """Buffers a forward can fill for the backward of the same problems: (pdiag (B,N), flags (B) uint8)."""
+    B, N = q.shape[0], q.shape[1]
+    return (torch.empty((B, N), dtype=torch.float64, device=q.device),
+            torch.empty(B, dtype=torch.uint8, device=q.device))
+
+
 def qp_forward(P, q, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, layout=_capi.P_AUTO, return_iters=False,
-               out=None):
-    """Batched QP solve min 1/2 x'Px + q'x, x >= 0 (reference qcqp.py:24-33). -> x (B,N,1)"""
+               out=None, cache=None):
+    """Batched QP solve min 1/2 x'Px + q'x, x >= 0 (reference qcqp.py:24-33). -> x (B,N,1).
+    cache: optional `diag_cache(q)` buffers; pass the same pair to qp_backward (P must be unchanged)."""
     B, N, pshape = _dims(P, q, layout)
     P, q = _prep(P, "P", pshape), _prep(q, "q", (B, N, 1))
     x = out if out is not None else torch.empty((B, N, 1), dtype=torch.float64, device=q.device)
@@ -80,14 +88,16 @@ def qp_forward(P, q, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, layout=_cap
     stream = _raw_stream(q.device.index)
     ws = _workspace(q.device, B, stream)
     with _device_guard(q.device):
+        pd, fl = cache if cache is not None else (None, None)
         rc = _capi.lib().dqq_qp_fwd_f64(_ptr(P), _ptr(q), _ptr(x), B, N, float(eps), float(mu_prox), int(max_iter),
-                                        int(bool(adaptive_rho)), layout, _ptr(iters), _ptr(ws), ws.numel() * 4, stream)
+                                        int(bool(adaptive_rho)), layout, _ptr(iters), _ptr(pd), _ptr(fl), _ptr(ws),
+                                        ws.numel() * 4, stream)
     _capi.check(rc, "dqq_qp_fwd_f64")
     return (x, iters) if return_iters else x
 
 
 def qcqp_forward(P, q, l_n, mu, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, layout=_capi.P_AUTO,
-                 return_iters=False, out=None):
+                 return_iters=False, out=None, cache=None):
     """Batched QCQP solve, ||x_(i)|| <= mu_i*l_n_i per contact (reference qcqp.py:144-153)."""
     B, N, pshape = _dims(P, q, layout)
     P, q = _prep(P, "P", pshape), _prep(q, "q", (B, N, 1))
@@ -97,15 +107,16 @@ def qcqp_forward(P, q, l_n, mu, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, 
     stream = _raw_stream(q.device.index)
     ws = _workspace(q.device, B, stream)
     with _device_guard(q.device):
+        pd, fl = cache if cache is not None else (None, None)
         rc = _capi.lib().dqq_qcqp_fwd_f64(_ptr(P), _ptr(q), _ptr(l_n), _ptr(mu), _ptr(x), B, N, float(eps),
                                           float(mu_prox), int(max_iter), int(bool(adaptive_rho)), layout, _ptr(iters),
-                                          _ptr(ws), ws.numel() * 4, stream)
+                                          _ptr(pd), _ptr(fl), _ptr(ws), ws.numel() * 4, stream)
     _capi.check(rc, "dqq_qcqp_fwd_f64")
     return (x, iters) if return_iters else x
 
 
 def qp_backward(P, q, x, grad_x, need_P=True, need_q=True, layout=_capi.P_AUTO, return_steps=False, out=None,
-                epsilon=1e-10):
+                epsilon=1e-10, cache=None):
     """Implicit-function backward of the QP (reference qcqp.py:36-52). -> (grad_P|None, grad_q|None)"""
     B, N, pshape = _dims(P, q, layout)
     P, q = _prep(P, "P", pshape), _prep(q, "q", (B, N, 1))
@@ -120,14 +131,16 @@ def qp_backward(P, q, x, grad_x, need_P=True, need_q=True, layout=_capi.P_AUTO, 
     stream = _raw_stream(dev.index)
     ws = _workspace(dev, B, stream)
     with _device_guard(dev):
+        pd, fl = cache if cache is not None else (None, None)
         rc = _capi.lib().dqq_qp_bwd_f64(_ptr(P), _ptr(q), _ptr(x), _ptr(grad_x), _ptr(gP), _ptr(gq), B, N,
-                                        float(epsilon), layout, _ptr(steps), _ptr(ws), ws.numel() * 4, stream)
+                                        float(epsilon), layout, _ptr(steps), _ptr(pd), _ptr(fl), _ptr(ws),
+                                        ws.numel() * 4, stream)
     _capi.check(rc, "dqq_qp_bwd_f64")
     return (gP, gq, steps) if return_steps else (gP, gq)
 
 
 def qcqp_backward(P, q, l_n, mu, x, grad_x, need=(True, True, True, True), layout=_capi.P_AUTO, return_steps=False,
-                  out=None, epsilon=1e-10, duals=None):
+                  out=None, epsilon=1e-10, duals=None, cache=None):
     """Implicit-function backward of the QCQP (reference qcqp.py:156-181).
     -> (grad_P, grad_q, grad_l_n, grad_mu), None where not needed.  duals: optional pair of (B,N/2,1)
     tensors that receive the contact duals gamma and their derivative terms dgamma."""
@@ -148,8 +161,9 @@ def qcqp_backward(P, q, l_n, mu, x, grad_x, need=(True, True, True, True), layou
     ws = _workspace(dev, B, stream)
     with _device_guard(dev):
         gam, dgam = duals if duals is not None else (None, None)
+        pd, fl = cache if cache is not None else (None, None)
         rc = _capi.lib().dqq_qcqp_bwd_f64(_ptr(P), _ptr(q), _ptr(l_n), _ptr(mu), _ptr(x), _ptr(grad_x), _ptr(gP),
                                           _ptr(gq), _ptr(gl), _ptr(gm), _ptr(gam), _ptr(dgam), B, N, float(epsilon),
-                                          layout, _ptr(steps), _ptr(ws), ws.numel() * 4, stream)
+                                          layout, _ptr(steps), _ptr(pd), _ptr(fl), _ptr(ws), ws.numel() * 4, stream)
     _capi.check(rc, "dqq_qcqp_bwd_f64")
     return (gP, gq, gl, gm, steps) if return_steps else (gP, gq, gl, gm)

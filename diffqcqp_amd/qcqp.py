@@ -43,18 +43,19 @@ class QPFn2(Function):
         else:
             dev = _device_for(q)
             Pd, qd = P.detach().to(dev), q.detach().to(dev)
-        l_2 = ops.qp_forward(Pd, qd, eps, max_iter, mu_prox, adaptive_rho=True)
-        ctx.save_for_backward(Pd, qd, l_2)
+        cache = ops.diag_cache(qd)  # verified diagonal of P, reused by backward instead of re-reading P
+        l_2 = ops.qp_forward(Pd, qd, eps, max_iter, mu_prox, adaptive_rho=True, cache=cache)
+        ctx.save_for_backward(Pd, qd, l_2, *cache)
         ctx.home = q.device
         return l_2 if q.is_cuda else l_2.to(q.device)
 
     @staticmethod
     def backward(ctx, grad_l):
-        P, q, l = ctx.saved_tensors
+        P, q, l, pdiag, flags = ctx.saved_tensors
         need_P, need_q = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         grad_P, grad_q = None, None
         if need_P or need_q:
-            grad_P, grad_q = ops.qp_backward(P, q, l, grad_l.to(l.device), need_P, need_q)
+            grad_P, grad_q = ops.qp_backward(P, q, l, grad_l.to(l.device), need_P, need_q, cache=(pdiag, flags))
             if ctx.home != l.device:
                 grad_P = None if grad_P is None else grad_P.to(ctx.home)
                 grad_q = None if grad_q is None else grad_q.to(ctx.home)
@@ -70,18 +71,19 @@ class QCQPFn2(Function):
             dev = _device_for(q)
             Pd, qd = P.detach().to(dev), q.detach().to(dev)
             lnd, mud = l_n.detach().to(dev), mu.detach().to(dev)
-        l_2 = ops.qcqp_forward(Pd, qd, lnd, mud, eps, max_iter, mu_prox, adaptive_rho=True)
-        ctx.save_for_backward(Pd, qd, lnd, mud, l_2)
+        cache = ops.diag_cache(qd)
+        l_2 = ops.qcqp_forward(Pd, qd, lnd, mud, eps, max_iter, mu_prox, adaptive_rho=True, cache=cache)
+        ctx.save_for_backward(Pd, qd, lnd, mud, l_2, *cache)
         ctx.home = q.device
         return l_2 if q.is_cuda else l_2.to(q.device)
 
     @staticmethod
     def backward(ctx, grad_l):
-        P, q, l_n, mu, l = ctx.saved_tensors
+        P, q, l_n, mu, l, pdiag, flags = ctx.saved_tensors
         need = tuple(ctx.needs_input_grad[0:4])
         grads = (None, None, None, None)
         if any(need):
-            grads = ops.qcqp_backward(P, q, l_n, mu, l, grad_l.to(l.device), need)
+            grads = ops.qcqp_backward(P, q, l_n, mu, l, grad_l.to(l.device), need, cache=(pdiag, flags))
             if ctx.home != l.device:
                 grads = tuple(None if g is None else g.to(ctx.home) for g in grads)
         return grads + (None, None, None, None)

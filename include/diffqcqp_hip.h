@@ -66,10 +66,13 @@ int dqq_max_n(int kind);
 
 /* Replaces the loop qcqp.py:29-31 (QPFn2.forward -> diffqcqp.solveQP,
  * pybindings.cpp:17-22 -> Solver::solveQP, Solver.cpp:61-123).
- * iters (B ints, ADMM iterations executed per problem) may be NULL. */
+ * iters (B ints, ADMM iterations executed per problem) may be NULL.
+ * pdiag_out (B,N doubles) / diag_flags_out (B bytes), both optional and DQQ_P_AUTO only: the forward leaves
+ * the diagonal of every problem it verified to be diagonal (flag 1; flag 0 otherwise) for the backward of
+ * the SAME P, which then skips re-reading P for those problems (see dqq_qp_bwd_f64). */
 int dqq_qp_fwd_f64(const double* P, const double* q, double* x, int64_t B, int N, double eps, double mu_prox,
-                   int max_iter, int adaptive_rho, int p_layout, int* iters, void* workspace,
-                   size_t workspace_bytes, void* stream);
+                   int max_iter, int adaptive_rho, int p_layout, int* iters, double* pdiag_out,
+                   unsigned char* diag_flags_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Replaces the loop qcqp.py:45-47 + the assembly qcqp.py:48-51
  * (QPFn2.backward -> diffqcqp.solveDerivativesQP, pybindings.cpp:24-30 ->
@@ -77,17 +80,20 @@ int dqq_qp_fwd_f64(const double* P, const double* q, double* x, int64_t B, int N
  *   grad_P = -dl x^T (B,N,N), grad_q = -dl (B,N,1).  Either may be NULL
  * (ctx.needs_input_grad).  epsilon is the dual-recovery threshold of
  * solveDerivativesQP (pybindings.cpp:24, default 1e-10; qcqp.py never overrides
- * it).  ir_steps (B ints) may be NULL. */
+ * it).  ir_steps (B ints) may be NULL.  pdiag / diag_flags: optional, what the forward of the same
+ * (unchanged) P stored; P itself must still be passed (non-flagged problems read it). */
 int dqq_qp_bwd_f64(const double* P, const double* q, const double* x, const double* grad_x, double* grad_P,
                    double* grad_q, int64_t B, int N, double epsilon, int p_layout, int* ir_steps,
-                   void* workspace, size_t workspace_bytes, void* stream);
+                   const double* pdiag, const unsigned char* diag_flags, void* workspace, size_t workspace_bytes,
+                   void* stream);
 
 /* Replaces the loop qcqp.py:149-151 (QCQPFn2.forward -> diffqcqp.solveQCQP,
  * pybindings.cpp:54-60 -> Solver::solveQCQP, Solver.cpp:521-582).  l_n and mu
  * are the raw inputs; the radius l_n*mu is formed inside (pybindings.cpp:57). */
 int dqq_qcqp_fwd_f64(const double* P, const double* q, const double* l_n, const double* mu, double* x,
                      int64_t B, int N, double eps, double mu_prox, int max_iter, int adaptive_rho,
-                     int p_layout, int* iters, void* workspace, size_t workspace_bytes, void* stream);
+                     int p_layout, int* iters, double* pdiag_out, unsigned char* diag_flags_out, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 /* Replaces the loop qcqp.py:167-172 + the assembly qcqp.py:173-180
  * (QCQPFn2.backward -> diffqcqp.solveDerivativesQCQP, pybindings.cpp:62-71 ->
@@ -100,7 +106,8 @@ int dqq_qcqp_fwd_f64(const double* P, const double* q, const double* l_n, const 
 int dqq_qcqp_bwd_f64(const double* P, const double* q, const double* l_n, const double* mu, const double* x,
                      const double* grad_x, double* grad_P, double* grad_q, double* grad_l_n, double* grad_mu,
                      double* gamma, double* dgamma, int64_t B, int N, double epsilon, int p_layout,
-                     int* ir_steps, void* workspace, size_t workspace_bytes, void* stream);
+                     int* ir_steps, const double* pdiag, const unsigned char* diag_flags, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 /* Tuning knobs (process-wide, read at launch time).  Unknown name -> DQQ_E_BAD_OPTION.
  *   "fwd_lpp"        lanes per problem of the diagonal forward kernel (0 = built-in choice from B)

@@ -42,17 +42,17 @@ def test_version_and_limits(lib):
 def test_argument_validation_without_gpu(lib):
     one = ctypes.c_void_p(8)  # never dereferenced: the checks fail first
     f = lib.dqq_qp_fwd_f64
-    assert f(one, one, one, -1, 8, 1e-7, 1e-7, 10, 1, 0, None, None, 0, None) == -2
-    assert f(one, one, one, 4, 0, 1e-7, 1e-7, 10, 1, 0, None, None, 0, None) == -2
-    assert f(one, one, one, 4, 8, 1e-7, 1e-7, 10, 1, 7, None, None, 0, None) == -4
-    assert f(None, one, one, 4, 8, 1e-7, 1e-7, 10, 1, 0, None, None, 0, None) == -1
-    assert f(one, one, one, 4, 8, 1e-7, 1e-7, 10, 1, 0, None, None, 0, None) == -5  # AUTO needs a workspace
-    assert f(one, one, one, 4, 200, 1e-7, 1e-7, 10, 1, 1, None, None, 0, None) == -3
-    assert f(one, one, one, 0, 8, 1e-7, 1e-7, 10, 1, 0, None, None, 0, None) == 0   # empty batch is a no-op
+    assert f(one, one, one, -1, 8, 1e-7, 1e-7, 10, 1, 0, None, None, None, None, 0, None) == -2
+    assert f(one, one, one, 4, 0, 1e-7, 1e-7, 10, 1, 0, None, None, None, None, 0, None) == -2
+    assert f(one, one, one, 4, 8, 1e-7, 1e-7, 10, 1, 7, None, None, None, None, 0, None) == -4
+    assert f(None, one, one, 4, 8, 1e-7, 1e-7, 10, 1, 0, None, None, None, None, 0, None) == -1
+    assert f(one, one, one, 4, 8, 1e-7, 1e-7, 10, 1, 0, None, None, None, None, 0, None) == -5  # AUTO needs a workspace
+    assert f(one, one, one, 4, 200, 1e-7, 1e-7, 10, 1, 1, None, None, None, None, 0, None) == -3
+    assert f(one, one, one, 0, 8, 1e-7, 1e-7, 10, 1, 0, None, None, None, None, 0, None) == 0   # empty batch: no-op
     g = lib.dqq_qcqp_fwd_f64
-    assert g(one, one, one, one, one, 4, 7, 1e-7, 1e-7, 10, 1, 0, None, None, 0, None) == -2  # odd N
+    assert g(one, one, one, one, one, 4, 7, 1e-7, 1e-7, 10, 1, 0, None, None, None, None, 0, None) == -2  # odd N
     assert lib.dqq_qcqp_bwd_f64(one, one, one, one, one, one, None, None, None, None, None, None, 4, 48, 1e-10, 1,
-                                None, None, 0, None) == -3
+                                None, None, None, None, 0, None) == -3
     assert lib.dqq_set_option(b"no_such_knob", 1) == -6
 
 

@@ -175,6 +175,34 @@ def test_ragged_and_empty_batches(oracle, ops, kind, B):
     check_backward_exact(grads, st, oracle_bwd(oracle, kind, d, xo))
 
 
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("N,B,structure", [(8, 2051, "diag"), (8, 700, "mixed"), (32, 131, "diag"), (32, 61, "mixed"),
+                                           (2, 777, "diag"), (64, 20, "diag")])
+def test_backward_with_the_forwards_diagonal_cache_is_identical(oracle, ops, kind, N, B, structure):
+    """The forward can leave the verified diagonal of P for the backward of the same problems (which then
+    skips the P stream); non-diagonal tiles are flagged and still read P.  Results must be bit-identical."""
+    d = make_problem(kind, B, N, 420 + N, structure)
+    g = dev(d)
+    cache = ops.diag_cache(g["q"])
+    cache[1].fill_(1)  # stale flags must be overwritten by the forward, not trusted
+    if kind == "qp":
+        x = ops.qp_forward(g["P"], g["q"], 1e-7, 1000, cache=cache)
+        a = ops.qp_backward(g["P"], g["q"], x, g["grad_x"])
+        b = ops.qp_backward(g["P"], g["q"], x, g["grad_x"], cache=cache)
+    else:
+        x = ops.qcqp_forward(g["P"], g["q"], g["l_n"], g["mu"], 1e-7, 1000, cache=cache)
+        a = ops.qcqp_backward(g["P"], g["q"], g["l_n"], g["mu"], x, g["grad_x"])
+        b = ops.qcqp_backward(g["P"], g["q"], g["l_n"], g["mu"], x, g["grad_x"], cache=cache)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    flags = cache[1].cpu().numpy()
+    offdiag = (d["P"] - torch.diag_embed(torch.diagonal(d["P"], dim1=1, dim2=2))).abs().amax((1, 2)).numpy() > 0
+    assert not flags[offdiag].any(), "a non-diagonal problem was flagged diagonal"
+    if structure == "diag":
+        assert flags.all()
+        assert torch.equal(cache[0], torch.diagonal(g["P"], dim1=1, dim2=2))
+
+
 def test_compact_diagonal_layout_extension(oracle, ops):
     """DQQ_P_DIAG: P given as (B,N) -- same numbers as the (B,N,N) layout."""
     from diffqcqp_amd import _capi
@@ -415,7 +443,9 @@ def test_autograd_functions_match_reference_contract(oracle, ops):
     assert not x1.is_cuda and torch.equal(x1, x2)
     x1.sum().backward()
     assert w1.grad is None and qc.grad is not None and qc.grad.shape == (10, 8, 1)
-    out = QPFn2.backward(type("C", (), {"saved_tensors": (Pc.cuda(), qc.detach().cuda(), x1.detach().cuda()),
+    cache = ops.diag_cache(qc.detach().cuda())
+    cache[1].zero_()  # no verified diagonal: the backward reads P
+    out = QPFn2.backward(type("C", (), {"saved_tensors": (Pc.cuda(), qc.detach().cuda(), x1.detach().cuda()) + cache,
                                         "needs_input_grad": (False, True, False, False, False, False),
                                         "home": torch.device("cpu")})(), torch.ones(10, 8, 1))
     assert len(out) == 6 and out[0] is None and out[2:] == (None, None, None, None)
