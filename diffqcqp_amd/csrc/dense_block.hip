@@ -1,25 +1,24 @@
 // dense_block.hip -- general (dense P) forward solve for N = 32 and N = 64: one 256-thread
-// workgroup per problem, everything resident in LDS (BASELINE configs[4]: B=65536, N=64).
+// workgroup per problem (BASELINE configs[4]: B=65536, N=64).
 //
 // Same algorithm as dense_core.h / the reference (Solver::solveQP / solveQCQP, Solver.cpp:61-123,
 // 521-582): power iteration, adaptive-rho ADMM with the explicit inverse of P + (rho+mu) I rebuilt
 // at every rho update (the reference's llt() + solveInPlace(Identity), Solver.cpp:76-77, 100-101,
 // 114-115).  What changes is how the O(N^2) and O(N^3) pieces are spread over 4 waves:
 //
-//   R = 256/N threads share a row (thread t: row i = t/R, part r = t%R).
-//   mat-vec       M^-1 lives in a "slab" layout, element (i,c) at ((c/R)*N + i)*R + c%R, so that step j
-//                 of thread t reads word j*256 + t: every ds_read_b64 of a wave is 512 contiguous bytes.
-//                 N/R multiply-adds per thread, then a DPP all-reduce over the R lanes of the row.
-//   Cholesky      right-looking, in place, row-major with stride N+R (conflict-free for the (row,part)
-//                 lane pattern); per column: scale by 1/sqrt(pivot), rank-1 update of the trailing lower
-//                 triangle split over all 256 threads; two barriers per column.
-//   inverse       L^-1 column by column (R threads per column, DPP reductions, no barriers), then
-//                 M^-1 = L^-T L^-1 as N^2 independent dot products written straight into the slab.
-// The factorisation therefore sums in a different order than the reference's left-looking LLT and
-// column-wise substitutions (differences ~1e-16 * cond, far inside the 1e-6 parity tolerance; the
-// iteration counts are still required to match the oracle in tests/).  FP contraction is off.
+//   refactor      blocked (16-column panels) right-looking Cholesky in LDS, L^-1 by blocked forward
+//                 substitution and M^-1 = L^-T L^-1 as tile products -- all 16x16 tile products run on
+//                 the f64 matrix cores (v_mfma_f64_16x16x4_f64); only the 16x16 diagonal blocks are
+//                 factored / inverted by one wave in registers (v_readlane broadcasts).  Three
+//                 workgroup barriers per panel.
+//   iteration     every wave keeps ALL rows (one per lane) and a quarter of the columns of M^-1 in
+//                 registers; one barrier per ADMM iteration (see WaveRows below).
+// The factorisation sums in a different order than the reference's left-looking LLT and column-wise
+// substitutions, and FP contraction is on here (the matrix cores fuse anyway): differences are
+// ~1e-16 * cond, far inside the 1e-6 parity tolerance; the iteration counts are still required to
+// match the oracle in tests/.
 //
-// LDS: two regions of N*(N+R) doubles (68 KiB at N=64) -> two workgroups per CU.
+// LDS: two regions of N*(N+R) doubles (68 KiB at N=64) + 8.6 KiB scratch -> two workgroups per CU.
 #include "common.h"
 #include "launch.h"
 
@@ -28,114 +27,252 @@ namespace dqq {
 template <int N>
 struct BlockGeom {
     static constexpr int T = 256;
-    static constexpr int R = T / N;        // threads per row
-    static constexpr int LD = N + R;       // row stride of the row-major regions
-    static constexpr int REGION = N * LD;  // doubles per region
-    static constexpr int VEC = 4 * N;      // scratch vectors
-    static constexpr size_t LDS_BYTES = sizeof(double) * (2 * REGION + VEC);
+    static constexpr int R = T / N;            // row padding (doubles) of the row-major regions
+    static constexpr int LD = N + R;           // row stride of the row-major regions
+    static constexpr int REGION = N * LD;      // doubles per region
+    static constexpr int VEC = 8 * N + N;      // WaveRows<N>::LDS_DOUBLES
+    static constexpr int TILES = 4 * 256 + 2;  // one 16x16 scratch tile per wave + the failure flag
+    static constexpr size_t LDS_BYTES = sizeof(double) * (2 * REGION + VEC + TILES);
 };
 
-template <int R>
-DQQ_D double row_sum(double v) // all-reduce over the R adjacent lanes of a row
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// value held by lane `src` (wave-uniform) of the calling wave
+DQQ_D double lane_bcast(double v, int src)
 {
-#pragma clang fp contract(off)
-    return LaneGroup<R>::sum(v);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
 }
 
-// W (row-major, stride LD, lower triangle + diagonal valid) -> L in place (right-looking).
-template <int N>
-DQQ_D void block_cholesky(double* W, int t)
+// One 16x16 f64 tile product on the matrix cores: acc += sum_{k<K} A[i][k] * B[k][j] with
+// A[i][k] = a[i*ars + k*acs], B[k][j] = b[k*brs + j*bcs]  (gfx950 v_mfma_f64_16x16x4_f64: lane l feeds
+// A[l&15][l>>4], B[l>>4][l&15]; result register r of lane l is C[(l>>4) + 4r][l&15]).
+DQQ_D v4d tile_mma(v4d acc, const double* a, int ars, int acs, const double* b, int brs, int bcs, int K, int l,
+                   bool negate_a)
 {
-#pragma clang fp contract(off)
-    using G = BlockGeom<N>;
-    const int i = t / G::R, r = t % G::R;
-    for (int k = 0; k < N; ++k) {
-        const double d = sqrt(W[k * G::LD + k]);
-        __syncthreads(); // everybody has read the pivot
-        if (r == 0) {
-            if (i == k) W[k * G::LD + k] = d;
-            else if (i > k) W[i * G::LD + k] = W[i * G::LD + k] / d;
-        }
-        __syncthreads();
-        if (i > k) {
-            const double lik = W[i * G::LD + k];
-            for (int j = k + 1 + r; j <= i; j += G::R) W[i * G::LD + j] -= lik * W[j * G::LD + k];
-        }
-        // the next pivot W[k+1][k+1] is written by row k+1's threads above; the barrier at the top of
-        // the next iteration orders it
-        __syncthreads();
+    const double* ap = a + (l & 15) * ars + (l >> 4) * acs;
+    const double* bp = b + (l >> 4) * brs + (l & 15) * bcs;
+    for (int k = 0; k < K; k += 4) {
+        const double av = ap[k * acs];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(negate_a ? -av : av, bp[k * brs], acc, 0, 0, 0);
     }
+    return acc;
 }
 
-// L (row-major in W) -> LinvT (LinvT[c][j] = (L^-1)[j][c], row-major stride LD) ; R threads per column.
+// Diagonal block kb of the blocked factorisation, by ONE wave in registers (lanes 0-15 = rows of the
+// block): right-looking Cholesky of the 16x16 block of W in place, then its inverse (column c per lane c)
+// into the diagonal block of LinvT (LinvT[c][i] = (L^-1)[i][c]).  Broadcasts via v_readlane, no LDS
+// round trips inside.
 template <int N>
-DQQ_D void block_tri_inverse(const double* W, double* LinvT, int t)
+DQQ_D void diag_block_factor(double* W, double* LinvT, int kb, int l, bool& bad)
 {
-#pragma clang fp contract(off)
     using G = BlockGeom<N>;
-    const int c = t / G::R, r = t % G::R;
-    double* y = LinvT + c * G::LD;
-    const double ycc = 1.0 / W[c * G::LD + c];
-    if (r == 0) y[c] = ycc;
-    wave_lds_fence();
-    for (int i = c + 1; i < N; ++i) { // rows of a column live in one wave: no workgroup barrier needed
-        double s = 0.0;
-        for (int j = c + r; j < i; j += G::R) s += W[i * G::LD + j] * y[j];
-        s = row_sum<G::R>(s);
-        const double yi = -s / W[i * G::LD + i];
-        if (r == 0) y[i] = yi;
-        wave_lds_fence();
-    }
-}
-
-// Minv = L^-T L^-1 into the slab layout: Minv[a][b] = sum_{k >= max(a,b)} LinvT[a][k] * LinvT[b][k].
-template <int N>
-DQQ_D void block_inverse_product(const double* LinvT, double* slab, int t)
-{
-#pragma clang fp contract(off)
-    using G = BlockGeom<N>;
-    const int a = t / G::R, r = t % G::R;
-    for (int j = 0; j < N / G::R; ++j) {
-        const int b = j * G::R + r;
-        const int k0 = a > b ? a : b;
-        double s = 0.0;
-        for (int k = k0; k < N; ++k) s += LinvT[a * G::LD + k] * LinvT[b * G::LD + k];
-        slab[j * G::T + t] = s;
-    }
-}
-
-// out_i = sum_c M[i][c] v[c] with M in the slab layout; result valid in all R lanes of row i.
-template <int N>
-DQQ_D double block_matvec(const double* slab, const double* v, int t)
-{
-#pragma clang fp contract(off)
-    using G = BlockGeom<N>;
-    const int r = t % G::R;
-    double s = 0.0;
+    const int row = (l & 15);
+    double w[16], rinv[16];
+    double* wrow = W + (16 * kb + row) * G::LD + 16 * kb;
 #pragma unroll
-    for (int j = 0; j < N / G::R; ++j) s += slab[j * G::T + t] * v[j * G::R + r];
-    return row_sum<G::R>(s);
+    for (int j = 0; j < 16; ++j) w[j] = wrow[j];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double d = lane_bcast(w[k], k);
+        bad = bad || !(d > 0.0);
+        const double rs = fast_rsqrt(d);
+        rinv[k] = rs;
+        w[k] = (row == k) ? d * rs : w[k] * rs;
+#pragma unroll
+        for (int j = k + 1; j < 16; ++j) w[j] -= w[k] * lane_bcast(w[k], j);
+    }
+    double y[16]; // column `row` of the inverse of the block
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        double t = (row == i) ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < i; ++j) t -= lane_bcast(w[j], i) * y[j];
+        y[i] = t * rinv[i];
+    }
+    if (l < 16) {
+        double* yrow = LinvT + (16 * kb + row) * G::LD + 16 * kb;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            wrow[j] = w[j];
+            yrow[j] = y[j];
+        }
+    }
 }
 
-// max over the N entries of vec (LDS), identical in every thread; vec must be complete (barrier before).
+// Blocked (16-column panels) right-looking Cholesky of W in place + L^-1 (as LinvT), 256 threads.
+// Per panel: diagonal block in registers (wave 0), panel solve and trailing update as 16x16x16 tile
+// products on the f64 matrix cores; 3 workgroup barriers per panel instead of 3 per column.
 template <int N>
-DQQ_D double block_max(const double* vec, int t)
+DQQ_D void block_cholesky_and_inverse(double* W, double* LinvT, double* tile_scratch, int t, bool& bad)
 {
-    double m = vec[t % N];
-    return LaneGroup<(N < 64 ? N : 64)>::max(m);
+    using G = BlockGeom<N>;
+    constexpr int NT = N / 16;
+    const int wave = t >> 6, l = t & 63;
+    for (int kb = 0; kb < NT; ++kb) {
+        if (wave == 0) {
+            diag_block_factor<N>(W, LinvT, kb, l, bad);
+            if (l == 0 && bad) tile_scratch[4 * 256] = 1.0; // non-positive pivot: poison the result (NaN)
+        }
+        __syncthreads();
+        // panel: L[ib][kb] = A[ib][kb] * L11^-T ; (L11^-T)[k][j] = Linv11[j][k] = LinvT[16kb+k][16kb+j]
+        for (int ib = kb + 1 + wave; ib < NT; ib += 4) {
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            acc = tile_mma(acc, W + (16 * ib) * G::LD + 16 * kb, G::LD, 1, LinvT + (16 * kb) * G::LD + 16 * kb, G::LD, 1,
+                           16, l, false);
+            wave_lds_fence(); // all lanes have read the A tile before it is overwritten by L
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) W[(16 * ib + (l >> 4) + 4 * rg) * G::LD + 16 * kb + (l & 15)] = acc[rg];
+        }
+        __syncthreads();
+        // trailing update: A[ib][jb] -= L[ib][kb] * L[jb][kb]^T for kb < jb <= ib
+        int tile = 0;
+        for (int ib = kb + 1; ib < NT; ++ib)
+            for (int jb = kb + 1; jb <= ib; ++jb, ++tile) {
+                if ((tile & 3) != wave) continue;
+                v4d acc;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) acc[rg] = W[(16 * ib + (l >> 4) + 4 * rg) * G::LD + 16 * jb + (l & 15)];
+                acc = tile_mma(acc, W + (16 * ib) * G::LD + 16 * kb, G::LD, 1, W + (16 * jb) * G::LD + 16 * kb, 1, G::LD,
+                               16, l, true);
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) W[(16 * ib + (l >> 4) + 4 * rg) * G::LD + 16 * jb + (l & 15)] = acc[rg];
+            }
+        __syncthreads();
+    }
+    // off-diagonal blocks of L^-1, block row by block row:
+    //   Linv[i][j] = -Linv[i][i] * sum_{k=j}^{i-1} L[i][k] * Linv[k][j];   Linv[a][b] lives at LinvT[b][a]
+    double* T = tile_scratch + wave * 256;
+    for (int i = 1; i < NT; ++i) {
+        for (int j = wave; j < i; j += 4) {
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            // A = L[16i.., 16j..16i), B[k][c] = Linv[16j+k][16j+c] = LinvT[(16j+c)*LD + 16j+k]
+            acc = tile_mma(acc, W + (16 * i) * G::LD + 16 * j, G::LD, 1, LinvT + (16 * j) * G::LD + 16 * j, 1, G::LD,
+                           16 * (i - j), l, false);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) T[((l >> 4) + 4 * rg) * 16 + (l & 15)] = acc[rg];
+            wave_lds_fence();
+            v4d res = {0.0, 0.0, 0.0, 0.0};
+            // A = Linv[16i+a][16i+k] = LinvT[(16i+k)*LD + 16i+a]  (negated), B = T
+            res = tile_mma(res, LinvT + (16 * i) * G::LD + 16 * i, 1, G::LD, T, 16, 1, 16, l, true);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) // element (row a, col c) of Linv[i][j] -> LinvT[16j+c][16i+a]
+                LinvT[(16 * j + (l & 15)) * G::LD + 16 * i + (l >> 4) + 4 * rg] = res[rg];
+            wave_lds_fence();
+        }
+        __syncthreads();
+    }
+    // zero the blocks of LinvT left of the diagonal (the MFMA product sums over all k)
+    for (int idx = t; idx < N * N; idx += G::T) {
+        const int c = idx / N, k = idx % N;
+        if ((k >> 4) < (c >> 4)) LinvT[c * G::LD + k] = 0.0;
+    }
+    __syncthreads();
 }
 
+// Minv = L^-T L^-1 = LinvT LinvT^T (row-major, stride LD) on the f64 matrix cores.  Wave w owns the
+// tile row ti = w (N = 64: 4 waves x 4 tiles; N = 32: waves 0-1 x 2 tiles).
+// Minv[a][b] = sum_k LinvT[a][k] * LinvT[b][k]; LinvT rows are zero left of the diagonal block, so
+// tile (ti,tj) only needs k >= 16*max(ti,tj).  Tiles (ti,tj) and (tj,ti) sum the same products in the
+// same order: the result is bitwise symmetric.
 template <int N>
-DQQ_D double block_sum_seq(const double* vec)
+DQQ_D void block_inverse_product(const double* LinvT, double* out, int t)
 {
-#pragma clang fp contract(off)
-    double s = 0.0;
-    for (int i = 0; i < N; ++i) s += vec[i];
-    return s;
+    using G = BlockGeom<N>;
+    constexpr int NT = N / 16;
+    const int wave = t >> 6, l = t & 63;
+    if (wave >= NT) return;
+    const int ti = wave;
+    for (int tj = 0; tj < NT; ++tj) {
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        const double* arow = LinvT + (16 * ti + (l & 15)) * G::LD + (l >> 4);
+        const double* brow = LinvT + (16 * tj + (l & 15)) * G::LD + (l >> 4);
+        const int s0 = 4 * (ti > tj ? ti : tj);
+#pragma unroll 4
+        for (int s = s0; s < N / 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[4 * s], brow[4 * s], acc, 0, 0, 0);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int row = 16 * ti + (l >> 4) + 4 * rg, col = 16 * tj + (l & 15);
+            out[row * G::LD + col] = acc[rg];
+        }
+    }
 }
+
+// ---- iteration layout: every wave holds ALL rows (lane l = row l & (N-1); the upper half of the wave
+// duplicates the lower one when N = 32) and a block of CW = N/4 columns of the matrix in registers.
+// A mat-vec is: the wave drops its CW right-hand-side entries into a wave-private LDS strip and reads
+// them back as broadcasts (ds_read_b128 of a wave-uniform address), CW multiply-adds per lane, one
+// ds_write of the partial row sums, ONE workgroup barrier, and four ds_reads summed in a fixed order --
+// so the four waves end up with bit-identical vectors and run the element-wise ADMM update, the
+// residual reductions and the stop / rho logic redundantly, with no further exchange.  The partial-sum
+// buffer alternates with the parity of the mat-vec counter: a buffer is rewritten only after the next
+// barrier, which every wave reaches after its reads.
+template <int N>
+struct WaveRows {
+    static constexpr int CW = N / 4;
+    static constexpr int LDS_DOUBLES = 8 * N + 4 * CW; // partial sums (2 x 4 x N) + one strip per wave
+    int wave, lane, row, parity;
+    double* part;
+    double* strip;
+
+    DQQ_D void init(double* base, int t)
+    {
+        wave = __builtin_amdgcn_readfirstlane(t >> 6);
+        lane = t & 63;
+        row = lane & (N - 1);
+        parity = 0;
+        part = base;
+        strip = base + 8 * N + CW * wave;
+    }
+    // sum_c M[row][c] v[c]; m[k] = M[row][CW*wave + k], v = this lane's row entry of the vector
+    DQQ_D double matvec(const double (&m)[CW], double v)
+    {
+        if ((unsigned)(lane - CW * wave) < (unsigned)CW) strip[lane - CW * wave] = v;
+        wave_lds_fence();
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int k = 0; k < CW; k += 4) {
+            a0 = fma(m[k + 0], strip[k + 0], a0);
+            a1 = fma(m[k + 1], strip[k + 1], a1);
+            a2 = fma(m[k + 2], strip[k + 2], a2);
+            a3 = fma(m[k + 3], strip[k + 3], a3);
+        }
+        double* buf = part + parity * 4 * N;
+        parity ^= 1;
+        if (lane < N) buf[wave * N + row] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        return ((buf[row] + buf[N + row]) + buf[2 * N + row]) + buf[3 * N + row];
+    }
+    // max over the N rows of a and of b (both >= 0), identical in every lane of every wave.  One
+    // butterfly serves both: the lower half-wave carries a, the upper one b (gfx950 v_permlane32_swap
+    // exchanges the half-waves of two registers; at N = 32 the upper half already duplicates the rows).
+    DQQ_D void max2_rows(double a, double b, double& ma, double& mb) const
+    {
+        double v;
+        if (N == 64) {
+            const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+            const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+            // [0] = {a[0..31], b[0..31]}, [1] = {a[32..63], b[32..63]}  (tools/ubench/permlane_probe.hip)
+            v = fmax(__hiloint2double(hi[0], lo[0]), __hiloint2double(hi[1], lo[1]));
+        } else {
+            v = lane < 32 ? a : b;
+        }
+        const double m = LaneGroup<16>::max(v);
+        ma = fmax(lane_bcast(m, 0), lane_bcast(m, 16));
+        mb = fmax(lane_bcast(m, 32), lane_bcast(m, 48));
+    }
+    static DQQ_D double sum_rows(double v)
+    {
+        const double m = LaneGroup<16>::sum(v);
+        double out = lane_bcast(m, 0) + lane_bcast(m, 16);
+        if (N == 64) out = (out + lane_bcast(m, 32)) + lane_bcast(m, 48);
+        return out;
+    }
+};
 
 template <int KIND, int N>
-__global__ __launch_bounds__(256) void fwd_dense_block_kernel(const double* __restrict__ P,
+__global__ __launch_bounds__(256, 2) void fwd_dense_block_kernel(const double* __restrict__ P,
                                                               const double* __restrict__ q,
                                                               const double* __restrict__ l_n,
                                                               const double* __restrict__ mu_c, double* __restrict__ x,
@@ -143,94 +280,80 @@ __global__ __launch_bounds__(256) void fwd_dense_block_kernel(const double* __re
                                                               int* __restrict__ iters, int* __restrict__ ws,
                                                               int use_worklist)
 {
-#pragma clang fp contract(off)
     using G = BlockGeom<N>;
+    using WR = WaveRows<N>;
+    constexpr int CW = WR::CW;
+    static_assert(WR::LDS_DOUBLES == G::VEC, "exchange area size");
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* X = smem;                 // region 0: P (slab) -> W / L -> M^-1 (slab)
+    double* X = smem;                 // region 0: W / L -> M^-1 (row-major, stride LD)
     double* Y = X + G::REGION;        // region 1: LinvT
-    double* va = Y + G::REGION;       // N
-    double* vb = va + N;              // N
-    double* vc = vb + N;              // N
-    double* vd = vc + N;              // N
-    const int t = threadIdx.x, i = t / G::R, r = t % G::R;
+    double* part = Y + G::REGION;     // WaveRows exchange area
+    double* tiles = part + G::VEC;    // 4 x 256 + flag
+    const int t = threadIdx.x;
+    WR wr;
+    wr.init(part, t);
+    const int row = wr.row;
     const long count = use_worklist ? (long)ws[kWsCount] : B;
 
     for (long w = blockIdx.x; w < count; w += gridDim.x) {
         const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
         const double* Pg = P + prob * (long)(N * N);
-        __syncthreads();
-        // ---- P into the slab layout (for the power iteration)
-        for (int idx = t; idx < N * N; idx += G::T) {
-            const int row = idx / N, c = idx % N;
-            X[((c / G::R) * N + row) * G::R + c % G::R] = Pg[idx];
-        }
+        double m[CW]; // the wave's column block of P (power iteration), then of M^-1 (ADMM)
+#pragma unroll
+        for (int k = 0; k < CW; ++k) m[k] = Pg[row * N + CW * wr.wave + k];
         // ---- power_iteration, Solver.cpp:46-59
         double v = 1 / sqrt((double)N);
-        if (r == 0) va[i] = v * v;
-        __syncthreads();
         {
-            const double s = block_sum_seq<N>(va);
+            const double s = WR::sum_rows(v * v);
             if (s > 0) v = v / sqrt(s);
         }
         const int pi_steps = (KIND == 0) ? 10 : 100;
         for (int k = 0; k < pi_steps; ++k) {
-            __syncthreads();
-            if (r == 0) vb[i] = v;
-            __syncthreads();
-            const double Av = block_matvec<N>(X, vb, t);
-            if (r == 0) va[i] = Av * Av;
-            __syncthreads();
-            const double s = block_sum_seq<N>(va);
+            const double Av = wr.matvec(m, v);
+            const double s = WR::sum_rows(Av * Av);
             v = (s > 0) ? Av / sqrt(s) : Av;
         }
-        double Lmax;
-        {
-            __syncthreads();
-            if (r == 0) vb[i] = v;
-            __syncthreads();
-            const double Av = block_matvec<N>(X, vb, t);
-            if (r == 0) va[i] = v * Av;
-            __syncthreads();
-            Lmax = block_sum_seq<N>(va);
-        }
+        const double Lmax = WR::sum_rows(v * wr.matvec(m, v));
+        bool bad = false;
+        if (t == 0) tiles[4 * 256] = 0.0;
         double rho = sqrt(mu * Lmax) * pow(Lmax / mu, .4);       // :72 / :531
         double tau_inc = pow(Lmax / mu, .15), tau_dec = tau_inc; // :73 / :532
-        double mdiag = Pg[i * N + i] + (rho + mu);               // accumulated shifted diagonal, :75
+        double mdiag = Pg[row * N + row] + (rho + mu);           // accumulated shifted diagonal, :75
 
         auto refactor = [&]() { // llt() + solveInPlace(Identity) of P + shift, Solver.cpp:76-77
             __syncthreads();
             for (int idx = t; idx < N * N; idx += G::T) {
-                const int row = idx / N, c = idx % N;
-                if (c <= row) X[row * G::LD + c] = (c == row) ? 0.0 : Pg[idx];
+                const int rr = idx / N, c = idx % N;
+                if (c < rr) X[rr * G::LD + c] = Pg[idx];
             }
+            if (t < N) X[row * G::LD + row] = mdiag;
             __syncthreads();
-            if (r == 0) X[i * G::LD + i] = mdiag;
-            __syncthreads();
-            block_cholesky<N>(X, t);
-            block_tri_inverse<N>(X, Y, t);
-            __syncthreads();
+            block_cholesky_and_inverse<N>(X, Y, tiles, t, bad);
             block_inverse_product<N>(Y, X, t);
             __syncthreads();
+            // M^-1 is symmetric: read the column block entries as rows (conflict-free)
+#pragma unroll
+            for (int k = 0; k < CW; ++k) m[k] = X[(CW * wr.wave + k) * G::LD + row];
         };
-        refactor();
 
-        const double qi = q[prob * N + i];
+        const double qi = q[prob * N + row];
         double rad = 0.0;
-        if (KIND == 1) rad = l_n[prob * (N / 2) + i / 2] * mu_c[prob * (N / 2) + i / 2];
+        if (KIND == 1) rad = l_n[prob * (N / 2) + row / 2] * mu_c[prob * (N / 2) + row / 2];
         double qp = qi, l2 = 0.0, l2p = 0.0, u = 0.0;
         int rho_up = 0, cpt = 0, it_done = 0;
+        bool need_refactor = true;
+        double inv_rho = 1.0 / rho;
         for (int it = 0; it < max_iter; ++it) {
+            if (need_refactor) { refactor(); need_refactor = false; inv_rho = 1.0 / rho; } // the ONLY call site
             it_done = it + 1;
-            if (r == 0) va[i] = rho * l2 - u - qp;
-            __syncthreads();
-            const double l = block_matvec<N>(X, va, t);                  // :80 / :539
+            const double l = wr.matvec(m, rho * l2 - u - qp);            // :80 / :539
             qp = qi - mu * l;                                            // :81 / :540
-            double z = kAlpha * l + (1 - kAlpha) * l2 + u / rho;         // :82 / :541
+            double z = kAlpha * l + (1 - kAlpha) * l2 + u * inv_rho;     // :82 / :541 (inv_rho = 1/rho)
             if (KIND == 0) {
                 z = z < 0 ? 0 : z;
             } else {                                                     // prox_circle, :505-519
-                const double other = __shfl_xor(z, G::R, 64);            // the row i^1 sits R lanes away
-                const double a = (i & 1) ? other : z, b = (i & 1) ? z : other;
+                const double other = partner<1>(z);                      // row ^ 1
+                const double a = (row & 1) ? other : z, b = (row & 1) ? z : other;
                 const double nrm = sqrt(a * a + b * b);
                 if (nrm > rad) z = z * rad / nrm;
             }
@@ -239,16 +362,13 @@ __global__ __launch_bounds__(256) void fwd_dense_block_kernel(const double* __re
             const double rd_i = (KIND == 0) ? fabs(rho * (l2 - l2p)) : fabs(l2 - l2p);
             const double rp_i = fabs(l2 - (kAlpha * l + (1 - kAlpha) * l2p));
             l2p = l2;
-            if (r == 0) { vb[i] = rd_i; vc[i] = rp_i; if (KIND == 1) vd[i] = l * l; }
-            __syncthreads();
-            const double rdm = block_max<N>(vb, t), res_prim = block_max<N>(vc, t);
+            double rdm, res_prim;
+            wr.max2_rows(rd_i, rp_i, rdm, res_prim);
             const double res_dual = (KIND == 0) ? rdm : rho * rdm;
             bool stop = res_dual < eps;                                  // :88
-            if (KIND == 1) stop = (res_prim < eps + kEpsRel * sqrt(block_sum_seq<N>(vd))) && stop; // :548
-            __syncthreads(); // va/vb/vc are rewritten next iteration
+            if (KIND == 1) stop = (res_prim < eps + kEpsRel * sqrt(WR::sum_rows(l * l))) && stop; // :548
             if (stop) break;
             if (adaptive) {
-                bool upd = false;
                 if (res_prim > kMuThresh * res_dual) {                   // :92 / :552
                     if (cpt % 5 == 0) {
                         if (rho_up == -1) {
@@ -258,7 +378,7 @@ __global__ __launch_bounds__(256) void fwd_dense_block_kernel(const double* __re
                         mdiag += rho * (tau_inc - 1);
                         rho *= tau_inc;
                         rho_up = 1;
-                        upd = true;
+                        need_refactor = true;
                     }
                     cpt++;
                 } else if (res_dual > kMuThresh * res_prim) {            // :106 / :566
@@ -270,14 +390,15 @@ __global__ __launch_bounds__(256) void fwd_dense_block_kernel(const double* __re
                         mdiag += rho * (1. / tau_dec - 1);
                         rho /= tau_dec;
                         rho_up = -1;
-                        upd = true;
+                        need_refactor = true;
                     }
                     cpt++;
                 }
-                if (upd) refactor();
             }
         }
-        if (r == 0) x[prob * N + i] = l2;
+        __syncthreads(); // the failure flag of the last refactor is visible; X/Y free for the next problem
+        const bool failed = tiles[4 * 256] != 0.0 || !(rho > 0.0) || !(rho < 1.79e308);
+        if (t < N) x[prob * N + row] = failed ? NAN : l2;
         if (iters != nullptr && t == 0) iters[prob] = it_done;
     }
     // last workgroup out re-zeroes the work-list header (nothing to do when the list was empty)
