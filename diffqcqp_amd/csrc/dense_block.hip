@@ -18,7 +18,8 @@
 // ~1e-16 * cond, far inside the 1e-6 parity tolerance; the iteration counts are still required to
 // match the oracle in tests/.
 //
-// LDS: two regions of N*(N+R) doubles (68 KiB at N=64) + 8.6 KiB scratch -> two workgroups per CU.
+// LDS: two regions of N*(N+R) doubles (68 KiB at N=64) + 4.5 KiB exchange area = 72.5 KiB -> two
+// workgroups per CU (160 KiB); the scratch tiles of the blocked inverse live inside the second region.
 #include "common.h"
 #include "launch.h"
 
@@ -31,8 +32,7 @@ struct BlockGeom {
     static constexpr int LD = N + R;           // row stride of the row-major regions
     static constexpr int REGION = N * LD;      // doubles per region
     static constexpr int VEC = 8 * N + N;      // WaveRows<N>::LDS_DOUBLES
-    static constexpr int TILES = 4 * 256 + 2;  // one 16x16 scratch tile per wave + the failure flag
-    static constexpr size_t LDS_BYTES = sizeof(double) * (2 * REGION + VEC + TILES);
+    static constexpr size_t LDS_BYTES = sizeof(double) * (2 * REGION + VEC + 2); // + the failure flag
 };
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -105,7 +105,7 @@ DQQ_D void diag_block_factor(double* W, double* LinvT, int kb, int l, bool& bad)
 // Per panel: diagonal block in registers (wave 0), panel solve and trailing update as 16x16x16 tile
 // products on the f64 matrix cores; 3 workgroup barriers per panel instead of 3 per column.
 template <int N>
-DQQ_D void block_cholesky_and_inverse(double* W, double* LinvT, double* tile_scratch, int t, bool& bad)
+DQQ_D void block_cholesky_and_inverse(double* W, double* LinvT, double* fail_flag, int t, bool& bad)
 {
     using G = BlockGeom<N>;
     constexpr int NT = N / 16;
@@ -113,7 +113,7 @@ DQQ_D void block_cholesky_and_inverse(double* W, double* LinvT, double* tile_scr
     for (int kb = 0; kb < NT; ++kb) {
         if (wave == 0) {
             diag_block_factor<N>(W, LinvT, kb, l, bad);
-            if (l == 0 && bad) tile_scratch[4 * 256] = 1.0; // non-positive pivot: poison the result (NaN)
+            if (l == 0 && bad) *fail_flag = 1.0; // non-positive pivot: poison the result (NaN)
         }
         __syncthreads();
         // panel: L[ib][kb] = A[ib][kb] * L11^-T ; (L11^-T)[k][j] = Linv11[j][k] = LinvT[16kb+k][16kb+j]
@@ -143,7 +143,9 @@ DQQ_D void block_cholesky_and_inverse(double* W, double* LinvT, double* tile_scr
     }
     // off-diagonal blocks of L^-1, block row by block row:
     //   Linv[i][j] = -Linv[i][i] * sum_{k=j}^{i-1} L[i][k] * Linv[k][j];   Linv[a][b] lives at LinvT[b][a]
-    double* T = tile_scratch + wave * 256;
+    // Per-wave 16x16 scratch tile: a block of LinvT LEFT of the diagonal (last block row, block column
+    // `wave`) -- those blocks are untouched until the zero fill below, and at most NT-1 waves are active.
+    double* T = LinvT + (16 * (NT - 1)) * G::LD + 16 * (wave < NT - 1 ? wave : 0);
     for (int i = 1; i < NT; ++i) {
         for (int j = wave; j < i; j += 4) {
             v4d acc = {0.0, 0.0, 0.0, 0.0};
@@ -151,11 +153,11 @@ DQQ_D void block_cholesky_and_inverse(double* W, double* LinvT, double* tile_scr
             acc = tile_mma(acc, W + (16 * i) * G::LD + 16 * j, G::LD, 1, LinvT + (16 * j) * G::LD + 16 * j, 1, G::LD,
                            16 * (i - j), l, false);
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) T[((l >> 4) + 4 * rg) * 16 + (l & 15)] = acc[rg];
+            for (int rg = 0; rg < 4; ++rg) T[((l >> 4) + 4 * rg) * G::LD + (l & 15)] = acc[rg];
             wave_lds_fence();
             v4d res = {0.0, 0.0, 0.0, 0.0};
             // A = Linv[16i+a][16i+k] = LinvT[(16i+k)*LD + 16i+a]  (negated), B = T
-            res = tile_mma(res, LinvT + (16 * i) * G::LD + 16 * i, 1, G::LD, T, 16, 1, 16, l, true);
+            res = tile_mma(res, LinvT + (16 * i) * G::LD + 16 * i, 1, G::LD, T, G::LD, 1, 16, l, true);
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) // element (row a, col c) of Linv[i][j] -> LinvT[16j+c][16i+a]
                 LinvT[(16 * j + (l & 15)) * G::LD + 16 * i + (l >> 4) + 4 * rg] = res[rg];
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void fwd_dense_block_kernel(const double* _
     double* X = smem;                 // region 0: W / L -> M^-1 (row-major, stride LD)
     double* Y = X + G::REGION;        // region 1: LinvT
     double* part = Y + G::REGION;     // WaveRows exchange area
-    double* tiles = part + G::VEC;    // 4 x 256 + flag
+    double* fail_flag = part + G::VEC;
     const int t = threadIdx.x;
     WR wr;
     wr.init(part, t);
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void fwd_dense_block_kernel(const double* _
         }
         const double Lmax = WR::sum_rows(v * wr.matvec(m, v));
         bool bad = false;
-        if (t == 0) tiles[4 * 256] = 0.0;
+        if (t == 0) *fail_flag = 0.0;
         double rho = sqrt(mu * Lmax) * pow(Lmax / mu, .4);       // :72 / :531
         double tau_inc = pow(Lmax / mu, .15), tau_dec = tau_inc; // :73 / :532
         double mdiag = Pg[row * N + row] + (rho + mu);           // accumulated shifted diagonal, :75
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void fwd_dense_block_kernel(const double* _
             }
             if (t < N) X[row * G::LD + row] = mdiag;
             __syncthreads();
-            block_cholesky_and_inverse<N>(X, Y, tiles, t, bad);
+            block_cholesky_and_inverse<N>(X, Y, fail_flag, t, bad);
             block_inverse_product<N>(Y, X, t);
             __syncthreads();
             // M^-1 is symmetric: read the column block entries as rows (conflict-free)
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void fwd_dense_block_kernel(const double* _
             }
         }
         __syncthreads(); // the failure flag of the last refactor is visible; X/Y free for the next problem
-        const bool failed = tiles[4 * 256] != 0.0 || !(rho > 0.0) || !(rho < 1.79e308);
+        const bool failed = *fail_flag != 0.0 || !(rho > 0.0) || !(rho < 1.79e308);
         if (t < N) x[prob * N + row] = failed ? NAN : l2;
         if (iters != nullptr && t == 0) iters[prob] = it_done;
     }
