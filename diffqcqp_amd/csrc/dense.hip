@@ -170,6 +170,8 @@ static hipError_t launch_bwd_kind(const BwdArgs& a, bool use_worklist, hipStream
 hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
+    if (bwd_dense_block_supported(kind, a.N) && g_dense_block.load() != 0)
+        return launch_bwd_dense_block(kind, a, use_worklist, s);
     return kind == 0 ? launch_bwd_kind<0>(a, use_worklist, s) : launch_bwd_kind<1>(a, use_worklist, s);
 }
 

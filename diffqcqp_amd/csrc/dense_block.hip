@@ -21,6 +21,7 @@
 // LDS: two regions of N*(N+R) doubles (68 KiB at N=64) + 4.5 KiB exchange area = 72.5 KiB -> two
 // workgroups per CU (160 KiB); the scratch tiles of the blocked inverse live inside the second region.
 #include "common.h"
+#include "kkt_core.h"
 #include "launch.h"
 
 namespace dqq {
@@ -177,8 +178,8 @@ DQQ_D void block_cholesky_and_inverse(double* W, double* LinvT, double* fail_fla
 // tile row ti = w (N = 64: 4 waves x 4 tiles; N = 32: waves 0-1 x 2 tiles).
 // Minv[a][b] = sum_k LinvT[a][k] * LinvT[b][k]; LinvT rows are zero left of the diagonal block, so
 // tile (ti,tj) only needs k >= 16*max(ti,tj).  Tiles (ti,tj) and (tj,ti) sum the same products in the
-// same order: the result is bitwise symmetric.
-template <int N>
+// same order: the result is bitwise symmetric.  FULL: rows without structure (plain Gram matrix A A^T).
+template <int N, bool FULL = false>
 DQQ_D void block_inverse_product(const double* LinvT, double* out, int t)
 {
     using G = BlockGeom<N>;
@@ -190,7 +191,7 @@ DQQ_D void block_inverse_product(const double* LinvT, double* out, int t)
         v4d acc = {0.0, 0.0, 0.0, 0.0};
         const double* arow = LinvT + (16 * ti + (l & 15)) * G::LD + (l >> 4);
         const double* brow = LinvT + (16 * tj + (l & 15)) * G::LD + (l >> 4);
-        const int s0 = 4 * (ti > tj ? ti : tj);
+        const int s0 = FULL ? 0 : 4 * (ti > tj ? ti : tj);
 #pragma unroll 4
         for (int s = s0; s < N / 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[4 * s], brow[4 * s], acc, 0, 0, 0);
 #pragma unroll
@@ -435,6 +436,152 @@ hipError_t launch_fwd_dense_block(int kind, const FwdArgs& a, bool use_worklist,
     if (a.B == 0) return hipSuccess;
     if (a.N == 64) return kind == 0 ? launch_block<0, 64>(a, use_worklist, s) : launch_block<1, 64>(a, use_worklist, s);
     if (a.N == 32) return kind == 0 ? launch_block<0, 32>(a, use_worklist, s) : launch_block<1, 32>(a, use_worklist, s);
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------- backward (QP), N = 32 / 64
+// One workgroup per problem; the composition of pybindings.cpp:24-30 -> Solver::dualFromPrimalQP
+// (Solver.cpp:125-134), Solver::solveDerivativesQP (:136-196), Solver::iterative_refinement (:15-44) and
+// the gradient assembly of qcqp.py:48-51.
+//
+// The reference orders the unknowns (active..., inactive...) and solves A^T b = [0; grad_I] with
+// A = blkdiag(diag(l_A), P_II) through the normal equations.  Here the system keeps the ORIGINAL index
+// order with the active rows / columns of P masked out (A~[r][c] = P[r][c] if r and c are inactive,
+// l_r if r = c is active, 0 otherwise): a symmetric permutation of the same block-diagonal matrix.  The
+// 1x1 active blocks never mix with the rest in K = A~ A~^T + mu I, its Cholesky factor or its inverse
+// (all cross terms are exact zeros), and the inactive indices keep their relative order, so the
+// arithmetic on the inactive block is the reference's up to the summation order inside the tile
+// products.  K, the factorisation and K^-1 run on the matrix cores as in the forward kernel; the
+// refinement loop uses the WaveRows layout (K and K^-1 column blocks in registers).
+template <int N>
+__global__ __launch_bounds__(256, 2) void bwd_dense_block_qp_kernel(const double* __restrict__ P,
+                                                                 const double* __restrict__ q,
+                                                                 const double* __restrict__ x,
+                                                                 const double* __restrict__ grad_x,
+                                                                 double* __restrict__ grad_P, double* __restrict__ grad_q,
+                                                                 long B, double dual_eps, int* __restrict__ ir_steps,
+                                                                 int* __restrict__ ws, int use_worklist)
+{
+    using G = BlockGeom<N>;
+    using WR = WaveRows<N>;
+    constexpr int CW = WR::CW;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* X = smem;                 // K -> L -> K^-1
+    double* Y = X + G::REGION;        // masked P -> LinvT
+    double* part = Y + G::REGION;
+    double* fail_flag = part + G::VEC;
+    const int t = threadIdx.x;
+    WR wr;
+    wr.init(part, t);
+    const int row = wr.row;
+    const long count = use_worklist ? (long)ws[kWsCount] : B;
+
+    for (long w = blockIdx.x; w < count; w += gridDim.x) {
+        const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
+        const double* Pg = P + prob * (long)(N * N);
+        double m[CW]; // P[row][CW*wave ..]
+#pragma unroll
+        for (int k = 0; k < CW; ++k) m[k] = Pg[row * N + CW * wr.wave + k];
+        const double xi = x[prob * N + row], gi = grad_x[prob * N + row], qi = q[prob * N + row];
+        if (t == 0) *fail_flag = 0.0;
+        // dualFromPrimalQP, Solver.cpp:125-134, and the active set of solveDerivativesQP, :139-147
+        double gamma = -(wr.matvec(m, xi) + qi);
+        if (xi > dual_eps) gamma = 0;
+        const bool is_act = gamma < -kActiveEps;
+        unsigned long long am = __ballot(is_act);
+        if (N == 32) am &= 0xffffffffull;
+        // A~ (see above) into Y, row-major
+        for (int idx = t; idx < N * N; idx += G::T) {
+            const int r = idx / N, c = idx % N;
+            const bool masked = ((am >> r) | (am >> c)) & 1ull;
+            Y[r * G::LD + c] = masked ? 0.0 : Pg[idx];
+        }
+        __syncthreads();
+        if (t < N && is_act) Y[row * G::LD + row] = xi;                       // diag(l_A), :148-158
+        __syncthreads();
+        // A^T b (:19) with b = [0; grad_I]: sum over the inactive k of P[i][k] g[k]; zero on active rows
+        double Ab = wr.matvec(m, is_act ? 0.0 : gi);
+        if (is_act) Ab = 0.0;
+        // K = A~ A~^T + mu_ir I (:20-21) -> X
+        block_inverse_product<N, true>(Y, X, t);
+        __syncthreads();
+        if (t < N) X[row * G::LD + row] += kMuIr;
+        __syncthreads();
+        double kk[CW]; // K[row][CW*wave ..] (bitwise symmetric: read as columns, conflict-free)
+#pragma unroll
+        for (int k = 0; k < CW; ++k) kk[k] = X[(CW * wr.wave + k) * G::LD + row];
+        __syncthreads();
+        bool bad = false;
+        block_cholesky_and_inverse<N>(X, Y, fail_flag, t, bad);              // :22-23
+        block_inverse_product<N>(Y, X, t);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CW; ++k) m[k] = X[(CW * wr.wave + k) * G::LD + row]; // K^-1
+        const double KinvAb = wr.matvec(m, Ab);                               // :27
+        double xs = 0.0;
+        IrControl ctl;
+        ctl.init();
+        int steps = 0;
+        for (int it = 0; it < kIrMaxIter; ++it) {
+            steps = it + 1;
+            xs = kMuIr * wr.matvec(m, xs) + KinvAb;                           // :29
+            const double d = wr.matvec(kk, xs) - Ab;                          // :30
+            const double res = sqrt(WR::sum_rows(d * d));                     // :31
+            if (ctl.update(res)) break;                                       // :32-41
+        }
+        const bool failed = *fail_flag != 0.0;
+        const double dl = failed ? NAN : (is_act ? 0.0 : xs);                 // :187-191
+        if (t < N && grad_q != nullptr) grad_q[prob * N + row] = -dl;        // qcqp.py:49
+        if (grad_P != nullptr) {                                              // qcqp.py:48: -(dl l^T)
+            double* Gp = grad_P + prob * (long)(N * N);
+            const int lane = t & 63;
+#pragma unroll
+            for (int k = 0; k < N * N / 256; ++k) {
+                double dr;
+                if (N == 64) {
+                    dr = lane_bcast(dl, wr.wave + 4 * k);
+                } else {
+                    const double d0 = lane_bcast(dl, 2 * (wr.wave + 4 * k)), d1 = lane_bcast(dl, 2 * (wr.wave + 4 * k) + 1);
+                    dr = (lane >> 5) ? d1 : d0;
+                }
+                __builtin_nontemporal_store(-(dr * xi), Gp + (wr.wave + 4 * k) * 64 + lane);
+            }
+        }
+        if (ir_steps != nullptr && t == 0) ir_steps[prob] = steps;
+        __syncthreads(); // X / Y / the failure flag are free for the next problem
+    }
+    if (use_worklist && count > 0 && t == 0) {
+        const int tk = atomicAdd(&ws[kWsTicket], 1);
+        if (tk == (int)gridDim.x - 1) {
+            ws[kWsCount] = 0;
+            ws[kWsTicket] = 0;
+        }
+    }
+}
+
+template <int N>
+static hipError_t launch_block_bwd(const BwdArgs& a, bool use_worklist, hipStream_t s)
+{
+    using G = BlockGeom<N>;
+    auto kernel = bwd_dense_block_qp_kernel<N>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    const long cap = 256L * 2 * 4;
+    const unsigned grid = use_worklist ? 512u : (unsigned)(a.B < cap ? (a.B > 0 ? a.B : 1) : cap);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), G::LDS_BYTES, s, a.P, a.q, a.x, a.grad_x, a.grad_P, a.grad_q, a.B,
+                       a.epsilon, a.ir_steps, a.ws, use_worklist ? 1 : 0);
+    return hipGetLastError();
+}
+
+bool bwd_dense_block_supported(int kind, int N) { return kind == 0 && (N == 32 || N == 64); }
+
+hipError_t launch_bwd_dense_block(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)
+{
+    if (a.B == 0) return hipSuccess;
+    if (kind != 0) return hipErrorInvalidValue;
+    if (a.N == 64) return launch_block_bwd<64>(a, use_worklist, s);
+    if (a.N == 32) return launch_block_bwd<32>(a, use_worklist, s);
     return hipErrorInvalidValue;
 }
 

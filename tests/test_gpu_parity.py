@@ -252,6 +252,25 @@ def test_block_and_wave_dense_forward_agree(oracle, ops, kind, N, B):
     assert (out[0][0] - out[1][0]).abs().max() < 1e-8
 
 
+@pytest.mark.parametrize("N,B", [(32, 40), (64, 12), (64, 300)])
+def test_block_and_wave_dense_backward_agree(oracle, ops, N, B):
+    """N = 32 / 64 QP backward has two general kernels: workgroup-per-problem on the matrix cores (default)
+    and wave-per-problem in the reference's operation order.  Both are checked against the oracle."""
+    from diffqcqp_amd import _capi
+    d = make_problem("qp", B, N, 690 + N, "dense")
+    g = dev(d)
+    xo, _ = oracle_fwd(oracle, "qp", d)
+    ref = oracle_bwd(oracle, "qp", d, xo)
+    out = {}
+    for blk in (1, 0):
+        _capi.set_option("dense_block", blk)
+        out[blk] = hip_bwd(ops, "qp", g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
+        check_backward_exact(out[blk][0], out[blk][1], ref, exact=False)
+    _capi.set_option("dense_block", 1)
+    for a, b in zip(out[0][0], out[1][0]):
+        assert (a - b).abs().max() <= 1e-9 * max(1.0, float(b.abs().max()))
+
+
 @pytest.mark.parametrize("kind", ["qp", "qcqp"])
 @pytest.mark.parametrize("N,B", [(8, 1000), (6, 130), (4, 300), (2, 65)])
 def test_lane_and_wave_dense_forward_agree(oracle, ops, kind, N, B):
