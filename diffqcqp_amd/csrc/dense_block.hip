@@ -275,7 +275,7 @@ struct WaveRows {
 };
 
 template <int KIND, int N>
-__global__ __launch_bounds__(256, 2) void fwd_dense_block_kernel(const double* __restrict__ P,
+__global__ __launch_bounds__(256, N == 32 ? 3 : 2) void fwd_dense_block_kernel(const double* __restrict__ P,
                                                               const double* __restrict__ q,
                                                               const double* __restrict__ l_n,
                                                               const double* __restrict__ mu_c, double* __restrict__ x,
@@ -422,7 +422,7 @@ static hipError_t launch_block(const FwdArgs& a, bool use_worklist, hipStream_t 
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     if (e != hipSuccess) return e;
-    const long cap = 256L * 2 * 2; // persistent: two workgroups per CU fit in LDS, x2 for load balance
+    const long cap = 256L * (N == 32 ? 3 : 2) * 2; // persistent: 2 (N=64, LDS) or 3 (N=32, VGPRs) workgroups per CU, x2 for balance
     const unsigned grid = use_worklist ? 512u : (unsigned)(a.B < cap ? (a.B > 0 ? a.B : 1) : cap);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), G::LDS_BYTES, s, a.P, a.q, a.l_n, a.mu, a.x, a.B, a.eps, a.mu_prox,
                        a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0);
