@@ -145,15 +145,21 @@ static void prox_circle(double *l, const double *l_n, int nc)
 
 /* --------------------------------------------------------------- forward */
 
-/* Solver::solveQP (kind 0), qcqplib/Solver.cpp:61-123, and Solver::solveQCQP
- * (kind 1), qcqplib/Solver.cpp:521-582.  `radius` is l_n o mu (pybindings.cpp:57)
- * for kind 1 and unused for kind 0.  warm_start is accepted by the reference
+/* Solver::solveQP (kind 0), qcqplib/Solver.cpp:61-123, Solver::solveQCQP
+ * (kind 1), qcqplib/Solver.cpp:521-582, Solver::solveBoxQP (kind 2), :198-261,
+ * and Solver::solveSignedBoxQP (kind 3), :374-439.  The two box solvers are the
+ * QP loop with another projection (:219-220 / :396-398); everything else --
+ * 10 power steps, symmetric tau damping, dual-residual-only stop -- is the QP's.
+ * `radius` is l_n o mu (pybindings.cpp:57) for kind 1; `l_min`, `l_max` for
+ * kinds 2, 3; `v` for kind 3.  warm_start is accepted by the reference
  * and overwritten before it is ever read (Solver.cpp:70/80, 529/539), so it is
  * not a parameter here.  Returns the number of ADMM iterations executed. */
-static int admm_solve(int kind, const double *P_in, const double *q, const double *radius, int n,
-                      double epsilon, double mu_prox, int max_iter, int adaptative_rho, double *x_out,
-                      double *ws /* 2n^2 + n^2 + 8n */)
+static int admm_solve_ex(int kind, const double *P_in, const double *q, const double *radius,
+                         const double *l_min, const double *l_max, const double *v_in, int n, double epsilon,
+                         double mu_prox, int max_iter, int adaptative_rho, double *x_out,
+                         double *ws /* 2n^2 + n^2 + 8n */)
 {
+    const int qp_like = (kind != 1);
     const double mu_thresh = 10., alpha_relax = 1.5, eps_rel = 1e-4;
     double *P = ws, *Pinv = P + n * n, *L = Pinv + n * n;
     double *q_prox = L + n * n, *l = q_prox + n, *l_2 = l + n, *l_2_pred = l_2 + n, *u = l_2_pred + n,
@@ -162,7 +168,7 @@ static int admm_solve(int kind, const double *P_in, const double *q, const doubl
     int i, it, rho_up = 0, cpt = 0, iters = 0;
     memcpy(P, P_in, sizeof(double) * n * n); /* MatrixXd P by value, :61 / :521 */
     for (i = 0; i < n; ++i) { u[i] = 0; l_2[i] = 0; l_2_pred[i] = 0; }
-    Lmax = power_iteration(P, n, kind == 0 ? 10 : 100, rhs, tmp); /* :71 / :530 */
+    Lmax = power_iteration(P, n, qp_like ? 10 : 100, rhs, tmp); /* :71 / :530 / :209 / :385 */
     rho = sqrt(mu_prox * Lmax) * pow(Lmax / mu_prox, .4);          /* :72 / :531 */
     tau_inc = pow(Lmax / mu_prox, .15);                            /* :73 / :532 */
     tau_dec = tau_inc;
@@ -181,6 +187,19 @@ static int admm_solve(int kind, const double *P_in, const double *q, const doubl
                 double t = alpha_relax * l[i] + (1 - alpha_relax) * l_2[i] + u[i] / rho;
                 l_2[i] = t < 0 ? 0 : t;                            /* cwiseMax(0) = std::max(t,0) */
             }
+        } else if (kind == 2 || kind == 3) {
+            for (i = 0; i < n; ++i) {                              /* :219-220 / :396-397 */
+                double t = alpha_relax * l[i] + (1 - alpha_relax) * l_2[i] + u[i] / rho;
+                t = t < l_min[i] ? l_min[i] : t;                   /* cwiseMax(l_min) */
+                t = l_max[i] < t ? l_max[i] : t;                   /* cwiseMin(l_max) */
+                if (kind == 3) {                                   /* :395, :398: v = sign(v); l_2 = v o min(v o l_2, 0) */
+                    const double sg = (double)((v_in[i] > 0) - (v_in[i] < 0));
+                    double m = sg * t;
+                    m = 0 < m ? 0 : m;
+                    t = sg * m;
+                }
+                l_2[i] = t;
+            }
         } else {
             for (i = 0; i < n; ++i)                                /* :541 */
                 l_2[i] = alpha_relax * l[i] + (1 - alpha_relax) * l_2[i] + u[i] / rho;
@@ -188,7 +207,7 @@ static int admm_solve(int kind, const double *P_in, const double *q, const doubl
         }
         for (i = 0; i < n; ++i)                                    /* :83 / :543 */
             u[i] += rho * (alpha_relax * l[i] + (1 - alpha_relax) * l_2_pred[i] - l_2[i]);
-        if (kind == 0) {
+        if (qp_like) {
             for (i = 0; i < n; ++i) {                              /* :84-85 */
                 Plqu[i] = rho * (l_2[i] - l_2_pred[i]);
                 if (fabs(Plqu[i]) > rd) rd = fabs(Plqu[i]);
@@ -214,7 +233,7 @@ static int admm_solve(int kind, const double *P_in, const double *q, const doubl
                 if (cpt % 5 == 0) {
                     if (rho_up == -1) {
                         tau_inc = 1 + .8 * (tau_inc - 1);
-                        if (kind == 0) tau_dec = 1 + .8 * (tau_dec - 1); /* :94-97 vs :554-556 */
+                        if (qp_like) tau_dec = 1 + .8 * (tau_dec - 1); /* :94-97 vs :554-556 */
                     }
                     add_to_diag(P, n, rho * (tau_inc - 1));
                     rho *= tau_inc;
@@ -225,7 +244,7 @@ static int admm_solve(int kind, const double *P_in, const double *q, const doubl
             } else if (res_dual > mu_thresh * res_prim) {          /* :106 / :566 */
                 if (cpt % 5 == 0) {
                     if (rho_up == 1) {
-                        if (kind == 0) tau_inc = 1 + .8 * (tau_inc - 1); /* :108-111 vs :568-570 */
+                        if (qp_like) tau_inc = 1 + .8 * (tau_inc - 1); /* :108-111 vs :568-570 */
                         tau_dec = 1 + .8 * (tau_dec - 1);
                     }
                     add_to_diag(P, n, rho * (1. / tau_dec - 1));
@@ -241,13 +260,21 @@ static int admm_solve(int kind, const double *P_in, const double *q, const doubl
     return iters;
 }
 
+static int admm_solve(int kind, const double *P_in, const double *q, const double *radius, int n,
+                      double epsilon, double mu_prox, int max_iter, int adaptative_rho, double *x_out, double *ws)
+{
+    return admm_solve_ex(kind, P_in, q, radius, NULL, NULL, NULL, n, epsilon, mu_prox, max_iter, adaptative_rho,
+                         x_out, ws);
+}
+
 /* -------------------------------------------------------------- backward */
 
 /* Solver::iterative_refinement, qcqplib/Solver.cpp:15-44, with its defaults
  * mu_ir=1e-7, epsilon=1e-10, max_iter=10.  A is n x n.  Returns the number of
  * loop bodies executed.  ws: 3 n^2 + 4 n. */
-static int iterative_refinement(const double *A, const double *b, int n, double *x, double *ws)
+static int iterative_refinement_rect(const double *A, const double *b, int rows, int n, double *x, double *ws)
 {
+    /* A is rows x n (row-major); the unknown has n = A.cols() entries.  ws: 3 n^2 + 4 n. */
     const double mu_ir = 1e-7, epsilon = 1e-10;
     const int max_iter = 10;
     double *K = ws, *Kinv = K + n * n, *L = Kinv + n * n;
@@ -257,13 +284,13 @@ static int iterative_refinement(const double *A, const double *b, int n, double 
     for (i = 0; i < n; ++i) x[i] = 0;
     for (i = 0; i < n; ++i) { /* Ab = A^T b, :19 */
         double s = 0;
-        for (k = 0; k < n; ++k) s += A[k * n + i] * b[k];
+        for (k = 0; k < rows; ++k) s += A[k * n + i] * b[k];
         Ab[i] = s;
     }
     for (i = 0; i < n; ++i)   /* AA_tild = A^T A (+ mu_ir I), :20-21 */
         for (j = 0; j < n; ++j) {
             double s = 0;
-            for (k = 0; k < n; ++k) s += A[k * n + i] * A[k * n + j];
+            for (k = 0; k < rows; ++k) s += A[k * n + i] * A[k * n + j];
             K[i * n + j] = s;
         }
     add_to_diag(K, n, mu_ir);
@@ -285,6 +312,11 @@ static int iterative_refinement(const double *A, const double *b, int n, double 
         if (res < epsilon || not_improved == 2) break; /* :39 */
     }
     return steps;
+}
+
+static int iterative_refinement(const double *A, const double *b, int n, double *x, double *ws)
+{
+    return iterative_refinement_rect(A, b, n, n, x, ws);
 }
 
 /* Solver::dualFromPrimalQP, qcqplib/Solver.cpp:125-134 */
@@ -443,6 +475,88 @@ static int solve_derivatives_qcqp(const double *P, const double *l_n, const doub
     return steps;
 }
 
+/* ------------------------------------------------------------ box QP backward
+ * The index bookkeeping shared by Solver::dualFromPrimalBoxQP (:263-308) and
+ * Solver::solveDerivativesBoxQP (:310-371): coordinate i contributes the lower
+ * multiplier i when l_i - l_min_i <= eps and the upper multiplier n + i when
+ * l_i - l_max_i >= -eps, in that (interleaved) order.  Returns their number. */
+static int box_not_null(const double *l_min, const double *l_max, const double *l, int n, double epsilon,
+                        int *not_null)
+{
+    int i, nn = 0;
+    for (i = 0; i < n; ++i) {
+        if (!(l[i] - l_min[i] > epsilon)) not_null[nn++] = i;        /* :268-274 / :315-320 */
+        if (!(l[i] - l_max[i] < -epsilon)) not_null[nn++] = n + i;   /* :275-282 / :321-327 */
+    }
+    return nn;
+}
+
+/* Id2 (n x nn), :291-300 / :331-340: column j holds -1 (lower bound) or +1 (upper bound) in the row of
+ * its coordinate. */
+static void box_id2(const int *not_null, int nn, int n, double *Id2)
+{
+    int j;
+    for (j = 0; j < n * nn; ++j) Id2[j] = 0;
+    for (j = 0; j < nn; ++j) {
+        if (not_null[j] < n) Id2[not_null[j] * nn + j] = -1;
+        else Id2[(not_null[j] - n) * nn + j] = 1;
+    }
+}
+
+/* Solver::dualFromPrimalBoxQP, qcqplib/Solver.cpp:263-308 (the std::cout loop of :287-289 is debugging
+ * output and not reproduced).  gamma: 2n.  ws: n*2n + 2n + 3(2n)^2 + 4(2n).  Returns the refinement steps. */
+static int dual_from_primal_box(const double *P, const double *q, const double *l_min, const double *l_max,
+                                const double *l, int n, double epsilon, double *gamma, double *ws)
+{
+    double *Id2 = ws, *rhs = Id2 + 2 * n * n, *gnn = rhs + n, *irws = gnn + 2 * n;
+    int *not_null = (int *)malloc(sizeof(int) * (2 * n + 1));
+    int nn, i, j, steps = 0;
+    for (i = 0; i < 2 * n; ++i) gamma[i] = 0;
+    nn = box_not_null(l_min, l_max, l, n, epsilon, not_null);
+    box_id2(not_null, nn, n, Id2);
+    for (i = 0; i < n; ++i) {                                          /* -P*l - q, :301 */
+        double s = 0;
+        for (j = 0; j < n; ++j) s += (-P[i * n + j]) * l[j];
+        rhs[i] = s - q[i];
+    }
+    if (nn > 0) steps = iterative_refinement_rect(Id2, rhs, n, nn, gnn, irws);
+    for (j = 0; j < nn; ++j) gamma[not_null[j]] = gnn[j];              /* :302-304 */
+    free(not_null);
+    return steps;
+}
+
+/* Solver::solveDerivativesBoxQP, qcqplib/Solver.cpp:310-371.  blgamma: 3n = [dgamma (2n, scattered); dl (n)].
+ * ws: (3n)^2 + 2*3n + n*2n + 3(3n)^2 + 4*3n. */
+static int solve_derivatives_box(const double *P, const double *l_min, const double *l_max, const double *l,
+                                 const double *gamma, const double *grad_l, int n, double epsilon,
+                                 double *blgamma, double *ws)
+{
+    const int mmax = 3 * n;
+    double *A = ws, *dd = A + mmax * mmax, *b = dd + mmax, *Id2 = b + mmax, *irws = Id2 + 2 * n * n;
+    int *not_null = (int *)malloc(sizeof(int) * (2 * n + 1));
+    int nn, m, i, j, steps;
+    nn = box_not_null(l_min, l_max, l, n, epsilon, not_null);
+    m = nn + n;
+    box_id2(not_null, nn, n, Id2);
+    /* A = [[0, B],[Id2, P]], B.row(j) = gamma(not_null[j]) * Id2.col(j)^T, :341-350 */
+    for (i = 0; i < m * m; ++i) A[i] = 0;
+    for (j = 0; j < nn; ++j)
+        for (i = 0; i < n; ++i) A[j * m + nn + i] = gamma[not_null[j]] * Id2[i * nn + j];
+    for (i = 0; i < n; ++i) {
+        for (j = 0; j < nn; ++j) A[(nn + i) * m + j] = Id2[i * nn + j];
+        for (j = 0; j < n; ++j) A[(nn + i) * m + nn + j] = P[i * n + j];
+    }
+    for (i = 0; i < m; ++i)                                            /* A.transposeInPlace(), :351 */
+        for (j = i + 1; j < m; ++j) { double t = A[i * m + j]; A[i * m + j] = A[j * m + i]; A[j * m + i] = t; }
+    for (i = 0; i < m; ++i) dd[i] = (i < nn) ? 0. : grad_l[i - nn];     /* :352-360 */
+    steps = iterative_refinement(A, dd, m, b, irws);                   /* :362 */
+    for (i = 0; i < 3 * n; ++i) blgamma[i] = 0;                         /* :363-369 */
+    for (j = 0; j < nn; ++j) blgamma[not_null[j]] = b[j];
+    for (i = 0; i < n; ++i) blgamma[2 * n + i] = b[nn + i];
+    free(not_null);
+    return steps;
+}
+
 /* ---------------------------------------------- single-problem entry points
  * Same composition as the pybind11 module `diffqcqp` (pybindings.cpp:17-30,
  * 54-71).  Return value: iteration / refinement-step count (diagnostic the
@@ -509,6 +623,53 @@ ORC_API int orc_solveDerivativesQCQP(const double *P, const double *q, const dou
     if (gamma_out) for (i = 0; i < nc; ++i) gamma_out[i] = gamma[i];
     free(ws);
     return steps;
+}
+
+/* pybindings.cpp:32-37 */
+ORC_API int orc_solveBoxQP(const double *P, const double *q, const double *l_min, const double *l_max,
+                           const double *warm_start, int n, double epsilon, double mu_prox, int max_iter,
+                           int adaptative_rho, double *x)
+{
+    double *ws = (double *)malloc(sizeof(double) * fwd_ws_doubles(n));
+    int it;
+    (void)warm_start; /* dead in the reference: Solver.cpp:208 then :217 */
+    it = admm_solve_ex(2, P, q, NULL, l_min, l_max, NULL, n, epsilon, mu_prox, max_iter, adaptative_rho, x, ws);
+    free(ws);
+    return it;
+}
+
+/* pybindings.cpp:47-52 */
+ORC_API int orc_solveSignedBoxQP(const double *P, const double *q, const double *l_min, const double *l_max,
+                                 const double *v, const double *warm_start, int n, double epsilon,
+                                 double mu_prox, int max_iter, int adaptative_rho, double *x)
+{
+    double *ws = (double *)malloc(sizeof(double) * fwd_ws_doubles(n));
+    int it;
+    (void)warm_start; /* dead in the reference: Solver.cpp:384 then :393 */
+    it = admm_solve_ex(3, P, q, NULL, l_min, l_max, v, n, epsilon, mu_prox, max_iter, adaptative_rho, x, ws);
+    free(ws);
+    return it;
+}
+
+static size_t box_ws_doubles(int n)
+{
+    size_t m = (size_t)3 * n + 1;
+    return 4 * m * m + 2 * (size_t)n * n + 16 * m + 64;
+}
+
+/* pybindings.cpp:39-45: returns (blgamma (3n), gamma (2n)).  steps_out (may be NULL): [0] refinement steps
+ * of the dual recovery, [1] of the derivative system (also the return value). */
+ORC_API int orc_solveDerivativesBoxQP(const double *P, const double *q, const double *l_min,
+                                      const double *l_max, const double *l, const double *grad_l, int n,
+                                      double epsilon, double *blgamma, double *gamma, int *steps_out)
+{
+    double *ws = (double *)malloc(sizeof(double) * box_ws_doubles(n));
+    int s0, s1;
+    s0 = dual_from_primal_box(P, q, l_min, l_max, l, n, epsilon, gamma, ws);
+    s1 = solve_derivatives_box(P, l_min, l_max, l, gamma, grad_l, n, epsilon, blgamma, ws);
+    if (steps_out) { steps_out[0] = s0; steps_out[1] = s1; }
+    free(ws);
+    return s1;
 }
 
 /* ------------------------------------------------------ batched entry points
@@ -588,6 +749,59 @@ ORC_API void orc_qcqp_bwd_batch(const double *P, const double *q, const double *
         if (grad_mu)
             for (i = 0; i < nc; ++i) grad_mu[b * nc + i] = e1[i] * dg[i];
         free(buf);
+    }
+}
+
+/* The batch loops of BoxQPFn2 / SignedBoxQPFn2.forward, qcqp.py:60-62 / :103-105.  v == NULL: box QP. */
+ORC_API void orc_boxqp_fwd_batch(const double *P, const double *q, const double *l_min, const double *l_max,
+                                 const double *v, long B, int n, double eps, double mu_prox, int max_iter,
+                                 double *x, int *iters, int nthreads)
+{
+    long b;
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+    for (b = 0; b < B; ++b) {
+        int it = v ? orc_solveSignedBoxQP(P + b * n * n, q + b * n, l_min + b * n, l_max + b * n, v + b * n, NULL, n,
+                                          eps, mu_prox, max_iter, 1, x + b * n)
+                   : orc_solveBoxQP(P + b * n * n, q + b * n, l_min + b * n, l_max + b * n, NULL, n, eps, mu_prox,
+                                    max_iter, 1, x + b * n);
+        if (iters) iters[b] = it;
+    }
+}
+
+/* BoxQPFn2.backward as intended by qcqp.py:79-93 (the shipped Python does not run: SURVEY.md section 2 #7):
+ * grad_P = -dl x^T, grad_q = -dl, and for the bounds the sensitivities of the complementarity rows
+ * gamma_j c_j(l) with c_lower = l_min - l, c_upper = l - l_max:
+ *   grad_l_min = -dgamma_lower o gamma_lower        (qcqp.py:91)
+ *   grad_l_max = +dgamma_upper o gamma_upper        (qcqp.py:93 writes a minus sign; finite differences
+ *                                                    -- tests/test_oracle.py -- say plus)
+ * gamma_out (B,2n), ir_steps (B,2) may be NULL. */
+ORC_API void orc_boxqp_bwd_batch(const double *P, const double *q, const double *l_min, const double *l_max,
+                                 const double *x, const double *grad_x, long B, int n, double *grad_P,
+                                 double *grad_q, double *grad_l_min, double *grad_l_max, double *gamma_out,
+                                 int *ir_steps, int nthreads)
+{
+    long b;
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+    for (b = 0; b < B; ++b) {
+        double *blg = (double *)malloc(sizeof(double) * 5 * n);
+        double *gam = blg + 3 * n;
+        const double *dg = blg, *dl = blg + 2 * n;
+        int i, j, st[2];
+        orc_solveDerivativesBoxQP(P + b * n * n, q + b * n, l_min + b * n, l_max + b * n, x + b * n, grad_x + b * n,
+                                  n, 1e-10, blg, gam, st);
+        if (ir_steps) { ir_steps[2 * b] = st[0]; ir_steps[2 * b + 1] = st[1]; }
+        if (grad_P)
+            for (i = 0; i < n; ++i)
+                for (j = 0; j < n; ++j) grad_P[b * n * n + i * n + j] = -(dl[i] * x[b * n + j]);
+        if (grad_q)
+            for (i = 0; i < n; ++i) grad_q[b * n + i] = -dl[i];
+        if (grad_l_min)
+            for (i = 0; i < n; ++i) grad_l_min[b * n + i] = -(dg[i] * gam[i]);
+        if (grad_l_max)
+            for (i = 0; i < n; ++i) grad_l_max[b * n + i] = dg[n + i] * gam[n + i];
+        if (gamma_out)
+            for (i = 0; i < 2 * n; ++i) gamma_out[b * 2 * n + i] = gam[i];
+        free(blg);
     }
 }
 

@@ -38,9 +38,11 @@ def lib():
             build()
         _lib = ctypes.CDLL(_LIB_PATH)
         _lib.orc_max_threads.restype = ctypes.c_int
-        for name in ("orc_solveQP", "orc_solveQCQP", "orc_solveDerivativesQP", "orc_solveDerivativesQCQP"):
+        for name in ("orc_solveQP", "orc_solveQCQP", "orc_solveDerivativesQP", "orc_solveDerivativesQCQP",
+                     "orc_solveBoxQP", "orc_solveSignedBoxQP", "orc_solveDerivativesBoxQP"):
             getattr(_lib, name).restype = ctypes.c_int
-        for name in ("orc_qp_fwd_batch", "orc_qcqp_fwd_batch", "orc_qp_bwd_batch", "orc_qcqp_bwd_batch"):
+        for name in ("orc_qp_fwd_batch", "orc_qcqp_fwd_batch", "orc_qp_bwd_batch", "orc_qcqp_bwd_batch",
+                     "orc_boxqp_fwd_batch", "orc_boxqp_bwd_batch"):
             getattr(_lib, name).restype = None
     return _lib
 
@@ -103,6 +105,42 @@ def solveDerivativesQCQP(P, q, l_n, mu, l, grad_l, epsilon=1e-10, return_steps=F
     return out + (st, gam) if return_steps else out
 
 
+def solveBoxQP(P, q, l_min, l_max, warm_start, epsilon=1e-10, mu_prox=1e-7, max_iter=1000, adaptative_rho=True,
+               return_iters=False):
+    """pybindings.cpp:32-37, :77"""
+    P, q, l_min, l_max = _c(P), _c(q).reshape(-1), _c(l_min).reshape(-1), _c(l_max).reshape(-1)
+    n = q.size
+    x = np.empty(n)
+    it = lib().orc_solveBoxQP(_p(P), _p(q), _p(l_min), _p(l_max), None, ctypes.c_int(n), ctypes.c_double(epsilon),
+                              ctypes.c_double(mu_prox), ctypes.c_int(int(max_iter)),
+                              ctypes.c_int(bool(adaptative_rho)), _p(x))
+    return (x, it) if return_iters else x
+
+
+def solveSignedBoxQP(P, q, l_min, l_max, v, warm_start, epsilon=1e-10, mu_prox=1e-7, max_iter=1000,
+                     adaptative_rho=True, return_iters=False):
+    """pybindings.cpp:47-52, :78"""
+    P, q, l_min, l_max, v = _c(P), _c(q).reshape(-1), _c(l_min).reshape(-1), _c(l_max).reshape(-1), _c(v).reshape(-1)
+    n = q.size
+    x = np.empty(n)
+    it = lib().orc_solveSignedBoxQP(_p(P), _p(q), _p(l_min), _p(l_max), _p(v), None, ctypes.c_int(n),
+                                    ctypes.c_double(epsilon), ctypes.c_double(mu_prox), ctypes.c_int(int(max_iter)),
+                                    ctypes.c_int(bool(adaptative_rho)), _p(x))
+    return (x, it) if return_iters else x
+
+
+def solveDerivativesBoxQP(P, q, l_min, l_max, l, grad_l, epsilon=1e-10, return_steps=False):
+    """Returns (blgamma (3n,), gamma (2n,)) like pybindings.cpp:39-45, :81."""
+    P, q, l_min, l_max = _c(P), _c(q).reshape(-1), _c(l_min).reshape(-1), _c(l_max).reshape(-1)
+    l, grad_l = _c(l).reshape(-1), _c(grad_l).reshape(-1)
+    n = q.size
+    blg, gam = np.empty(3 * n), np.empty(2 * n)
+    st = np.zeros(2, dtype=np.int32)
+    lib().orc_solveDerivativesBoxQP(_p(P), _p(q), _p(l_min), _p(l_max), _p(l), _p(grad_l), ctypes.c_int(n),
+                                    ctypes.c_double(epsilon), _p(blg), _p(gam), _ip(st))
+    return (blg, gam, st) if return_steps else (blg, gam)
+
+
 # ---- batched API: the loops of qcqp.py:24-52, 144-181 ---------------------------
 
 def max_threads():
@@ -153,3 +191,30 @@ def qcqp_bwd_batch(P, q, l_n, mu, x, grad_x, nthreads=1):
     lib().orc_qcqp_bwd_batch(_p(P), _p(q), _p(l_n), _p(mu), _p(x), _p(grad_x), ctypes.c_long(B), ctypes.c_int(n),
                              _p(gP), _p(gq), _p(gl), _p(gm), _ip(steps), ctypes.c_int(nthreads))
     return gP, gq, gl, gm, steps
+
+
+def boxqp_fwd_batch(P, q, l_min, l_max, eps, max_iter, v=None, mu_prox=1e-7, nthreads=1):
+    """BoxQPFn2.forward (qcqp.py:56-65); with v: SignedBoxQPFn2.forward (qcqp.py:99-108)."""
+    P, q, l_min, l_max = _c(P), _c(q), _c(l_min), _c(l_max)
+    v = None if v is None else _c(v)
+    B, n = q.shape[0], q.shape[1]
+    x = np.empty((B, n, 1))
+    iters = np.empty(B, dtype=np.int32)
+    lib().orc_boxqp_fwd_batch(_p(P), _p(q), _p(l_min), _p(l_max), _p(v), ctypes.c_long(B), ctypes.c_int(n),
+                              ctypes.c_double(eps), ctypes.c_double(mu_prox), ctypes.c_int(int(max_iter)), _p(x),
+                              _ip(iters), ctypes.c_int(nthreads))
+    return x, iters
+
+
+def boxqp_bwd_batch(P, q, l_min, l_max, x, grad_x, nthreads=1):
+    """-> grad_P, grad_q, grad_l_min (B,n,1), grad_l_max (B,n,1), gamma (B,2n), ir_steps (B,2)"""
+    P, q, l_min, l_max, x, grad_x = _c(P), _c(q), _c(l_min), _c(l_max), _c(x), _c(grad_x)
+    B, n = q.shape[0], q.shape[1]
+    gP, gq = np.empty((B, n, n)), np.empty((B, n, 1))
+    glo, ghi = np.empty((B, n, 1)), np.empty((B, n, 1))
+    gam = np.empty((B, 2 * n))
+    steps = np.empty((B, 2), dtype=np.int32)
+    lib().orc_boxqp_bwd_batch(_p(P), _p(q), _p(l_min), _p(l_max), _p(x), _p(grad_x), ctypes.c_long(B),
+                              ctypes.c_int(n), _p(gP), _p(gq), _p(glo), _p(ghi), _p(gam), _ip(steps),
+                              ctypes.c_int(nthreads))
+    return gP, gq, glo, ghi, gam, steps

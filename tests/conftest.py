@@ -24,6 +24,7 @@ def oracle():
 
 def make_problem(kind, B, N, seed, structure="diag", p_lo=0.1, dtype=np.float64):
     """Seeded synthetic batch in the reference's layouts (SURVEY.md 8d distributions).
+    kind: 'qp', 'qcqp', 'box' (+ l_min, l_max) or 'sbox' (+ l_min, l_max, v).
     structure: 'diag' P = diag(U(p_lo, p_lo+1)); 'dense' P = S S^T/N + 0.1 I; 'mixed' alternates."""
     import torch
     g = torch.Generator().manual_seed(seed)
@@ -43,4 +44,11 @@ def make_problem(kind, B, N, seed, structure="diag", p_lo=0.1, dtype=np.float64)
     if kind == "qcqp":
         out["l_n"] = torch.rand(B, N // 2, 1, generator=g, dtype=torch.float64)
         out["mu"] = torch.rand(B, N // 2, 1, generator=g, dtype=torch.float64)
+    if kind in ("box", "sbox"):
+        # the reference's own box test, Solver.cpp:807-808: l_min in [-1.5,-0.5], l_max in [0.5,1.5]; here
+        # scaled by 0.6 so that, with q ~ U(-1,1), bounds are active on roughly half of the coordinates
+        out["l_min"] = -0.6 * (torch.rand(B, N, 1, generator=g, dtype=torch.float64) + 0.5)
+        out["l_max"] = 0.6 * (torch.rand(B, N, 1, generator=g, dtype=torch.float64) + 0.5)
+        if kind == "sbox":
+            out["v"] = 2 * torch.rand(B, N, 1, generator=g, dtype=torch.float64) - 1  # Solver.cpp:796
     return out

@@ -183,6 +183,96 @@ def test_qcqp_fd_gradients(oracle):
         assert np.allclose(np.diag(E1), 2 * gam * ln * ln * mu) and np.allclose(np.diag(E2), 2 * gam * ln * mu * mu)
 
 
+# ---------------------------------------------------------------- box QP / signed box QP
+def test_box_diag_closed_form(oracle):
+    """Diagonal P: x* = clamp(-q/p, l_min, l_max); signed box additionally v o x <= 0 (Solver.cpp:396-398).
+
+    Reference quirk (Solver.cpp:226): the loop stops on the DUAL residual rho*|l_2 - l_2_pred| alone, so when
+    the over-relaxed iterate is clamped to the same bounds on every coordinate in two consecutive iterations it
+    stops there (iteration 2) whatever the primal residual is.  Such returns have no interior coordinate; every
+    other problem must match the closed form."""
+    d = make_problem("sbox", 64, 8, 71)
+    P, q = d["P"].numpy(), d["q"].numpy()
+    lo, hi, v = d["l_min"].numpy(), d["l_max"].numpy(), d["v"].numpy()
+    p = np.diagonal(P, axis1=1, axis2=2)[..., None]
+    x, it = oracle.boxqp_fwd_batch(P, q, lo, hi, 1e-9, 10000)
+    ref = np.clip(-q / p, lo, hi)
+    interior = ((x > lo) & (x < hi)).any(axis=(1, 2))
+    assert interior.mean() > 0.8 and it.max() < 10000
+    assert np.abs(x - ref)[interior].max() < 1e-6
+    early = ~interior & (np.abs(x - ref).max(axis=(1, 2)) > 1e-6)
+    assert (it[early] <= 2).all()           # the quirk, and nothing else, explains a wrong return
+    xs, its = oracle.boxqp_fwd_batch(P, q, lo, hi, 1e-9, 10000, v=v)
+    sg = np.sign(v)
+    refs = sg * np.minimum(sg * ref, 0.0)  # the feasible set is a box with one side moved to 0
+    lo_s, hi_s = np.where(sg < 0, np.maximum(lo, 0.0), lo), np.where(sg > 0, np.minimum(hi, 0.0), hi)
+    interior_s = ((xs > lo_s) & (xs < hi_s)).any(axis=(1, 2))
+    assert np.abs(xs - refs)[interior_s].max() < 1e-6 and its.max() < 10000
+    assert (sg * xs <= 0).all() and (xs >= lo).all() and (xs <= hi).all()
+
+
+def test_box_matches_qp_when_bounds_are_zero_and_infinity(oracle):
+    """l_min = 0, l_max = +huge reduces solveBoxQP to solveQP (same loop, Solver.cpp:198-261 vs :61-123)."""
+    d = make_problem("qp", 16, 8, 72, "dense")
+    P, q = d["P"].numpy(), d["q"].numpy()
+    x0, it0 = oracle.qp_fwd_batch(P, q, 1e-7, 1000)
+    x1, it1 = oracle.boxqp_fwd_batch(P, q, np.zeros_like(q), np.full_like(q, 1e300), 1e-7, 1000)
+    assert np.array_equal(x0, x1) and np.array_equal(it0, it1)
+
+
+def test_box_kkt_and_fd_gradients(oracle):
+    """KKT of the recovered duals and finite differences of every input.  Settles the sign the reference
+    leaves open (qcqp.py:93 vs Solver.cpp:837): grad_l_min = -dgamma_lo*gamma_lo, grad_l_max = +dgamma_hi*gamma_hi."""
+    rng = np.random.default_rng(0)
+    n = 6
+    S = rng.random((n, n))
+    P = S @ S.T / n + 0.1 * np.eye(n)
+    q = rng.uniform(-1, 1, n)
+    lo = -(rng.random(n) * 0.5 + 0.05)
+    hi = rng.random(n) * 0.5 + 0.05
+    g = rng.standard_normal(n)
+
+    def sol(P=P, q=q, lo=lo, hi=hi):
+        return oracle.solveBoxQP(P, q, lo, hi, np.zeros(n), 1e-12, 1e-7, 100000)
+
+    x = sol()
+    blg, gam, st = oracle.solveDerivativesBoxQP(P, q, lo, hi, x, g, return_steps=True)
+    assert (gam >= -1e-9).all() and 0 < (gam > 1e-6).sum() < n
+    assert np.abs(P @ x + q - gam[:n] + gam[n:]).max() < 1e-6
+    dg, dl = blg[:2 * n], blg[2 * n:]
+    h = 1e-6
+    E = np.eye(n)
+    fd = lambda f: np.array([g @ (f(+h * E[i]) - f(-h * E[i])) / (2 * h) for i in range(n)])
+    assert np.allclose(-dl, fd(lambda e: sol(q=q + e)), atol=2e-5)
+    assert np.allclose(-(dg[:n] * gam[:n]), fd(lambda e: sol(lo=lo + e)), atol=2e-5)
+    assert np.allclose(+(dg[n:] * gam[n:]), fd(lambda e: sol(hi=hi + e)), atol=2e-5)
+    gP = -np.outer(dl, x)
+    for (i, j) in [(0, 0), (1, 4), (4, 1), (5, 5)]:
+        D = np.zeros((n, n)); D[i, j] = D[j, i] = h  # LLT reads the lower triangle only: perturb symmetrically
+        num = g @ (sol(P=P + D) - sol(P=P - D)) / (2 * h)
+        ana = gP[i, j] + (gP[j, i] if i != j else 0.0)
+        assert abs(num - ana) < 5e-5
+    # batched assembly agrees with the single-problem composition
+    out = oracle.boxqp_bwd_batch(P[None], q[None, :, None], lo[None, :, None], hi[None, :, None], x[None, :, None],
+                                 g[None, :, None])
+    assert np.array_equal(out[0][0], gP) and np.array_equal(out[1][0, :, 0], -dl)
+    assert np.array_equal(out[2][0, :, 0], -(dg[:n] * gam[:n])) and np.array_equal(out[3][0, :, 0], dg[n:] * gam[n:])
+    assert np.array_equal(out[4][0], gam) and out[5][0].tolist() == st.tolist()
+
+
+def test_box_both_bounds_active(oracle):
+    """l_min == l_max pins a coordinate: both multipliers enter the system (a 3x3 block per coordinate)."""
+    d = make_problem("box", 8, 4, 73)
+    P, q = d["P"].numpy(), d["q"].numpy()
+    lo, hi = d["l_min"].numpy().copy(), d["l_max"].numpy().copy()
+    hi[:, 1] = lo[:, 1]
+    x, _ = oracle.boxqp_fwd_batch(P, q, lo, hi, 1e-9, 10000)
+    assert np.abs(x[:, 1] - lo[:, 1]).max() < 1e-12
+    out = oracle.boxqp_bwd_batch(P, q, lo, hi, x, d["grad_x"].numpy())
+    assert all(np.isfinite(o).all() for o in out[:5])
+    assert np.abs(out[1][:, 1]).max() < 1e-5  # a pinned coordinate does not move with q
+
+
 def test_warm_start_is_dead(oracle):
     """Solver.cpp:70 then :80 -- the argument cannot change the result."""
     d = make_problem("qp", 1, 8, 41, "dense")
