@@ -31,14 +31,20 @@
 
 namespace dqq {
 
-// KIND 0 = QP (x >= 0), 1 = QCQP (per-contact disk of radius rad[c]).
-// p, q: this lane's E coordinates; rad: this lane's E/2 radii (KIND 1).
+// KIND 0 = QP (x >= 0), 1 = QCQP (per-contact disk of radius rad[c]), 2 = box QP (lo <= x <= hi,
+// Solver::solveBoxQP, Solver.cpp:198-261), 3 = signed box QP (box and sg o x <= 0, sg = sign(v),
+// Solver::solveSignedBoxQP, :374-439).  The box solvers are the QP loop with another projection line
+// (:219-220 / :396-398): 10 power steps, both taus damped, dual-residual-only stop.
+// p, q: this lane's E coordinates; rad: this lane's E/2 radii (KIND 1); lo, hi, sg: this lane's E bounds and
+// signs (KIND 2, 3; may be null otherwise).
 // valid = false: the lane only keeps the wave's control flow company.
 // Returns the number of ADMM iterations executed (Solver.cpp:79 / :538 loop).
 template <int KIND, int E, class G>
 DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const double* rad, int n, double eps,
-                         double mu, int max_iter, int adaptive, bool valid, double (&x)[E])
+                         double mu, int max_iter, int adaptive, bool valid, double (&x)[E],
+                         const double* lo = nullptr, const double* hi = nullptr, const double* sg = nullptr)
 {
+    constexpr bool QP_LIKE = (KIND != 1);
     static_assert(E % 2 == 0, "E must be even");
     double M[E], Minv[E], qp[E], l2[E], u[E];
 
@@ -62,7 +68,7 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
                 const double s1 = ldexp(p[e], -k); // |s1| < 1, the largest is >= 0.5
                 const double s2 = s1 * s1, s4 = s2 * s2, s8 = s4 * s4, s16 = s8 * s8;
                 double a; // s1^(2K)
-                if (KIND == 0) {
+                if (QP_LIKE) {
                     a = s16 * s4;                                   // ^20
                 } else {
                     const double s32 = s16 * s16, s64 = s32 * s32, s128 = s64 * s64;
@@ -111,6 +117,19 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
             if (KIND == 0) {
 #pragma unroll
                 for (int e = 0; e < E; ++e) z[e] = fmax(z[e], 0.0);           // cwiseMax(0), :82
+            } else if (KIND == 2 || KIND == 3) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    double t = z[e];
+                    t = t < lo[e] ? lo[e] : t;                                // cwiseMax(l_min), :219 / :396
+                    t = hi[e] < t ? hi[e] : t;                                // cwiseMin(l_max), :220 / :397
+                    if (KIND == 3) {                                          // v o min(v o l_2, 0), :398
+                        double m = sg[e] * t;
+                        m = 0 < m ? 0 : m;
+                        t = sg[e] * m;
+                    }
+                    z[e] = t;
+                }
             } else {
 #pragma unroll
                 for (int c = 0; c < E / 2; ++c) {                             // prox_circle, :505-519
@@ -153,7 +172,7 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
                 if (fire) {
                     if (rho_up == (inc ? -1 : 1)) {                           // direction flipped: damp tau
                         const double ti = 1 + .8 * (tau_inc - 1), td = 1 + .8 * (tau_dec - 1);
-                        if (KIND == 0) { tau_inc = ti; tau_dec = td; }        // :94-97, :108-111 (QP damps both)
+                        if (QP_LIKE) { tau_inc = ti; tau_dec = td; }          // :94-97, :108-111 (QP damps both)
                         else if (inc) tau_inc = ti;                           // :554-556
                         else tau_dec = td;                                    // :568-570
                     }

@@ -124,7 +124,7 @@ static int fwd_dispatch(int kind, dqq::FwdArgs& a, void* workspace, size_t works
     if (a.B == 0) return 0;
     (void)hipGetLastError(); // drop any stale error of the calling thread: ours are read after each launch
     const bool fast_ok = dqq::fwd_diag_supported(a.N);
-    const bool dense_ok = a.N <= dqq::dense_max_n(kind);
+    const bool dense_ok = a.N <= dqq::dense_max_n(kind == dqq::kKindQCQP ? 1 : 0);
     hipError_t e;
     if (a.layout == DQQ_P_DIAG) {
         if (!fast_ok) return DQQ_E_UNSUPPORTED_N;
@@ -142,7 +142,7 @@ static int fwd_dispatch(int kind, dqq::FwdArgs& a, void* workspace, size_t works
     a.ws = static_cast<int*>(workspace);
     bool needs_fallback = true;
     int fuse = g_fuse.load();
-    if (fuse < 0 && dqq::fwd_lane_dense_supported(a.N)) {
+    if (fuse < 0 && kind <= dqq::kKindQCQP && dqq::fwd_lane_dense_supported(a.N)) {
         a.hint = hint_device_pointer();
         if (a.hint != nullptr) {
             bool dense_before = false;
@@ -190,7 +190,7 @@ int dqq_qp_fwd_f64(const double* P, const double* q, double* x, int64_t B, int N
     if (int rc = check_common(B, N, p_layout, false)) return rc;
     if (B > 0 && (P == nullptr || q == nullptr || x == nullptr)) return DQQ_E_NULLPTR;
     const bool keep = p_layout == DQQ_P_AUTO && dqq::fwd_diag_supported(N);
-    dqq::FwdArgs a{P,        q,     nullptr, nullptr, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0,
+    dqq::FwdArgs a{P,        q,     nullptr, nullptr, nullptr, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0,
                    p_layout, iters, nullptr, keep ? pdiag_out : nullptr, keep ? diag_flags_out : nullptr, nullptr, 0};
     if (!keep && diag_flags_out != nullptr && B > 0) { // nothing will be verified: flag every problem 0
         hipError_t e = hipMemsetAsync(diag_flags_out, 0, (size_t)B, static_cast<hipStream_t>(stream));
@@ -208,13 +208,52 @@ int dqq_qcqp_fwd_f64(const double* P, const double* q, const double* l_n, const 
     if (B > 0 && (P == nullptr || q == nullptr || l_n == nullptr || mu == nullptr || x == nullptr))
         return DQQ_E_NULLPTR;
     const bool keep = p_layout == DQQ_P_AUTO && dqq::fwd_diag_supported(N);
-    dqq::FwdArgs a{P,     q,       l_n, mu, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0, p_layout,
+    dqq::FwdArgs a{P,     q,       l_n, mu, nullptr, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0, p_layout,
                    iters, nullptr, keep ? pdiag_out : nullptr, keep ? diag_flags_out : nullptr, nullptr, 0};
     if (!keep && diag_flags_out != nullptr && B > 0) {
         hipError_t e = hipMemsetAsync(diag_flags_out, 0, (size_t)B, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return (int)e;
     }
     return fwd_dispatch(1, a, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+// Box QP (kind 2) and signed box QP (kind 3) share the forward plumbing: v == nullptr selects the box QP.
+static int box_fwd(const double* P, const double* q, const double* l_min, const double* l_max, const double* v,
+                   bool is_signed, double* x, int64_t B, int N, double eps, double mu_prox, int max_iter,
+                   int adaptive_rho, int p_layout, int* iters, double* pdiag_out, unsigned char* diag_flags_out,
+                   void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (int rc = check_common(B, N, p_layout, false)) return rc;
+    if (B > 0 && (P == nullptr || q == nullptr || l_min == nullptr || l_max == nullptr || x == nullptr ||
+                  (is_signed && v == nullptr)))
+        return DQQ_E_NULLPTR;
+    const bool keep = p_layout == DQQ_P_AUTO && dqq::fwd_diag_supported(N);
+    dqq::FwdArgs a{P,        q,     l_min,   l_max, v, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0,
+                   p_layout, iters, nullptr, keep ? pdiag_out : nullptr, keep ? diag_flags_out : nullptr, nullptr, 0};
+    if (!keep && diag_flags_out != nullptr && B > 0) {
+        hipError_t e = hipMemsetAsync(diag_flags_out, 0, (size_t)B, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return (int)e;
+    }
+    return fwd_dispatch(is_signed ? dqq::kKindSignedBox : dqq::kKindBox, a, workspace, workspace_bytes,
+                        static_cast<hipStream_t>(stream));
+}
+
+int dqq_boxqp_fwd_f64(const double* P, const double* q, const double* l_min, const double* l_max, double* x, int64_t B,
+                      int N, double eps, double mu_prox, int max_iter, int adaptive_rho, int p_layout, int* iters,
+                      double* pdiag_out, unsigned char* diag_flags_out, void* workspace, size_t workspace_bytes,
+                      void* stream)
+{
+    return box_fwd(P, q, l_min, l_max, nullptr, false, x, B, N, eps, mu_prox, max_iter, adaptive_rho, p_layout, iters,
+                   pdiag_out, diag_flags_out, workspace, workspace_bytes, stream);
+}
+
+int dqq_signedboxqp_fwd_f64(const double* P, const double* q, const double* l_min, const double* l_max,
+                            const double* v, double* x, int64_t B, int N, double eps, double mu_prox, int max_iter,
+                            int adaptive_rho, int p_layout, int* iters, double* pdiag_out,
+                            unsigned char* diag_flags_out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    return box_fwd(P, q, l_min, l_max, v, true, x, B, N, eps, mu_prox, max_iter, adaptive_rho, p_layout, iters,
+                   pdiag_out, diag_flags_out, workspace, workspace_bytes, stream);
 }
 
 int dqq_qp_bwd_f64(const double* P, const double* q, const double* x, const double* grad_x, double* grad_P,

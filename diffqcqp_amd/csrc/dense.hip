@@ -31,7 +31,8 @@ static DQQ_D void worklist_release(int* ws, int lane, long count, int nwaves)
 template <int KIND>
 __global__ __launch_bounds__(256) void fwd_dense_kernel(const double* __restrict__ P, const double* __restrict__ q,
                                                         const double* __restrict__ l_n,
-                                                        const double* __restrict__ mu_c, double* __restrict__ x, long B,
+                                                        const double* __restrict__ mu_c,
+                                                        const double* __restrict__ v_sign, double* __restrict__ x, long B,
                                                         int n, double eps, double mu, int max_iter, int adaptive,
                                                         int* __restrict__ iters, int* __restrict__ ws, int use_worklist,
                                                         int lds_per_wave)
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void fwd_dense_kernel(const double* __restrict
     const long nwaves = (long)gridDim.x * wpb;
     for (long w = (long)blockIdx.x * wpb + wave; w < count; w += nwaves) {
         const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
-        dense_fwd_problem<KIND>(P, q, l_n, mu_c, x, iters, prob, n, eps, mu, max_iter, adaptive, sw, lane);
+        dense_fwd_problem<KIND>(P, q, l_n, mu_c, v_sign, x, iters, prob, n, eps, mu, max_iter, adaptive, sw, lane);
     }
     if (use_worklist) worklist_release(ws, lane, count, (int)nwaves);
 }
@@ -110,27 +111,33 @@ static DenseGeom dense_geom(int lds_doubles, long B, bool use_worklist)
     return g;
 }
 
+template <int KIND>
+static hipError_t launch_fwd_wave(const FwdArgs& a, bool use_worklist, hipStream_t s)
+{
+    const DenseGeom g = dense_geom(dense_fwd_lds_doubles(a.N), a.B, use_worklist);
+    hipError_t e = set_lds(fwd_dense_kernel<KIND>, g.lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fwd_dense_kernel<KIND>, dim3(g.grid), dim3(64 * g.wpb), g.lds_bytes, s, a.P, a.q, a.l_n, a.mu, a.v,
+                       a.x, a.B, a.N, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0,
+                       g.lds_per_wave);
+    return hipGetLastError();
+}
+
 hipError_t launch_fwd_dense(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
-    if (fwd_lane_dense_supported(a.N) && g_lane_dense.load() != 0)
+    // the lane- and workgroup-per-problem kernels exist for QP / QCQP; the box kinds use the wave kernel
+    if (kind <= kKindQCQP && fwd_lane_dense_supported(a.N) && g_lane_dense.load() != 0)
         return launch_fwd_lane_dense(kind, a, use_worklist, s);
-    if (fwd_dense_block_supported(a.N) && g_dense_block.load() != 0)
+    if (kind <= kKindQCQP && fwd_dense_block_supported(a.N) && g_dense_block.load() != 0)
         return launch_fwd_dense_block(kind, a, use_worklist, s);
-    const DenseGeom g = dense_geom(dense_fwd_lds_doubles(a.N), a.B, use_worklist);
-    hipError_t e;
-    if (kind == 0) {
-        if ((e = set_lds(fwd_dense_kernel<0>, g.lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(fwd_dense_kernel<0>, dim3(g.grid), dim3(64 * g.wpb), g.lds_bytes, s, a.P, a.q, a.l_n, a.mu,
-                           a.x, a.B, a.N, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws,
-                           use_worklist ? 1 : 0, g.lds_per_wave);
-    } else {
-        if ((e = set_lds(fwd_dense_kernel<1>, g.lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(fwd_dense_kernel<1>, dim3(g.grid), dim3(64 * g.wpb), g.lds_bytes, s, a.P, a.q, a.l_n, a.mu,
-                           a.x, a.B, a.N, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws,
-                           use_worklist ? 1 : 0, g.lds_per_wave);
+    switch (kind) {
+    case 0: return launch_fwd_wave<0>(a, use_worklist, s);
+    case 1: return launch_fwd_wave<1>(a, use_worklist, s);
+    case 2: return launch_fwd_wave<2>(a, use_worklist, s);
+    case 3: return launch_fwd_wave<3>(a, use_worklist, s);
+    default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
 
 template <int KIND, int T>

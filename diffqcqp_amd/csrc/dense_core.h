@@ -106,12 +106,13 @@ constexpr int dense_bwd_lds_doubles(int kind, int n)
            (dense_bwd_rows(kind, n) + 3) / 2 + 1; // + perm ints
 }
 
-// One problem, forward: Solver::solveQP (KIND 0) / solveQCQP (KIND 1) on the dense P of problem
-// `prob`, executed by one wave.  smem: dense_fwd_lds_doubles(n) doubles of wave-private LDS.
+// One problem, forward: Solver::solveQP (KIND 0) / solveQCQP (KIND 1) / solveBoxQP (KIND 2, Solver.cpp:198-261;
+// l_n = l_min, mu_c = l_max per coordinate) / solveSignedBoxQP (KIND 3, :374-439, + v) on the dense P of
+// problem `prob`, executed by one wave.  smem: dense_fwd_lds_doubles(n) doubles of wave-private LDS.
 template <int KIND>
 static DQQ_D void dense_fwd_problem(const double* __restrict__ P, const double* __restrict__ q,
                                     const double* __restrict__ l_n, const double* __restrict__ mu_c,
-                                    double* __restrict__ x, int* __restrict__ iters, long prob, int n, double eps,
+                                    const double* __restrict__ v_sign, double* __restrict__ x, int* __restrict__ iters, long prob, int n, double eps,
                                     double mu, int max_iter, int adaptive, double* smem, int lane)
 {
 #pragma clang fp contract(off)
@@ -126,7 +127,8 @@ static DQQ_D void dense_fwd_problem(const double* __restrict__ P, const double* 
     DQQ_SYNC();
 
     // ---- power_iteration, Solver.cpp:46-59
-    const int pi_steps = (KIND == 0) ? 10 : 100;
+    constexpr bool QP_LIKE = (KIND != 1);
+    const int pi_steps = QP_LIKE ? 10 : 100;
     double v = 1 / sqrt((double)n);
     if (act) va[lane] = v;
     DQQ_SYNC();
@@ -166,6 +168,12 @@ static DQQ_D void dense_fwd_problem(const double* __restrict__ P, const double* 
     const double qi = act ? q[prob * n + lane] : 0.0;
     double rad = 0.0;
     if (KIND == 1) rad = act ? l_n[prob * (n / 2) + lane / 2] * mu_c[prob * (n / 2) + lane / 2] : 0.0;
+    double blo = 0.0, bhi = 0.0, bsg = 0.0;
+    if (KIND >= 2 && act) {
+        blo = l_n[prob * n + lane];
+        bhi = mu_c[prob * n + lane];
+        if (KIND == 3) { const double vv = v_sign[prob * n + lane]; bsg = (double)((vv > 0) - (vv < 0)); } // :395
+    }
     double qp = qi, l2 = 0.0, l2p = 0.0, u = 0.0;
     int rho_up = 0, cpt = 0, it_done = 0;
     for (int it = 0; it < max_iter; ++it) {
@@ -177,6 +185,14 @@ static DQQ_D void dense_fwd_problem(const double* __restrict__ P, const double* 
         double z = kAlpha * l + (1 - kAlpha) * l2 + u / rho;         // :82 / :541
         if (KIND == 0) {
             z = z < 0 ? 0 : z;
+        } else if (KIND >= 2) {
+            z = z < blo ? blo : z;                                   // cwiseMax(l_min), :219 / :396
+            z = bhi < z ? bhi : z;                                   // cwiseMin(l_max), :220 / :397
+            if (KIND == 3) {                                         // v o min(v o l_2, 0), :398
+                double m = bsg * z;
+                m = 0 < m ? 0 : m;
+                z = bsg * m;
+            }
         } else {                                                     // prox_circle, :505-519
             const double other = partner<1>(z);
             const double a = (lane & 1) ? other : z, b = (lane & 1) ? z : other;
@@ -186,11 +202,11 @@ static DQQ_D void dense_fwd_problem(const double* __restrict__ P, const double* 
         l2 = z;
         u += rho * (kAlpha * l + (1 - kAlpha) * l2p - l2);           // :83 / :543
         double rd, rp;
-        if (KIND == 0) rd = fabs(rho * (l2 - l2p)); else rd = fabs(l2 - l2p); // :84-85 / :544-545
+        if (QP_LIKE) rd = fabs(rho * (l2 - l2p)); else rd = fabs(l2 - l2p); // :84-85 / :544-545
         rp = fabs(l2 - (kAlpha * l + (1 - kAlpha) * l2p));           // :86 / :546
         rd = LaneGroup<64>::max(act ? rd : 0.0);
         rp = LaneGroup<64>::max(act ? rp : 0.0);
-        const double res_dual = (KIND == 0) ? rd : rho * rd;
+        const double res_dual = QP_LIKE ? rd : rho * rd;
         const double res_prim = rp;
         l2p = l2;                                                    // :87 / :547
         bool stop = res_dual < eps;
@@ -209,7 +225,7 @@ static DQQ_D void dense_fwd_problem(const double* __restrict__ P, const double* 
                 if (cpt % 5 == 0) {
                     if (rho_up == -1) {
                         tau_inc = 1 + .8 * (tau_inc - 1);
-                        if (KIND == 0) tau_dec = 1 + .8 * (tau_dec - 1);
+                        if (QP_LIKE) tau_dec = 1 + .8 * (tau_dec - 1);
                     }
                     mdiag += rho * (tau_inc - 1);
                     rho *= tau_inc;
@@ -220,7 +236,7 @@ static DQQ_D void dense_fwd_problem(const double* __restrict__ P, const double* 
             } else if (res_dual > kMuThresh * res_prim) {            // :106 / :566
                 if (cpt % 5 == 0) {
                     if (rho_up == 1) {
-                        if (KIND == 0) tau_inc = 1 + .8 * (tau_inc - 1);
+                        if (QP_LIKE) tau_inc = 1 + .8 * (tau_inc - 1);
                         tau_dec = 1 + .8 * (tau_dec - 1);
                     }
                     mdiag += rho * (1. / tau_dec - 1);

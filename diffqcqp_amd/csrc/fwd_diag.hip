@@ -28,7 +28,8 @@ template <int KIND, int N, int LPP, int WPB, bool FUSE>
 __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __restrict__ P,
                                                             const double* __restrict__ q,
                                                             const double* __restrict__ l_n,
-                                                            const double* __restrict__ mu_c, double* __restrict__ x,
+                                                            const double* __restrict__ mu_c,
+                                                            const double* __restrict__ v_sign, double* __restrict__ x,
                                                             long B, double eps, double mu_prox, int max_iter,
                                                             int adaptive, int layout, int* __restrict__ iters,
                                                             int* __restrict__ ws, int* __restrict__ hint, int hint_gen,
@@ -54,6 +55,8 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
     const bool valid = pl < nvalid;
 
     double p[E], qv[E], xv[E], rad[E / 2];
+    constexpr int EB = (KIND >= 2) ? E : 1;
+    double lo[EB], hi[EB], sg[EB]; // box kinds: l_n = l_min, mu_c = l_max, per coordinate
 
     if (layout == DQQ_P_DIAG) {
         const double* pp = P + first * N + lane * E;
@@ -76,8 +79,8 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
                 __hip_atomic_store(hint, hint_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if constexpr (FUSE) {
                 for (int j = 0; j < nvalid; ++j)
-                    dense_fwd_problem<KIND>(P, q, l_n, mu_c, x, iters, first + j, N, eps, mu_prox, max_iter, adaptive,
-                                            sd, lane);
+                    dense_fwd_problem<KIND>(P, q, l_n, mu_c, v_sign, x, iters, first + j, N, eps, mu_prox, max_iter,
+                                            adaptive, sd, lane);
                 return;
             }
             int base = 0;
@@ -107,8 +110,25 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
 #pragma unroll
         for (int c = 0; c < E / 2; ++c) rad[c] = 0.0;
     }
+    if constexpr (KIND >= 2) {
+        const long bo = first * N + lane * E;
+#pragma unroll
+        for (int e = 0; e < E; e += 2) {
+            const double2 a = valid ? *reinterpret_cast<const double2*>(l_n + bo + e) : make_double2(0.0, 0.0);
+            const double2 b = valid ? *reinterpret_cast<const double2*>(mu_c + bo + e) : make_double2(0.0, 0.0);
+            lo[e] = a.x; lo[e + 1] = a.y;
+            hi[e] = b.x; hi[e + 1] = b.y;
+            sg[e] = sg[e + 1] = 0.0;
+            if (KIND == 3) {
+                const double2 c = valid ? *reinterpret_cast<const double2*>(v_sign + bo + e) : make_double2(0.0, 0.0);
+                sg[e] = (double)((c.x > 0) - (c.x < 0));       // cwiseSign, Solver.cpp:395
+                sg[e + 1] = (double)((c.y > 0) - (c.y < 0));
+            }
+        }
+    }
 
-    const int it = admm_fwd_diag<KIND, E, LaneGroup<LPP>>(p, qv, rad, N, eps, mu_prox, max_iter, adaptive, valid, xv);
+    const int it = admm_fwd_diag<KIND, E, LaneGroup<LPP>>(p, qv, rad, N, eps, mu_prox, max_iter, adaptive, valid, xv,
+                                                          lo, hi, sg);
 
     if (valid) {
         double* xx = x + first * N + lane * E;
@@ -133,7 +153,7 @@ static hipError_t launch_one(const FwdArgs& a, hipStream_t s)
     const long nblocks = (ntiles + WPB - 1) / WPB;
     if (nblocks == 0) return hipSuccess;
     hipLaunchKernelGGL((fwd_diag_kernel<KIND, N, LPP, WPB, FUSE>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q,
-                       a.l_n, a.mu, a.x, a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.layout, a.iters, a.ws, a.hint, a.hint_gen,
+                       a.l_n, a.mu, a.v, a.x, a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.layout, a.iters, a.ws, a.hint, a.hint_gen,
                        a.pdiag_out, a.flags_out);
     return hipGetLastError();
 }
@@ -211,11 +231,17 @@ hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fus
                       (fuse_opt < 0 ? fwd_diag_fuses_fallback(a.N, a.B) : fuse_opt != 0);
     if (needs_fallback) *needs_fallback = (a.layout == DQQ_P_AUTO) && !fuse;
     hipError_t e = hipErrorInvalidValue;
-    bool found = kind == 0 ? launch_kind<0>(a, lpp, wpb, fuse, s, e) : launch_kind<1>(a, lpp, wpb, fuse, s, e);
-    if (!found) {
-        lpp = fwd_diag_default_lpp(a.N, a.B);
-        found = kind == 0 ? launch_kind<0>(a, lpp, wpb, fuse, s, e) : launch_kind<1>(a, lpp, wpb, fuse, s, e);
-    }
+    auto dispatch = [&](int l) {
+        switch (kind) {
+        case 0: return launch_kind<0>(a, l, wpb, fuse, s, e);
+        case 1: return launch_kind<1>(a, l, wpb, fuse, s, e);
+        case 2: return launch_kind<2>(a, l, wpb, fuse, s, e);
+        case 3: return launch_kind<3>(a, l, wpb, fuse, s, e);
+        default: return false;
+        }
+    };
+    bool found = dispatch(lpp);
+    if (!found) found = dispatch(fwd_diag_default_lpp(a.N, a.B));
     return found ? e : hipErrorInvalidValue;
 }
 

@@ -18,8 +18,9 @@ constexpr int kWsEntries = 4;
 struct FwdArgs {
     const double* P;
     const double* q;
-    const double* l_n; // QCQP only
-    const double* mu;  // QCQP only
+    const double* l_n; // QCQP: (B,N/2) normal forces; box kinds: (B,N) l_min
+    const double* mu;  // QCQP: (B,N/2) friction coefficients; box kinds: (B,N) l_max
+    const double* v;   // signed box QP only: (B,N)
     double* x;
     long B;
     int N;
@@ -62,6 +63,9 @@ struct BwdArgs {
 // the batch is too small to want more waves per SIMD anyway.
 constexpr bool fwd_diag_fuses(int N) { return N <= 16; }
 constexpr bool bwd_diag_fuses(int N) { return N <= 8; }
+
+// kind: 0 QP, 1 QCQP, 2 box QP, 3 signed box QP (forward only)
+constexpr int kKindQP = 0, kKindQCQP = 1, kKindBox = 2, kKindSignedBox = 3;
 
 // diagonal fast paths (fwd_diag.hip, bwd_diag.hip)
 bool fwd_diag_supported(int N);

@@ -115,6 +115,32 @@ def qcqp_forward(P, q, l_n, mu, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, 
     return (x, iters) if return_iters else x
 
 
+def boxqp_forward(P, q, l_min, l_max, eps, max_iter, v=None, mu_prox=1e-7, adaptive_rho=True, layout=_capi.P_AUTO,
+                  return_iters=False, out=None, cache=None):
+    """Batched box QP solve, l_min <= x <= l_max (reference qcqp.py:56-65); with `v` the signed box QP,
+    additionally sign(v_i) x_i <= 0 (reference qcqp.py:99-108)."""
+    B, N, pshape = _dims(P, q, layout)
+    P, q = _prep(P, "P", pshape), _prep(q, "q", (B, N, 1))
+    l_min, l_max = _prep(l_min, "l_min", (B, N, 1)), _prep(l_max, "l_max", (B, N, 1))
+    x = out if out is not None else torch.empty((B, N, 1), dtype=torch.float64, device=q.device)
+    iters = torch.empty(B, dtype=torch.int32, device=q.device) if return_iters else None
+    stream = _raw_stream(q.device.index)
+    ws = _workspace(q.device, B, stream)
+    with _device_guard(q.device):
+        pd, fl = cache if cache is not None else (None, None)
+        tail = (B, N, float(eps), float(mu_prox), int(max_iter), int(bool(adaptive_rho)), layout, _ptr(iters), _ptr(pd),
+                _ptr(fl), _ptr(ws), ws.numel() * 4, stream)
+        if v is None:
+            what = "dqq_boxqp_fwd_f64"
+            rc = _capi.lib().dqq_boxqp_fwd_f64(_ptr(P), _ptr(q), _ptr(l_min), _ptr(l_max), _ptr(x), *tail)
+        else:
+            what = "dqq_signedboxqp_fwd_f64"
+            v = _prep(v, "v", (B, N, 1))
+            rc = _capi.lib().dqq_signedboxqp_fwd_f64(_ptr(P), _ptr(q), _ptr(l_min), _ptr(l_max), _ptr(v), _ptr(x), *tail)
+    _capi.check(rc, what)
+    return (x, iters) if return_iters else x
+
+
 def qp_backward(P, q, x, grad_x, need_P=True, need_q=True, layout=_capi.P_AUTO, return_steps=False, out=None,
                 epsilon=1e-10, cache=None):
     """Implicit-function backward of the QP (reference qcqp.py:36-52). -> (grad_P|None, grad_q|None)"""

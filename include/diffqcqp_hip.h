@@ -14,6 +14,7 @@
  *     for the duration of the stream-ordered work); tensors are contiguous and
  *     batch-major exactly as torch lays them out:
  *         P (B,N,N)   q, x, grad_x, grad_q (B,N,1)   l_n, mu, grad_l_n, grad_mu (B,N/2,1)
+ *         l_min, l_max, v, grad_l_min, grad_l_max (B,N,1)
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL =
  *     the default stream) and the call returns without synchronising;
  *   - return value: 0 on success, <0 for an invalid argument (DQQ_E_*), >0 a
@@ -108,6 +109,25 @@ int dqq_qcqp_bwd_f64(const double* P, const double* q, const double* l_n, const 
                      double* gamma, double* dgamma, int64_t B, int N, double epsilon, int p_layout,
                      int* ir_steps, const double* pdiag, const unsigned char* diag_flags, void* workspace,
                      size_t workspace_bytes, void* stream);
+
+/* ---- the box-constrained members of the same solver family ------------------
+ *
+ * Replaces the loop qcqp.py:60-62 (BoxQPFn2.forward -> diffqcqp.solveBoxQP, pybindings.cpp:32-37 ->
+ * Solver::solveBoxQP, Solver.cpp:198-261): min 1/2 x'Px + q'x, l_min <= x <= l_max.
+ * l_min, l_max: (B,N,1).  Same loop as the QP with the projection of Solver.cpp:219-220. */
+int dqq_boxqp_fwd_f64(const double* P, const double* q, const double* l_min, const double* l_max, double* x,
+                      int64_t B, int N, double eps, double mu_prox, int max_iter, int adaptive_rho, int p_layout,
+                      int* iters, double* pdiag_out, unsigned char* diag_flags_out, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* Replaces the loop qcqp.py:103-105 (SignedBoxQPFn2.forward -> diffqcqp.solveSignedBoxQP,
+ * pybindings.cpp:47-52 -> Solver::solveSignedBoxQP, Solver.cpp:374-439): the box QP with the extra
+ * constraint sign(v_i) x_i <= 0 (projection of Solver.cpp:395-398).  v: (B,N,1), raw (its sign is taken
+ * inside).  The reference has no backward for this problem (qcqp.py:111 "not implemented"). */
+int dqq_signedboxqp_fwd_f64(const double* P, const double* q, const double* l_min, const double* l_max,
+                            const double* v, double* x, int64_t B, int N, double eps, double mu_prox,
+                            int max_iter, int adaptive_rho, int p_layout, int* iters, double* pdiag_out,
+                            unsigned char* diag_flags_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Tuning knobs (process-wide, read at launch time).  Unknown name -> DQQ_E_BAD_OPTION.
  *   "fwd_lpp"        lanes per problem of the diagonal forward kernel (0 = built-in choice from B)

@@ -415,6 +415,50 @@ def test_bad_inputs_terminate_and_poison_only_their_own_problem(oracle, ops):
     assert int(st.max()) <= 10
 
 
+# ---------------------------------------------------------------- box QP / signed box QP
+def _box_fwd(O, ops, kind, d, layout=0, eps=1e-7, max_iter=1000):
+    v = d.get("v")
+    xo, ito = O.boxqp_fwd_batch(d["P"].numpy(), d["q"].numpy(), d["l_min"].numpy(), d["l_max"].numpy(), eps, max_iter,
+                                v=None if v is None else v.numpy(), nthreads=8)
+    g = dev(d)
+    xh, ith = ops.boxqp_forward(g["P"], g["q"], g["l_min"], g["l_max"], eps, max_iter, v=g.get("v"), layout=layout,
+                                return_iters=True)
+    return xo, ito, xh, ith
+
+
+@pytest.mark.parametrize("kind", ["box", "sbox"])
+@pytest.mark.parametrize("N,B", [(2, 130), (4, 500), (8, 2051), (16, 301), (32, 131), (64, 37)])
+def test_box_forward_diag_fast_path(oracle, ops, kind, N, B):
+    d = make_problem(kind, B, N, 800 + N)
+    xo, ito, xh, ith = _box_fwd(oracle, ops, kind, d)
+    check_forward(xh, ith, xo, ito)
+    lo, hi = d["l_min"].numpy(), d["l_max"].numpy()
+    assert (npy(xh) >= lo).all() and (npy(xh) <= hi).all()
+    if kind == "sbox":
+        assert (np.sign(d["v"].numpy()) * npy(xh) <= 0).all()
+
+
+@pytest.mark.parametrize("kind", ["box", "sbox"])
+@pytest.mark.parametrize("N,B,structure", [(8, 200, "dense"), (5, 60, "dense"), (16, 40, "dense"), (32, 12, "dense"),
+                                           (8, 300, "mixed"), (32, 40, "mixed")])
+def test_box_forward_dense_and_mixed(oracle, ops, kind, N, B, structure):
+    from diffqcqp_amd import _capi
+    d = make_problem(kind, B, N, 820 + N, structure)
+    for layout in ((_capi.P_AUTO,) if structure == "mixed" else (_capi.P_AUTO, _capi.P_DENSE)):
+        xo, ito, xh, ith = _box_fwd(oracle, ops, kind, d, layout=layout)
+        check_forward(xh, ith, xo, ito, min_match=0.99)
+
+
+def test_box_forward_reduces_to_qp(oracle, ops):
+    """l_min = 0, l_max = huge: the box kernel follows the QP kernel's trajectory."""
+    d = make_problem("qp", 777, 8, 840)
+    g = dev(d)
+    x0, it0 = ops.qp_forward(g["P"], g["q"], 1e-7, 1000, return_iters=True)
+    x1, it1 = ops.boxqp_forward(g["P"], g["q"], torch.zeros_like(g["q"]), torch.full_like(g["q"], 1e300), 1e-7, 1000,
+                                return_iters=True)
+    assert torch.equal(it0, it1) and (x0 - x1).abs().max() < 1e-12
+
+
 # ---------------------------------------------------------------- golden fixtures
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))), ids=os.path.basename)
 def test_hip_reproduces_golden(ops, path):
