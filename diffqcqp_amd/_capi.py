@@ -40,6 +40,8 @@ SIGNATURES = {
     "dqq_boxqp_fwd_f64": ([_vp, _vp, _vp, _vp, _vp, _i64, _i, _d, _d, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp], _i),
     "dqq_signedboxqp_fwd_f64": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _d, _d, _i, _i, _i, _vp, _vp, _vp, _vp, _sz,
                                  _vp], _i),
+    "dqq_boxqp_bwd_f64": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _d, _i, _vp, _vp, _vp,
+                           _vp, _sz, _vp], _i),
     "dqq_set_option": ([ctypes.c_char_p, _i], _i),
     "dqq_get_option": ([ctypes.c_char_p, ctypes.POINTER(_i)], _i),
     "dqq_version": ([], ctypes.c_char_p),

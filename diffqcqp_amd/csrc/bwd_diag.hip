@@ -27,7 +27,7 @@
 namespace dqq {
 
 template <int KIND, int N, int WPB, bool FUSE>
-__global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : 4) : 1)) void bwd_diag_kernel(
+__global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : (KIND == 1 ? 4 : 2)) : 1)) void bwd_diag_kernel(
     const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ l_n,
     const double* __restrict__ mu_c, const double* __restrict__ x, const double* __restrict__ grad_x,
     double* __restrict__ grad_P, double* __restrict__ grad_q, double* __restrict__ grad_l_n,
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : 4) : 1)) void bw
     constexpr int HL = N / 2;          // lanes per problem
     constexpr int T = 64 / HL;         // problems per wave tile (T*N == 128)
     constexpr int NC = N / 2;          // contacts per problem
-    constexpr int RS = (KIND == 0) ? N : N + NC; // residual entries per problem
+    constexpr int RS = (KIND == 0) ? N : (KIND == 2 ? 3 * N : N + NC); // residual entries per problem
     static_assert(N >= 2 && (N & (N - 1)) == 0 && N <= 128, "N must be a power of two");
     __shared__ __attribute__((aligned(16))) double s_pd[WPB][128], s_dl[WPB][128], s_x[WPB][128], s_rs[WPB][T * RS];
     // FUSE (small N, small batches): a non-diagonal tile is handled right here by the general routine.  The
@@ -122,6 +122,78 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : 4) : 1)) void bw
         }
         dl0 = c0.dl();
         dl1 = c1.dl();
+    } else if (KIND == 2) {
+        // box QP: l_n = l_min, mu_c = l_max (per coordinate); two refinement loops (dual recovery, then the
+        // derivative system), each with its own problem-wide exit
+        const double2 lov = valid ? *reinterpret_cast<const double2*>(l_n + co) : zero2;
+        const double2 hiv = valid ? *reinterpret_cast<const double2*>(mu_c + co) : zero2;
+        BoxCoord c0, c1;
+        c0.setup_dual(pv.x, qv.x, xv.x, lov.x, hiv.x, dual_eps);
+        c1.setup_dual(pv.y, qv.y, xv.y, lov.y, hiv.y, dual_eps);
+        int steps_dual = 0;
+        for (int it = 0; it < kIrMaxIter; ++it) {
+            if (!done) {
+                double d0[3], d1[3];
+                c0.step_dual(d0);
+                c1.step_dual(d1);
+                rs[pl * RS + 4 * j] = d0[0]; rs[pl * RS + 4 * j + 1] = d0[1];
+                rs[pl * RS + 4 * j + 2] = d1[0]; rs[pl * RS + 4 * j + 3] = d1[1];
+            }
+            wave_lds_fence();
+            if (!done) {
+                double s = 0.0;
+                for (int i = 0; i < 2 * N; ++i) s += rs[pl * RS + i]; // multipliers, coordinate by coordinate
+                steps_dual = it + 1;
+                if (ctl.update(sqrt(s))) done = true;
+            }
+            wave_lds_fence();
+            if (__all(done)) break;
+        }
+        c0.setup_derivative(pv.x, gv.x);
+        c1.setup_derivative(pv.y, gv.y);
+        ctl.init();
+        done = !valid;
+        for (int it = 0; it < kIrMaxIter; ++it) {
+            if (!done) {
+                double d0[3], d1[3];
+                c0.step_derivative(d0);
+                c1.step_derivative(d1);
+                rs[pl * RS + 4 * j] = d0[0]; rs[pl * RS + 4 * j + 1] = d0[1];
+                rs[pl * RS + 4 * j + 2] = d1[0]; rs[pl * RS + 4 * j + 3] = d1[1];
+                rs[pl * RS + 2 * N + 2 * j] = d0[2];
+                rs[pl * RS + 2 * N + 2 * j + 1] = d1[2];
+            }
+            wave_lds_fence();
+            if (!done) {
+                double s = 0.0;
+                for (int i = 0; i < RS; ++i) s += rs[pl * RS + i]; // multipliers, then the l entries
+                steps = it + 1;
+                if (ctl.update(sqrt(s))) done = true;
+            }
+            wave_lds_fence();
+            if (__all(done)) break;
+        }
+        dl0 = c0.dl();
+        dl1 = c1.dl();
+        if (valid) {
+            // BoxQPFn2.backward as intended (qcqp.py:91-93; signs: tests/test_oracle.py)
+            if (grad_l_n != nullptr)
+                *reinterpret_cast<double2*>(grad_l_n + co) =
+                    make_double2(-(c0.dgamma_lo() * c0.gamma_lo), -(c1.dgamma_lo() * c1.gamma_lo));
+            if (grad_mu != nullptr)
+                *reinterpret_cast<double2*>(grad_mu + co) =
+                    make_double2(c0.dgamma_hi() * c0.gamma_hi, c1.dgamma_hi() * c1.gamma_hi);
+            const long go = (first + pl) * 2 * N + 2 * j; // gamma / dgamma: (B, 2N) = [lower (N) | upper (N)]
+            if (gamma_out != nullptr) {
+                *reinterpret_cast<double2*>(gamma_out + go) = make_double2(c0.gamma_lo, c1.gamma_lo);
+                *reinterpret_cast<double2*>(gamma_out + go + N) = make_double2(c0.gamma_hi, c1.gamma_hi);
+            }
+            if (dgamma_out != nullptr) {
+                *reinterpret_cast<double2*>(dgamma_out + go) = make_double2(c0.dgamma_lo(), c1.dgamma_lo());
+                *reinterpret_cast<double2*>(dgamma_out + go + N) = make_double2(c0.dgamma_hi(), c1.dgamma_hi());
+            }
+            if (ir_steps != nullptr && j == 0) ir_steps[2 * (first + pl)] = steps_dual;
+        }
     } else {
         const long cc = first * NC + lane;
         const double ln = valid ? l_n[cc] : 1.0, mc = valid ? mu_c[cc] : 1.0;
@@ -157,7 +229,7 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : 4) : 1)) void bw
     }
     if (valid) {
         if (grad_q != nullptr) *reinterpret_cast<double2*>(grad_q + co) = make_double2(-dl0, -dl1); // qcqp.py:51/176
-        if (ir_steps != nullptr && j == 0) ir_steps[first + pl] = steps;
+        if (ir_steps != nullptr && j == 0) ir_steps[KIND == 2 ? 2 * (first + pl) + 1 : first + pl] = steps;
     }
     if (grad_P == nullptr) return;
 
@@ -202,7 +274,7 @@ static hipError_t launch_one(const BwdArgs& a, hipStream_t s)
 template <int KIND, int N>
 static hipError_t launch_wpb(const BwdArgs& a, int wpb, bool fuse, hipStream_t s)
 {
-    if constexpr (bwd_diag_fuses(N)) {
+    if constexpr (bwd_diag_fuses(N) && KIND != 2) {
         if (fuse) return wpb == 1 ? launch_one<KIND, N, 1, true>(a, s) : launch_one<KIND, N, 4, true>(a, s);
     }
     return wpb == 1 ? launch_one<KIND, N, 1, false>(a, s) : launch_one<KIND, N, 4, false>(a, s);
@@ -230,9 +302,11 @@ static hipError_t launch_kind(const BwdArgs& a, int wpb, bool fuse, hipStream_t 
 hipError_t launch_bwd_diag(int kind, const BwdArgs& a, int wpb, int fuse_opt, hipStream_t s, bool* needs_fallback)
 {
     if (wpb != 1 && wpb != 4) wpb = 4;
-    const bool fuse = a.layout != DQQ_P_DIAG && bwd_diag_fuses(a.N) &&
+    // the box QP's general routine needs 3N rows of LDS: never fused, always queued for the dense kernel
+    const bool fuse = a.layout != DQQ_P_DIAG && bwd_diag_fuses(a.N) && kind != kKindBox &&
                       (fuse_opt < 0 ? bwd_diag_fuses_fallback(a.N, a.B) : fuse_opt != 0);
     if (needs_fallback) *needs_fallback = (a.layout == DQQ_P_AUTO) && !fuse;
+    if (kind == kKindBox) return launch_kind<2>(a, wpb, false, s);
     return kind == 0 ? launch_kind<0>(a, wpb, fuse, s) : launch_kind<1>(a, wpb, fuse, s);
 }
 

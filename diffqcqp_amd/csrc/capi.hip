@@ -162,7 +162,7 @@ static int bwd_dispatch(int kind, dqq::BwdArgs& a, void* workspace, size_t works
     if (a.B == 0) return 0;
     (void)hipGetLastError();
     const bool fast_ok = dqq::bwd_diag_supported(a.N);
-    const bool dense_ok = a.N <= dqq::dense_max_n(kind == 0 ? 0 : 2);
+    const bool dense_ok = a.N <= dqq::dense_max_n(kind == 0 ? 0 : (kind == dqq::kKindBox ? 3 : 2));
     hipError_t e;
     if (a.layout == DQQ_P_DIAG) {
         if (!fast_ok) return DQQ_E_UNSUPPORTED_N;
@@ -280,6 +280,21 @@ int dqq_qcqp_bwd_f64(const double* P, const double* q, const double* l_n, const 
     dqq::BwdArgs a{P,     q,          l_n,   mu,     x,       grad_x, grad_P,  grad_q,   grad_l_n, grad_mu,
                    pdiag, diag_flags, gamma, dgamma, (long)B, N,      epsilon, p_layout, ir_steps, nullptr};
     return bwd_dispatch(1, a, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, const double* l_max, const double* x,
+                      const double* grad_x, double* grad_P, double* grad_q, double* grad_l_min, double* grad_l_max,
+                      double* gamma, double* dgamma, int64_t B, int N, double epsilon, int p_layout, int* ir_steps,
+                      const double* pdiag, const unsigned char* diag_flags, void* workspace, size_t workspace_bytes,
+                      void* stream)
+{
+    if (int rc = check_common(B, N, p_layout, false)) return rc;
+    if (B > 0 && (P == nullptr || q == nullptr || l_min == nullptr || l_max == nullptr || x == nullptr ||
+                  grad_x == nullptr))
+        return DQQ_E_NULLPTR;
+    dqq::BwdArgs a{P,     q,          l_min, l_max,  x,       grad_x, grad_P,  grad_q,   grad_l_min, grad_l_max,
+                   pdiag, diag_flags, gamma, dgamma, (long)B, N,      epsilon, p_layout, ir_steps,   nullptr};
+    return bwd_dispatch(dqq::kKindBox, a, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 } // extern "C"

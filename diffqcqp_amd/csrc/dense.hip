@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void bwd_dense_kernel(
 int dense_max_n(int kind)
 {
     if (kind == 2) return (kDenseMaxRows * 2) / 3; // n + n/2 <= 64
+    if (kind == 3) return kDenseMaxRows / 3;       // box QP backward: 3n <= 64
     return kDenseMaxRows;
 }
 
@@ -179,6 +180,7 @@ hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipSt
     if (a.B == 0) return hipSuccess;
     if (bwd_dense_block_supported(kind, a.N) && g_dense_block.load() != 0)
         return launch_bwd_dense_block(kind, a, use_worklist, s);
+    if (kind == kKindBox) return launch_bwd_kind<2>(a, use_worklist, s);
     return kind == 0 ? launch_bwd_kind<0>(a, use_worklist, s) : launch_bwd_kind<1>(a, use_worklist, s);
 }
 

@@ -99,7 +99,7 @@ static DQQ_D void load_matrix(double* dst, int ld, const double* __restrict__ sr
 
 
 constexpr int dense_fwd_lds_doubles(int n) { return 2 * n * (n | 1) + 2 * n + 2; }
-constexpr int dense_bwd_rows(int kind, int n) { return kind == 0 ? n : n + n / 2; }
+constexpr int dense_bwd_rows(int kind, int n) { return kind == 0 ? n : (kind == 2 ? 3 * n : n + n / 2); }
 constexpr int dense_bwd_lds_doubles(int kind, int n)
 {
     return 3 * dense_bwd_rows(kind, n) * (dense_bwd_rows(kind, n) | 1) + 5 * n + 4 * dense_bwd_rows(kind, n) + 2 +
@@ -266,16 +266,18 @@ static DQQ_D void dense_fwd_problem(const double* __restrict__ P, const double* 
 // returns entry i of the solution.  At is overwritten (Cholesky workspace).
 template <int T = 64>
 static DQQ_D double ir_wave(double* At, double* K, double* Kinv, const double* dd, double* va, double* vb, int m,
-                            int ld, int lane, int& steps)
+                            int ld, int lane, int& steps, int rows = -1)
 {
 #pragma clang fp contract(off)
+    // rows x m system matrix (rows = m unless given: the box QP's dual recovery is rectangular)
+    if (rows < 0) rows = m;
     const bool act = lane < m;
     double Ab = 0.0;
     if (act) {
-        for (int k = 0; k < m; ++k) Ab += At[k * ld + lane] * dd[k];          // A^T b, :19
+        for (int k = 0; k < rows; ++k) Ab += At[k * ld + lane] * dd[k];       // A^T b, :19
         for (int j = 0; j < m; ++j) {                                         // A^T A, :20
             double s = 0.0;
-            for (int k = 0; k < m; ++k) s += At[k * ld + lane] * At[k * ld + j];
+            for (int k = 0; k < rows; ++k) s += At[k * ld + lane] * At[k * ld + j];
             K[lane * ld + j] = s;
         }
         K[lane * ld + lane] += kMuIr;                                         // :21
@@ -310,6 +312,123 @@ static DQQ_D double ir_wave(double* At, double* K, double* Kinv, const double* d
     return xs;
 }
 
+// Box QP backward, one problem per team: pybindings.cpp:39-45 -> Solver::dualFromPrimalBoxQP
+// (Solver.cpp:263-308), Solver::solveDerivativesBoxQP (:310-371), two runs of iterative_refinement (:15-44),
+// and the gradient assembly BoxQPFn2.backward intends (qcqp.py:87-93; signs as settled by finite
+// differences, tests/test_oracle.py): grad_P = -dl x^T, grad_q = -dl, grad_l_min = -dgamma_lo o gamma_lo,
+// grad_l_max = +dgamma_hi o gamma_hi.  Multipliers are ordered as the reference orders them: coordinate by
+// coordinate, the lower one (if l_i - l_min_i <= eps) before the upper one (if l_i - l_max_i >= -eps).
+// smem: dense_bwd_lds_doubles(2, n).  ir_steps: two ints per problem (dual recovery, derivative system).
+template <int T>
+static DQQ_D void dense_bwd_box_problem(const double* __restrict__ P, const double* __restrict__ q,
+                                        const double* __restrict__ l_min, const double* __restrict__ l_max,
+                                        const double* __restrict__ x, const double* __restrict__ grad_x,
+                                        double* __restrict__ grad_P, double* __restrict__ grad_q,
+                                        double* __restrict__ grad_l_min, double* __restrict__ grad_l_max,
+                                        double* __restrict__ gamma_out, double* __restrict__ dgamma_out,
+                                        int* __restrict__ ir_steps, long prob, int n, double dual_eps, double* smem,
+                                        int lane)
+{
+#pragma clang fp contract(off)
+    const int mmax = 3 * n;
+    const int ld = mmax | 1;
+    double* At = smem;               // mmax*ld
+    double* K = At + mmax * ld;      // mmax*ld (holds P while a system is assembled)
+    double* Kinv = K + mmax * ld;    // mmax*ld
+    double* vx = Kinv + mmax * ld;   // n
+    double* vg = vx + n;             // n
+    double* vdd = vg + n;            // mmax: right-hand side
+    double* va = vdd + mmax;         // mmax
+    double* vb = va + mmax;          // mmax
+    double* vgam = vb + mmax;        // 2n: gamma, scattered (lower | upper)
+    double* vdg = vgam + 2 * n;      // 2n: dgamma, scattered
+    double* vdl = vdg + 2 * n;       // n
+    int* nnl = reinterpret_cast<int*>(vdl + n); // 2n ints: not_null list
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const double* Pg = P + prob * (long)n * n;
+    double* Pl = K;
+    load_matrix<T>(Pl, ld, Pg, n, lane);
+    const bool actn = lane < n;
+    const double xi = actn ? x[prob * n + lane] : 0.0;
+    const double gi = actn ? grad_x[prob * n + lane] : 0.0;
+    const double qi = actn ? q[prob * n + lane] : 0.0;
+    const double lo = actn ? l_min[prob * n + lane] : 0.0, hi = actn ? l_max[prob * n + lane] : 0.0;
+    if (actn) { vx[lane] = xi; vg[lane] = gi; vgam[lane] = 0.0; vgam[n + lane] = 0.0; vdg[lane] = 0.0; vdg[n + lane] = 0.0; }
+    // not_null bookkeeping, :268-283 / :315-327
+    const bool aL = actn && !(xi - lo > dual_eps);
+    const bool aU = actn && !(xi - hi < -dual_eps);
+    const unsigned long long mL = team_ballot<T>(aL), mU = team_ballot<T>(aU);
+    const int nn = __popcll(mL) + __popcll(mU);
+    const int posL = __popcll(mL & below) + __popcll(mU & below);
+    const int posU = posL + (aL ? 1 : 0);
+    if (aL) nnl[posL] = lane;
+    if (aU) nnl[posU] = n + lane;
+    DQQ_SYNC();
+    // ---- dualFromPrimalBoxQP: gamma_not_null = iterative_refinement(Id2, -P*l - q), :291-304
+    double rhs = 0.0;
+    if (actn) {
+        for (int j = 0; j < n; ++j) rhs += (-Pl[lane * ld + j]) * vx[j];
+        rhs = rhs - qi;
+    }
+    for (int idx = lane; idx < n * nn; idx += T) At[(idx / nn) * ld + idx % nn] = 0.0;   // Id2: n x nn
+    if (actn) vdd[lane] = rhs;
+    DQQ_SYNC();
+    if (aL) At[lane * ld + posL] = -1.0;
+    if (aU) At[lane * ld + posU] = 1.0;
+    DQQ_SYNC();
+    int steps_dual = 1, steps = 0; // nn == 0: the reference runs one loop body on empty vectors and leaves
+    if (nn > 0) {
+        const double gnn = ir_wave<T>(At, K, Kinv, vdd, va, vb, nn, ld, lane, steps_dual, n);
+        if (lane < nn) vgam[nnl[lane]] = gnn;
+    }
+    DQQ_SYNC();
+    // ---- solveDerivativesBoxQP, :341-369: A = [[0, B],[Id2, P]], B.row(j) = gamma_j * Id2.col(j)^T
+    const int m = nn + n;
+    load_matrix<T>(Pl, ld, Pg, n, lane); // the refinement above used K as workspace
+    DQQ_SYNC();
+    for (int idx = lane; idx < m * m; idx += T) {
+        const int rr = idx / m, cc = idx % m; // At[rr][cc] = A[cc][rr]: row = cc, col = rr
+        const int row = cc, col = rr;
+        double val = 0.0;
+        if (row < nn) {
+            if (col >= nn) {
+                const int id = nnl[row], i = col - nn;
+                const double s = (id < n) ? ((id == i) ? -1.0 : 0.0) : ((id - n == i) ? 1.0 : 0.0); // Id2(i, row)
+                val = vgam[id] * s;
+            }
+        } else {
+            const int i = row - nn;
+            if (col < nn) {
+                const int id = nnl[col];
+                val = (id < n) ? ((id == i) ? -1.0 : 0.0) : ((id - n == i) ? 1.0 : 0.0);
+            } else {
+                val = Pl[i * ld + (col - nn)];
+            }
+        }
+        At[rr * ld + cc] = val;
+    }
+    if (lane < m) vdd[lane] = (lane < nn) ? 0.0 : vg[lane - nn];            // :352-360
+    DQQ_SYNC();
+    const double bsol = ir_wave<T>(At, K, Kinv, vdd, va, vb, m, ld, lane, steps); // :362
+    if (lane < nn) vdg[nnl[lane]] = bsol;                                   // :363-366
+    else if (lane < m) vdl[lane - nn] = bsol;                               // :367-369
+    DQQ_SYNC();
+    if (actn) {
+        const double glo = vgam[lane], ghi = vgam[n + lane], dlo = vdg[lane], dhi = vdg[n + lane];
+        if (grad_q != nullptr) grad_q[prob * n + lane] = -vdl[lane];
+        if (grad_l_min != nullptr) grad_l_min[prob * n + lane] = -(dlo * glo);
+        if (grad_l_max != nullptr) grad_l_max[prob * n + lane] = dhi * ghi;
+        if (gamma_out != nullptr) { gamma_out[prob * 2 * n + lane] = glo; gamma_out[prob * 2 * n + n + lane] = ghi; }
+        if (dgamma_out != nullptr) { dgamma_out[prob * 2 * n + lane] = dlo; dgamma_out[prob * 2 * n + n + lane] = dhi; }
+    }
+    if (grad_P != nullptr) {
+        double* Gp = grad_P + prob * (long)n * n;
+        for (int idx = lane; idx < n * n; idx += T) Gp[idx] = -(vdl[idx / n] * vx[idx % n]);
+    }
+    if (ir_steps != nullptr && lane == 0) { ir_steps[2 * prob] = steps_dual; ir_steps[2 * prob + 1] = steps; }
+    DQQ_SYNC();
+}
+
 // One problem, backward: the composition of pybindings.cpp:24-30 (KIND 0) / :62-71 (KIND 1) plus the
 // gradient assembly of qcqp.py:48-51 / :173-180, executed by one wave.  smem: dense_bwd_lds_doubles(KIND,n).
 template <int KIND, int T = 64>
@@ -323,6 +442,11 @@ static DQQ_D void dense_bwd_problem(const double* __restrict__ P, const double* 
                                     int lane)
 {
 #pragma clang fp contract(off)
+    if constexpr (KIND == 2) { // box QP: l_n = l_min, mu_c = l_max, grad_l_n = grad_l_min, grad_mu = grad_l_max
+        dense_bwd_box_problem<T>(P, q, l_n, mu_c, x, grad_x, grad_P, grad_q, grad_l_n, grad_mu, gamma_out, dgamma_out,
+                                 ir_steps, prob, n, dual_eps, smem, lane);
+        return;
+    }
     const int nc = n / 2;
     const int mmax = (KIND == 0) ? n : n + nc;
     const int ld = mmax | 1;

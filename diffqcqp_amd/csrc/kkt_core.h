@@ -188,4 +188,138 @@ struct QcqpContact {
     static DQQ_HD double e2(double gamma, double l_n, double mu) { return 2 * gamma * l_n * mu * mu; }
 };
 
+// ------------------------------------------------------------------ box QP
+// Solver::iterative_refinement (Solver.cpp:15-44) restricted to one diagonal block of a permuted
+// block-diagonal system, in the reference's operation order (left-looking LLT, column-wise
+// solveInPlace(Identity), row-wise products accumulated from 0) -- the loops of the oracle's chol_inverse /
+// matvec with the exact zeros of the other blocks left out.  The block always has three slots; a slot whose
+// unknown does not exist carries a zero column of A_t and a zero right-hand side: it decouples into
+// K = mu_ir, A^T b = 0, x = 0, residual 0, and contributes only exact zeros to the sums of the live slots,
+// so no runtime indexing (scratch memory) is needed.  At is 3 x 3 (rows beyond the block's are zero).
+struct SmallIr {
+    double K[3][3], Kinv[3][3], Ab[3], KinvAb[3], xs[3];
+
+    DQQ_HD void setup(const double (&At)[3][3], const double (&b)[3])
+    {
+        double L[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            xs[i] = 0.0;
+            double s = 0.0;                                            // A^T b, :19
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s += At[k][i] * b[k];
+            Ab[i] = s;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {                              // A^T A, :20
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) t += At[k][i] * At[k][j];
+                K[i][j] = t;
+                L[i][j] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) K[i][i] += kMuIr;                  // :21
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {                                  // llt(), :23
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < k; ++j) s += L[k][j] * L[k][j];
+            double xk = K[k][k] - s;
+            xk = sqrt(xk);
+            L[k][k] = xk;
+#pragma unroll
+            for (int i = k + 1; i < 3; ++i) {
+                double t = 0.0;
+#pragma unroll
+                for (int j = 0; j < k; ++j) t += L[i][j] * L[k][j];
+                L[i][k] = (K[i][k] - t) / xk;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {                                  // solveInPlace(Identity), :22-23
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                double t = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+                for (int j = 0; j < i; ++j) t -= L[i][j] * Kinv[j][c];
+                Kinv[i][c] = t / L[i][i];
+            }
+#pragma unroll
+            for (int i = 2; i >= 0; --i) {
+                double t = Kinv[i][c];
+#pragma unroll
+                for (int j = i + 1; j < 3; ++j) t -= L[j][i] * Kinv[j][c];
+                Kinv[i][c] = t / L[i][i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {                                  // :27
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) s += Kinv[i][j] * Ab[j];
+            KinvAb[i] = s;
+        }
+    }
+    // one refinement step (:29-31); dsq[i] = squared residual entry of slot i
+    DQQ_HD void step(double (&dsq)[3])
+    {
+        double t[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) s += Kinv[i][j] * xs[j];
+            t[i] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xs[i] = kMuIr * t[i] + KinvAb[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) s += K[i][j] * xs[j];
+            const double d = s - Ab[i];
+            dsq[i] = d * d;
+        }
+    }
+};
+
+// One coordinate of a diagonal-P box QP: Solver::dualFromPrimalBoxQP (Solver.cpp:263-308) then
+// Solver::solveDerivativesBoxQP (:310-371).  Slots: 0 = lower multiplier (exists when l - l_min <= eps),
+// 1 = upper multiplier (exists when l - l_max >= -eps), 2 = dl -- the reference's order.  The two refinement
+// loops exit on problem-wide residual norms; the callers sum the squared entries returned here in the
+// reference's entry order (multipliers coordinate by coordinate, then the l entries).
+struct BoxCoord {
+    bool aL, aU;
+    double gamma_lo, gamma_hi;
+    SmallIr ir;
+
+    DQQ_HD void setup_dual(double p, double q, double x, double lo, double hi, double eps)
+    {
+        aL = !(x - lo > eps);                                          // :268-274
+        aU = !(x - hi < -eps);                                         // :275-282
+        // the coordinate's row of Id2 (:291-300): -1 in the lower multiplier's column, +1 in the upper one's
+        const double At[3][3] = {{aL ? -1.0 : 0.0, aU ? 1.0 : 0.0, 0.0}, {0, 0, 0}, {0, 0, 0}};
+        const double b[3] = {(-p) * x - q, 0.0, 0.0};                  // -P*l - q, :301
+        ir.setup(At, b);
+    }
+    DQQ_HD void step_dual(double (&dsq)[3]) { ir.step(dsq); }           // dsq[2] is always 0
+    DQQ_HD void setup_derivative(double p, double g)
+    {
+        gamma_lo = aL ? ir.xs[0] : 0.0;                                // :302-304
+        gamma_hi = aU ? ir.xs[1] : 0.0;
+        // A = [[0, B],[Id2, P]] (:341-350) restricted to (lower, upper, l); iterative_refinement gets A^T (:351)
+        const double sL = aL ? -1.0 : 0.0, sU = aU ? 1.0 : 0.0;
+        const double bL = gamma_lo * sL, bU = gamma_hi * sU;           // B.row(j) = gamma_j * Id2.col(j)^T
+        const double At[3][3] = {{0.0, 0.0, sL}, {0.0, 0.0, sU}, {bL, bU, p}};
+        const double b[3] = {0.0, 0.0, g};                             // :352-360
+        ir.setup(At, b);
+    }
+    DQQ_HD void step_derivative(double (&dsq)[3]) { ir.step(dsq); }
+    DQQ_HD double dl() const { return ir.xs[2]; }                       // :367-369
+    DQQ_HD double dgamma_lo() const { return aL ? ir.xs[0] : 0.0; }     // :363-366
+    DQQ_HD double dgamma_hi() const { return aU ? ir.xs[1] : 0.0; }
+};
+
 } // namespace dqq

@@ -193,3 +193,34 @@ def qcqp_backward(P, q, l_n, mu, x, grad_x, need=(True, True, True, True), layou
                                           layout, _ptr(steps), _ptr(pd), _ptr(fl), _ptr(ws), ws.numel() * 4, stream)
     _capi.check(rc, "dqq_qcqp_bwd_f64")
     return (gP, gq, gl, gm, steps) if return_steps else (gP, gq, gl, gm)
+
+
+def boxqp_backward(P, q, l_min, l_max, x, grad_x, need=(True, True, True, True), layout=_capi.P_AUTO,
+                   return_steps=False, out=None, duals=None, epsilon=1e-10, cache=None):
+    """Implicit-function backward of the box QP: what BoxQPFn2.backward (reference qcqp.py:67-94) spells out,
+    with the signs finite differences confirm.  -> (grad_P, grad_q, grad_l_min, grad_l_max), None where not
+    needed.  duals: optional pair of (B,2N) tensors that receive gamma and dgamma ([lower | upper]).
+    return_steps: also the (B,2) refinement step counts (dual recovery, derivative system)."""
+    B, N, pshape = _dims(P, q, layout)
+    P, q = _prep(P, "P", pshape), _prep(q, "q", (B, N, 1))
+    l_min, l_max = _prep(l_min, "l_min", (B, N, 1)), _prep(l_max, "l_max", (B, N, 1))
+    x, grad_x = _prep(x, "x", (B, N, 1)), _prep(grad_x, "grad_x", (B, N, 1))
+    dev = q.device
+    if out is not None:
+        gP, gq, glo, ghi = out
+    else:
+        gP = torch.empty(pshape, dtype=torch.float64, device=dev) if need[0] else None
+        gq = torch.empty((B, N, 1), dtype=torch.float64, device=dev) if need[1] else None
+        glo = torch.empty((B, N, 1), dtype=torch.float64, device=dev) if need[2] else None
+        ghi = torch.empty((B, N, 1), dtype=torch.float64, device=dev) if need[3] else None
+    steps = torch.empty((B, 2), dtype=torch.int32, device=dev) if return_steps else None
+    stream = _raw_stream(dev.index)
+    ws = _workspace(dev, B, stream)
+    with _device_guard(dev):
+        gam, dgam = duals if duals is not None else (None, None)
+        pd, fl = cache if cache is not None else (None, None)
+        rc = _capi.lib().dqq_boxqp_bwd_f64(_ptr(P), _ptr(q), _ptr(l_min), _ptr(l_max), _ptr(x), _ptr(grad_x), _ptr(gP),
+                                           _ptr(gq), _ptr(glo), _ptr(ghi), _ptr(gam), _ptr(dgam), B, N, float(epsilon),
+                                           layout, _ptr(steps), _ptr(pd), _ptr(fl), _ptr(ws), ws.numel() * 4, stream)
+    _capi.check(rc, "dqq_boxqp_bwd_f64")
+    return (gP, gq, glo, ghi, steps) if return_steps else (gP, gq, glo, ghi)

@@ -62,7 +62,8 @@ extern "C" {
  * streams. */
 size_t dqq_workspace_bytes(int64_t B);
 
-/* Largest N accepted: kind 0 = QP forward/backward, 1 = QCQP forward, 2 = QCQP backward. */
+/* Largest N accepted by the general kernels: kind 0 = QP forward/backward and the box forwards, 1 = QCQP
+ * forward, 2 = QCQP backward, 3 = box QP backward. */
 int dqq_max_n(int kind);
 
 /* Replaces the loop qcqp.py:29-31 (QPFn2.forward -> diffqcqp.solveQP,
@@ -128,6 +129,21 @@ int dqq_signedboxqp_fwd_f64(const double* P, const double* q, const double* l_mi
                             const double* v, double* x, int64_t B, int N, double eps, double mu_prox,
                             int max_iter, int adaptive_rho, int p_layout, int* iters, double* pdiag_out,
                             unsigned char* diag_flags_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Replaces the loop + assembly of BoxQPFn2.backward (qcqp.py:67-94 -> diffqcqp.solveDerivativesBoxQP,
+ * pybindings.cpp:39-45 -> Solver::dualFromPrimalBoxQP / solveDerivativesBoxQP, Solver.cpp:263-371).  The
+ * shipped Python of that method does not run; the semantics here are the ones it
+ * spells out, with the signs finite differences confirm (tests/test_oracle.py):
+ *   grad_P = -dl x^T, grad_q = -dl, grad_l_min = -dgamma_lo o gamma_lo, grad_l_max = +dgamma_hi o gamma_hi.
+ * Any output may be NULL.  gamma / dgamma (B,2N: lower multipliers | upper multipliers, may be NULL) are the
+ * reference's per-problem return values: gamma, and blgamma[0:2N]; blgamma[2N:3N] = -grad_q.
+ * ir_steps (B,2 ints, may be NULL): refinement steps of the dual recovery and of the derivative system.
+ * General (non-diagonal) P: N <= dqq_max_n(3) = 21 this round. */
+int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, const double* l_max, const double* x,
+                      const double* grad_x, double* grad_P, double* grad_q, double* grad_l_min, double* grad_l_max,
+                      double* gamma, double* dgamma, int64_t B, int N, double epsilon, int p_layout, int* ir_steps,
+                      const double* pdiag, const unsigned char* diag_flags, void* workspace, size_t workspace_bytes,
+                      void* stream);
 
 /* Tuning knobs (process-wide, read at launch time).  Unknown name -> DQQ_E_BAD_OPTION.
  *   "fwd_lpp"        lanes per problem of the diagonal forward kernel (0 = built-in choice from B)

@@ -510,7 +510,7 @@ static int dual_from_primal_box(const double *P, const double *q, const double *
 {
     double *Id2 = ws, *rhs = Id2 + 2 * n * n, *gnn = rhs + n, *irws = gnn + 2 * n;
     int *not_null = (int *)malloc(sizeof(int) * (2 * n + 1));
-    int nn, i, j, steps = 0;
+    int nn, i, j, steps = 1; /* nn == 0: the reference's loop runs one body on empty vectors (res = 0) and leaves */
     for (i = 0; i < 2 * n; ++i) gamma[i] = 0;
     nn = box_not_null(l_min, l_max, l, n, epsilon, not_null);
     box_id2(not_null, nn, n, Id2);

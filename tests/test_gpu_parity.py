@@ -459,6 +459,64 @@ def test_box_forward_reduces_to_qp(oracle, ops):
     assert torch.equal(it0, it1) and (x0 - x1).abs().max() < 1e-12
 
 
+def _box_bwd(O, ops, d, x, layout=0):
+    ref = O.boxqp_bwd_batch(d["P"].numpy(), d["q"].numpy(), d["l_min"].numpy(), d["l_max"].numpy(), x,
+                            d["grad_x"].numpy(), nthreads=8)
+    g = dev(d)
+    B, N = d["q"].shape[0], d["q"].shape[1]
+    duals = (torch.empty(B, 2 * N, dtype=torch.float64, device="cuda"), torch.empty(B, 2 * N, dtype=torch.float64, device="cuda"))
+    out = ops.boxqp_backward(g["P"], g["q"], g["l_min"], g["l_max"], torch.from_numpy(x).cuda(), g["grad_x"],
+                             layout=layout, return_steps=True, duals=duals)
+    return ref, out, duals
+
+
+@pytest.mark.parametrize("N,B", [(2, 130), (4, 500), (8, 2051), (16, 301), (32, 131), (64, 37)])
+def test_box_backward_diag_fast_path_is_bit_exact(oracle, ops, N, B):
+    """Diagonal P, identical x: the per-coordinate blocks reproduce the oracle's dense arithmetic bit for bit
+    (gradients, multipliers, both refinement step counts)."""
+    d = make_problem("box", B, N, 850 + N)
+    xo, _ = oracle.boxqp_fwd_batch(d["P"].numpy(), d["q"].numpy(), d["l_min"].numpy(), d["l_max"].numpy(), 1e-7, 1000,
+                                   nthreads=8)
+    # make some coordinates sit exactly on a bound and pin a few (l_min == l_max): 3x3 blocks
+    d["l_max"][::7, 0, 0] = d["l_min"][::7, 0, 0]
+    xo[::7, 0, 0] = d["l_min"].numpy()[::7, 0, 0]
+    ref, out, duals = _box_bwd(oracle, ops, d, xo)
+    gP, gq, glo, ghi, gam, st = ref
+    assert np.array_equal(npy(out[4]), st)
+    for a, b in zip(out[:4], (gP, gq, glo, ghi)):
+        assert np.array_equal(npy(a), b), "max diff %g" % np.abs(npy(a) - b).max()
+    assert np.array_equal(npy(duals[0]), gam)
+    active = (gam > 0).reshape(B, 2, N).any(axis=1).mean()
+    assert 0.2 < active < 0.95  # the batch exercises active and inactive coordinates
+
+
+@pytest.mark.parametrize("N,B,structure", [(8, 200, "dense"), (4, 64, "dense"), (5, 60, "dense"), (16, 24, "dense"),
+                                           (21, 8, "dense"), (8, 300, "mixed"), (16, 90, "mixed")])
+def test_box_backward_dense_and_mixed(oracle, ops, N, B, structure):
+    from diffqcqp_amd import _capi
+    d = make_problem("box", B, N, 870 + N, structure)
+    xo, _ = oracle.boxqp_fwd_batch(d["P"].numpy(), d["q"].numpy(), d["l_min"].numpy(), d["l_max"].numpy(), 1e-7, 1000,
+                                   nthreads=8)
+    for layout in ((_capi.P_AUTO,) if structure == "mixed" or N in (5, 21) else (_capi.P_AUTO, _capi.P_DENSE)):
+        ref, out, duals = _box_bwd(oracle, ops, d, xo, layout=layout)
+        check_backward_exact(list(out[:4]), out[4], ref[:4] + (ref[5],), exact=False)
+        assert np.allclose(npy(duals[0]), ref[4], rtol=1e-9, atol=1e-12)
+
+
+def test_box_end_to_end_and_unsupported_n(oracle, ops):
+    """HIP forward -> HIP backward against the oracle chain; general-P box backward is limited to N <= 21."""
+    from diffqcqp_amd import _capi
+    d = make_problem("box", 1000, 8, 890)
+    xo, ito, xh, ith = _box_fwd(oracle, ops, "box", d)
+    check_forward(xh, ith, xo, ito)
+    ref, out, _ = _box_bwd(oracle, ops, d, npy(xh))
+    check_end_to_end(list(out[:4]), out[4][:, 1], (ref[0], ref[1], ref[2], ref[3], ref[5][:, 1]))
+    assert _capi.lib().dqq_max_n(3) == 21
+    big = dev(make_problem("box", 4, 32, 891, "dense"))
+    with pytest.raises(ValueError, match="UNSUPPORTED_N"):
+        ops.boxqp_backward(big["P"], big["q"], big["l_min"], big["l_max"], big["q"], big["grad_x"], layout=_capi.P_DENSE)
+
+
 # ---------------------------------------------------------------- golden fixtures
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))), ids=os.path.basename)
 def test_hip_reproduces_golden(ops, path):
