@@ -3,12 +3,14 @@ pybind11 module `diffqcqp` (reference pybindings.cpp:74-83), for consumers that 
 instead of the autograd Functions:
 
     from diffqcqp_amd.diffqcqp import solveQP, solveQCQP, solveDerivativesQP, solveDerivativesQCQP
+    from diffqcqp_amd.diffqcqp import solveBoxQP, solveSignedBoxQP, solveDerivativesBoxQP
 
 Each call solves ONE problem given as numpy arrays (vectors may be (N,) or (N,1), any float dtype --
 converted to float64 like pybind11 does), on the GPU through the same C ABI as the batched path
 (B = 1, host buffers staged over PCIe), and returns fresh numpy arrays shaped like the reference's:
 `solveQP/solveQCQP -> (N,)`, `solveDerivativesQP -> (N,)`, `solveDerivativesQCQP -> (E1 (nc,nc),
-E2 (nc,nc), blgamma (nc+N,))`.  `warm_start` is accepted and ignored (dead in the reference).
+E2 (nc,nc), blgamma (nc+N,))`, `solveBoxQP/solveSignedBoxQP -> (N,)`, `solveDerivativesBoxQP ->
+(blgamma (3N,), gamma (2N,))`.  `warm_start` is accepted and ignored (dead in the reference).
 The batched functions `*_batch` take stacked problems and are what you want for throughput.
 """
 import numpy as np
@@ -68,3 +70,37 @@ def solveDerivativesQCQP(P, q, l_n, mu, l, grad_l, epsilon=1e-10):
     E2 = np.diag(2 * g * ln1 * mu1 * mu1)
     blgamma = np.concatenate([dgam.reshape(nc).cpu().numpy(), (-gq).reshape(n).cpu().numpy()])
     return E1, E2, blgamma
+
+
+def solveBoxQP(P, q, l_min, l_max, warm_start, epsilon=1e-10, mu_prox=1e-7, max_iter=1000, adaptative_rho=True):
+    """pybindings.cpp:32-37, :77"""
+    dev = _dev()
+    n = np.asarray(q).size
+    x = ops.boxqp_forward(_t(P, (1, n, n), dev), _t(q, (1, n, 1), dev), _t(l_min, (1, n, 1), dev),
+                          _t(l_max, (1, n, 1), dev), epsilon, max_iter, mu_prox=mu_prox, adaptive_rho=adaptative_rho)
+    return x.reshape(n).cpu().numpy()
+
+
+def solveSignedBoxQP(P, q, l_min, l_max, v, warm_start, epsilon=1e-10, mu_prox=1e-7, max_iter=1000,
+                     adaptative_rho=True):
+    """pybindings.cpp:47-52, :78"""
+    dev = _dev()
+    n = np.asarray(q).size
+    x = ops.boxqp_forward(_t(P, (1, n, n), dev), _t(q, (1, n, 1), dev), _t(l_min, (1, n, 1), dev),
+                          _t(l_max, (1, n, 1), dev), epsilon, max_iter, v=_t(v, (1, n, 1), dev), mu_prox=mu_prox,
+                          adaptive_rho=adaptative_rho)
+    return x.reshape(n).cpu().numpy()
+
+
+def solveDerivativesBoxQP(P, q, l_min, l_max, l, grad_l, epsilon=1e-10):
+    """-> (blgamma (3N,), gamma (2N,)) like pybindings.cpp:39-45: blgamma = [dgamma_lower (N); dgamma_upper (N);
+    dl (N)], gamma = [lower multipliers (N); upper multipliers (N)]."""
+    dev = _dev()
+    n = np.asarray(q).size
+    gam = torch.empty((1, 2 * n), dtype=torch.float64, device=dev)
+    dgam = torch.empty_like(gam)
+    _, gq, _, _ = ops.boxqp_backward(_t(P, (1, n, n), dev), _t(q, (1, n, 1), dev), _t(l_min, (1, n, 1), dev),
+                                     _t(l_max, (1, n, 1), dev), _t(l, (1, n, 1), dev), _t(grad_l, (1, n, 1), dev),
+                                     need=(False, True, False, False), epsilon=epsilon, duals=(gam, dgam))
+    blgamma = np.concatenate([dgam.reshape(2 * n).cpu().numpy(), (-gq).reshape(n).cpu().numpy()])
+    return blgamma, gam.reshape(2 * n).cpu().numpy()

@@ -7,6 +7,8 @@ instead of a Python loop over per-problem C++ calls.
     from diffqcqp_amd.qcqp import QPFn2, QCQPFn2
     x = QPFn2.apply(P, q, warm_start, eps, max_iter)          # (B,N,1)
     x = QCQPFn2.apply(P, q, l_n, mu, warm_start, eps, max_iter)
+    x = BoxQPFn2.apply(P, q, l_min, l_max, warm_start, eps, max_iter)            # qcqp.py:54-94
+    x = SignedBoxQPFn2.apply(P, q, l_min, l_max, v, warm_start, eps, max_iter)   # qcqp.py:97-137, forward only
 
 Behaviour kept from the reference:
   * importing this module sets torch's default dtype to float64 (qcqp.py:13);
@@ -87,3 +89,59 @@ class QCQPFn2(Function):
             if ctx.home != l.device:
                 grads = tuple(None if g is None else g.to(ctx.home) for g in grads)
         return grads + (None, None, None, None)
+
+
+class BoxQPFn2(Function):
+    """min 1/2 x'Px + q'x, l_min <= x <= l_max (reference qcqp.py:54-94).
+
+    The reference's forward works; its backward does not run (wrong unpack counts, swapped saved tensors,
+    `.asDiagonal()` on a tensor -- SURVEY.md section 2 #7).  This backward computes what that code spells out,
+    grad_P = -dl l', grad_q = -dl, grad_l_min = -dgamma_lo*gamma_lo, and grad_l_max = +dgamma_hi*gamma_hi: the
+    reference writes a minus sign there (qcqp.py:93), finite differences say plus (tests/test_oracle.py)."""
+
+    @staticmethod
+    def forward(ctx, P, q, l_min, l_max, warm_start, eps, max_iter, mu_prox=1e-7):
+        tensors = (P, q, l_min, l_max)
+        if q.is_cuda:
+            Pd, qd, lod, hid = (t.detach() for t in tensors)
+        else:
+            dev = _device_for(q)
+            Pd, qd, lod, hid = (t.detach().to(dev) for t in tensors)
+        cache = ops.diag_cache(qd)
+        l_2 = ops.boxqp_forward(Pd, qd, lod, hid, eps, max_iter, mu_prox=mu_prox, adaptive_rho=True, cache=cache)
+        ctx.save_for_backward(Pd, qd, lod, hid, l_2, *cache)
+        ctx.home = q.device
+        return l_2 if q.is_cuda else l_2.to(q.device)
+
+    @staticmethod
+    def backward(ctx, grad_l):
+        P, q, l_min, l_max, l, pdiag, flags = ctx.saved_tensors
+        need = tuple(ctx.needs_input_grad[0:4])
+        grads = (None, None, None, None)
+        if any(need):
+            grads = ops.boxqp_backward(P, q, l_min, l_max, l, grad_l.to(l.device), need, cache=(pdiag, flags))
+            if ctx.home != l.device:
+                grads = tuple(None if g is None else g.to(ctx.home) for g in grads)
+        return grads + (None, None, None, None)
+
+
+class SignedBoxQPFn2(Function):
+    """The box QP with the extra constraint sign(v_i) x_i <= 0 (reference qcqp.py:97-137).  Forward only: the
+    reference marks its backward "not implemented" (qcqp.py:111) -- it would differentiate the plain box QP,
+    ignoring v -- so asking for a gradient raises instead of returning something wrong."""
+
+    @staticmethod
+    def forward(ctx, P, q, l_min, l_max, v, warm_start, eps, max_iter, mu_prox=1e-7):
+        tensors = (P, q, l_min, l_max, v)
+        if q.is_cuda:
+            Pd, qd, lod, hid, vd = (t.detach() for t in tensors)
+        else:
+            dev = _device_for(q)
+            Pd, qd, lod, hid, vd = (t.detach().to(dev) for t in tensors)
+        l_2 = ops.boxqp_forward(Pd, qd, lod, hid, eps, max_iter, v=vd, mu_prox=mu_prox, adaptive_rho=True)
+        return l_2 if q.is_cuda else l_2.to(q.device)
+
+    @staticmethod
+    def backward(ctx, grad_l):
+        raise NotImplementedError("SignedBoxQPFn2 has no backward (not implemented in the reference either, "
+                                  "qcqp.py:111)")

@@ -35,6 +35,16 @@ def run(kind, d, eps, max_iter):
         x, it = O.qp_fwd_batch(P, q, eps, max_iter)
         gP, gq, st = O.qp_bwd_batch(P, q, x, g)
         out.update(x=x, iters=it, grad_P=gP, grad_q=gq, ir_steps=st)
+    elif kind in ("box", "sbox"):
+        lo, hi = d["l_min"].numpy(), d["l_max"].numpy()
+        out.update(l_min=lo, l_max=hi)
+        if kind == "sbox":  # forward only (no backward in the reference, qcqp.py:111)
+            x, it = O.boxqp_fwd_batch(P, q, lo, hi, eps, max_iter, v=d["v"].numpy())
+            out.update(v=d["v"].numpy(), x=x, iters=it)
+        else:
+            x, it = O.boxqp_fwd_batch(P, q, lo, hi, eps, max_iter)
+            gP, gq, glo, ghi, gam, st = O.boxqp_bwd_batch(P, q, lo, hi, x, g)
+            out.update(x=x, iters=it, grad_P=gP, grad_q=gq, grad_l_min=glo, grad_l_max=ghi, gamma=gam, ir_steps=st)
     else:
         ln, mu = d["l_n"].numpy(), d["mu"].numpy()
         x, it = O.qcqp_fwd_batch(P, q, ln, mu, eps, max_iter)
@@ -53,6 +63,10 @@ def main():
         "qcqp_dense_n8": run("qcqp", make_problem("qcqp", 24, 8, 1106, "dense"), 1e-7, 1000),
         "qp_dense_n64": run("qp", make_problem("qp", 3, 64, 1005, "dense"), 1e-7, 1000),
         "qp_stress_n8": run("qp", make_problem("qp", 48, 8, 1007, p_lo=0.0), 1e-7, 1000),
+        # Solver::solveBoxQP / solveSignedBoxQP / solveDerivativesBoxQP
+        "box_diag_n8": run("box", make_problem("box", 48, 8, 1201), 1e-7, 1000),
+        "box_dense_n8": run("box", make_problem("box", 24, 8, 1202, "dense"), 1e-7, 1000),
+        "sbox_diag_n8": run("sbox", make_problem("sbox", 48, 8, 1203), 1e-7, 1000),
     }
     # README.md:35-38 verbatim: degenerate (q >= 0 => x = 0 after one iteration)
     g = torch.Generator().manual_seed(1001)
@@ -79,7 +93,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **c)
         print("%-16s B=%d N=%d iters mean %.1f max %d ir_steps %s" % (
             name, c["q"].shape[0], c["q"].shape[1], c["iters"].mean(), c["iters"].max(),
-            np.bincount(c["ir_steps"]).tolist()))
+            np.bincount(np.asarray(c["ir_steps"]).reshape(-1)).tolist() if "ir_steps" in c else "-"))
 
 
 if __name__ == "__main__":

@@ -517,13 +517,64 @@ def test_box_end_to_end_and_unsupported_n(oracle, ops):
         ops.boxqp_backward(big["P"], big["q"], big["l_min"], big["l_max"], big["q"], big["grad_x"], layout=_capi.P_DENSE)
 
 
+def test_box_autograd_functions_and_module_level_api(oracle, ops):
+    """BoxQPFn2 / SignedBoxQPFn2 keep the reference's signatures (qcqp.py:54-137); gradients flow to
+    P, q, l_min, l_max; the module-level numpy functions return the reference's shapes."""
+    from diffqcqp_amd.qcqp import BoxQPFn2, SignedBoxQPFn2
+    from diffqcqp_amd import diffqcqp as M
+    d = make_problem("sbox", 64, 8, 895)
+    g = {k: v.cuda().requires_grad_(k in ("P", "q", "l_min", "l_max")) for k, v in d.items()}
+    ws = torch.zeros_like(g["q"])
+    x = BoxQPFn2.apply(g["P"], g["q"], g["l_min"], g["l_max"], ws, 1e-7, 1000)
+    assert x.shape == (64, 8, 1)
+    (x * g["grad_x"]).sum().backward()
+    xo, _ = oracle.boxqp_fwd_batch(d["P"].numpy(), d["q"].numpy(), d["l_min"].numpy(), d["l_max"].numpy(), 1e-7, 1000)
+    ref = oracle.boxqp_bwd_batch(d["P"].numpy(), d["q"].numpy(), d["l_min"].numpy(), d["l_max"].numpy(), npy(x),
+                                 d["grad_x"].numpy())
+    assert np.abs(npy(x) - xo).max() <= X_TOL
+    for name, r in zip(("P", "q", "l_min", "l_max"), ref[:4]):
+        assert np.array_equal(npy(g[name].grad), r), name  # diagonal P, identical x: bit-exact
+    # CPU tensors are staged and come back on the CPU
+    xc = BoxQPFn2.apply(d["P"], d["q"], d["l_min"], d["l_max"], torch.zeros_like(d["q"]), 1e-7, 1000)
+    assert not xc.is_cuda and torch.equal(xc, x.detach().cpu())
+    # signed box: forward only
+    xs = SignedBoxQPFn2.apply(g["P"], g["q"], g["l_min"], g["l_max"], g["v"], ws, 1e-7, 1000)
+    xso, _ = oracle.boxqp_fwd_batch(d["P"].numpy(), d["q"].numpy(), d["l_min"].numpy(), d["l_max"].numpy(), 1e-7, 1000,
+                                    v=d["v"].numpy())
+    assert np.abs(npy(xs) - xso).max() <= X_TOL
+    with pytest.raises(NotImplementedError):
+        xs.sum().backward()
+    # module-level numpy API (pybindings.cpp:77-81)
+    P0, q0, lo0, hi0, v0 = (d[k][3].numpy() for k in ("P", "q", "l_min", "l_max", "v"))
+    x1 = M.solveBoxQP(P0, q0, lo0, hi0, np.zeros(8), 1e-7, 1e-7, 1000)
+    assert x1.shape == (8,) and np.abs(x1 - xo[3, :, 0]).max() <= X_TOL
+    x2 = M.solveSignedBoxQP(P0, q0, lo0, hi0, v0, np.zeros(8), 1e-7, 1e-7, 1000)
+    assert np.abs(x2 - xso[3, :, 0]).max() <= X_TOL
+    blg, gam = M.solveDerivativesBoxQP(P0, q0, lo0, hi0, xo[3], d["grad_x"][3].numpy())
+    blo, gamo = oracle.solveDerivativesBoxQP(P0, q0, lo0, hi0, xo[3], d["grad_x"][3].numpy())
+    assert blg.shape == (24,) and gam.shape == (16,)
+    assert np.array_equal(blg, blo) and np.array_equal(gam, gamo)
+
+
 # ---------------------------------------------------------------- golden fixtures
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))), ids=os.path.basename)
 def test_hip_reproduces_golden(ops, path):
     d = np.load(path)
+    eps, mi = float(d["eps"]), int(d["max_iter"])
+    if "l_min" in d.files:  # box QP / signed box QP (forward only)
+        g = {k: torch.from_numpy(d[k]).cuda() for k in ("P", "q", "grad_x", "l_min", "l_max", "v") if k in d.files}
+        xh, ith = ops.boxqp_forward(g["P"], g["q"], g["l_min"], g["l_max"], eps, mi, v=g.get("v"), return_iters=True)
+        assert np.abs(npy(xh) - d["x"]).max() <= X_TOL
+        assert (npy(ith) == d["iters"]).mean() >= 0.95
+        if "v" not in d.files:
+            out = ops.boxqp_backward(g["P"], g["q"], g["l_min"], g["l_max"], torch.from_numpy(d["x"]).cuda(), g["grad_x"],
+                                     return_steps=True)
+            assert np.array_equal(npy(out[4]), d["ir_steps"])
+            for a, n in zip(out[:4], ("grad_P", "grad_q", "grad_l_min", "grad_l_max")):
+                assert np.allclose(npy(a), d[n], rtol=1e-9, atol=1e-9 * max(1.0, np.abs(d[n]).max())), n
+        return
     kind = "qcqp" if "l_n" in d.files else "qp"
     g = {k: torch.from_numpy(d[k]).cuda() for k in ("P", "q", "grad_x", "l_n", "mu") if k in d.files}
-    eps, mi = float(d["eps"]), int(d["max_iter"])
     xh, ith = hip_fwd(ops, kind, g, eps=eps, max_iter=mi)
     assert np.abs(npy(xh) - d["x"]).max() <= X_TOL
     assert (npy(ith) == d["iters"]).mean() >= 0.95

@@ -287,6 +287,16 @@ def test_oracle_reproduces_golden(oracle, path):
     """The committed fixtures are what the oracle computes (here and on the GPU box's host)."""
     d = np.load(path)
     eps, mi = float(d["eps"]), int(d["max_iter"])
+    if "l_min" in d.files:  # box QP (with v: signed box QP, forward only)
+        v = d["v"] if "v" in d.files else None
+        x, it = oracle.boxqp_fwd_batch(d["P"], d["q"], d["l_min"], d["l_max"], eps, mi, v=v)
+        assert np.array_equal(it, d["iters"]) and np.allclose(x, d["x"], rtol=0, atol=1e-11)
+        if v is None:
+            gP, gq, glo, ghi, gam, st = oracle.boxqp_bwd_batch(d["P"], d["q"], d["l_min"], d["l_max"], d["x"], d["grad_x"])
+            assert np.array_equal(st, d["ir_steps"])
+            for a, n in ((gP, "grad_P"), (gq, "grad_q"), (glo, "grad_l_min"), (ghi, "grad_l_max"), (gam, "gamma")):
+                assert np.allclose(a, d[n], rtol=1e-9, atol=1e-12), n
+        return
     if "l_n" in d.files:
         x, it = oracle.qcqp_fwd_batch(d["P"], d["q"], d["l_n"], d["mu"], eps, mi)
         gP, gq, gl, gm, st = oracle.qcqp_bwd_batch(d["P"], d["q"], d["l_n"], d["mu"], d["x"], d["grad_x"])
