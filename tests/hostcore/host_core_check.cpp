@@ -20,7 +20,66 @@ static int fwd_one(const double* p, const double* q, const double* rad, double e
     return it;
 }
 
+template <int KIND, int E>
+static int box_one(const double* p, const double* q, const double* lo, const double* hi, const double* v, double eps,
+                   double mu, int max_iter, int adaptive, double* x)
+{
+    double pp[E], qq[E], xx[E], rr[E / 2], sg[E];
+    for (int e = 0; e < E; ++e) { pp[e] = p[e]; qq[e] = q[e]; sg[e] = v ? (double)((v[e] > 0) - (v[e] < 0)) : 0.0; }
+    for (int c = 0; c < E / 2; ++c) rr[c] = 0.0;
+    int it = admm_fwd_diag<KIND, E, HostGroup>(pp, qq, rr, E, eps, mu, max_iter, adaptive, true, xx, lo, hi, sg);
+    for (int e = 0; e < E; ++e) x[e] = xx[e];
+    return it;
+}
+
 extern "C" {
+
+// diagonal-P box QP (v == NULL) / signed box QP forward, one problem
+__attribute__((visibility("default"))) int hostcore_box_fwd(int n, const double* p, const double* q, const double* lo,
+                                                            const double* hi, const double* v, double eps, double mu,
+                                                            int max_iter, int adaptive, double* x)
+{
+#define CASE(NN) if (n == NN) return v ? box_one<3, NN>(p, q, lo, hi, v, eps, mu, max_iter, adaptive, x) \
+                                       : box_one<2, NN>(p, q, lo, hi, v, eps, mu, max_iter, adaptive, x);
+    CASE(2) CASE(4) CASE(8) CASE(16)
+#undef CASE
+    return -1;
+}
+
+// diagonal-P box QP backward, one problem: the per-coordinate blocks + the two refinement loops exactly as
+// bwd_diag.hip drives them.  out: dl (n), gamma (2n), dgamma (2n); steps[2].
+__attribute__((visibility("default"))) void hostcore_box_bwd(int n, const double* p, const double* q, const double* lo,
+                                                             const double* hi, const double* x, const double* g,
+                                                             double* dl, double* gamma, double* dgamma, int* steps)
+{
+    BoxCoord* c = new BoxCoord[n];
+    for (int i = 0; i < n; ++i) c[i].setup_dual(p[i], q[i], x[i], lo[i], hi[i], kActiveEps);
+    IrControl ctl;
+    ctl.init();
+    for (int it = 0; it < kIrMaxIter; ++it) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) { double d[3]; c[i].step_dual(d); s += d[0]; s += d[1]; }
+        steps[0] = it + 1;
+        if (ctl.update(sqrt(s))) break;
+    }
+    for (int i = 0; i < n; ++i) c[i].setup_derivative(p[i], g[i]);
+    ctl.init();
+    double* tail = new double[n];
+    for (int it = 0; it < kIrMaxIter; ++it) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) { double d[3]; c[i].step_derivative(d); s += d[0]; s += d[1]; tail[i] = d[2]; }
+        for (int i = 0; i < n; ++i) s += tail[i];
+        steps[1] = it + 1;
+        if (ctl.update(sqrt(s))) break;
+    }
+    for (int i = 0; i < n; ++i) {
+        dl[i] = c[i].dl();
+        gamma[i] = c[i].gamma_lo; gamma[n + i] = c[i].gamma_hi;
+        dgamma[i] = c[i].dgamma_lo(); dgamma[n + i] = c[i].dgamma_hi();
+    }
+    delete[] tail;
+    delete[] c;
+}
 
 // diagonal-P forward, one problem; p = diagonal (n), rad = l_n*mu (n/2) for kind 1
 __attribute__((visibility("default"))) int hostcore_fwd(int kind, int n, const double* p, const double* q,

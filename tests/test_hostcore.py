@@ -80,3 +80,45 @@ def test_backward_cores_are_bit_exact(oracle, hostcore):
     assert np.array_equal(sth, st)
     assert np.array_equal(-dl, gq[:, :, 0])
     assert np.array_equal(gl2, gl[:, :, 0]) and np.array_equal(gm2, gm[:, :, 0])
+
+
+@pytest.mark.parametrize("kind,N", [("box", 8), ("box", 2), ("box", 16), ("sbox", 8), ("sbox", 4)])
+def test_box_forward_core_follows_oracle_trajectory(oracle, hostcore, kind, N):
+    B = 300
+    d = make_problem(kind, B, N, 161 + N)
+    P, q = d["P"].numpy(), d["q"].numpy()
+    lo, hi = d["l_min"].numpy(), d["l_max"].numpy()
+    v = d["v"].numpy() if kind == "sbox" else None
+    xo, ito = oracle.boxqp_fwd_batch(P, q, lo, hi, 1e-7, 1000, v=v)
+    p = np.ascontiguousarray(np.diagonal(P, axis1=1, axis2=2))
+    qq, l1, h1 = (np.ascontiguousarray(a[:, :, 0]) for a in (q, lo, hi))
+    v1 = None if v is None else np.ascontiguousarray(v[:, :, 0])
+    xh, ith = np.zeros((B, N)), np.zeros(B, dtype=int)
+    for b in range(B):
+        ith[b] = hostcore.hostcore_box_fwd(N, _p(p[b]), _p(qq[b]), _p(l1[b]), _p(h1[b]), None if v1 is None else _p(v1[b]),
+                                           ctypes.c_double(1e-7), ctypes.c_double(1e-7), 1000, 1, _p(xh[b]))
+    assert np.array_equal(ith, ito)
+    assert (np.abs(xh - xo[:, :, 0]) / np.maximum(1.0, np.abs(xo[:, :, 0]))).max() < 1e-11
+
+
+def test_box_backward_core_is_bit_exact(oracle, hostcore):
+    """Per-coordinate blocks (1x1 / 2x2 dual, up to 3x3 derivative system, incl. pinned coordinates with both
+    multipliers) against the oracle's dense (3N)^2 solve: identical bits, identical refinement exits."""
+    B, N = 400, 8
+    d = make_problem("box", B, N, 171)
+    P, q, g = d["P"].numpy(), d["q"].numpy(), d["grad_x"].numpy()
+    lo, hi = d["l_min"].numpy().copy(), d["l_max"].numpy().copy()
+    x, _ = oracle.boxqp_fwd_batch(P, q, lo, hi, 1e-7, 1000)
+    hi[::5, 2, 0] = lo[::5, 2, 0]          # pinned coordinates: both bounds active
+    x[::5, 2, 0] = lo[::5, 2, 0]
+    gP, gq, glo, ghi, gam, st = oracle.boxqp_bwd_batch(P, q, lo, hi, x, g)
+    p = np.ascontiguousarray(np.diagonal(P, axis1=1, axis2=2))
+    qq, gg, xx, l1, h1 = (np.ascontiguousarray(a[:, :, 0]) for a in (q, g, x, lo, hi))
+    dl, gm, dg = np.zeros((B, N)), np.zeros((B, 2 * N)), np.zeros((B, 2 * N))
+    sth = np.zeros((B, 2), dtype=np.int32)
+    for b in range(B):
+        hostcore.hostcore_box_bwd(N, _p(p[b]), _p(qq[b]), _p(l1[b]), _p(h1[b]), _p(xx[b]), _p(gg[b]), _p(dl[b]),
+                                  _p(gm[b]), _p(dg[b]), sth[b].ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    assert np.array_equal(sth, st)
+    assert np.array_equal(-dl, gq[:, :, 0]) and np.array_equal(gm, gam)
+    assert np.array_equal(-(dg[:, :N] * gm[:, :N]), glo[:, :, 0]) and np.array_equal(dg[:, N:] * gm[:, N:], ghi[:, :, 0])
