@@ -64,12 +64,16 @@ int* hint_device_pointer()
     return d;
 }
 
-// Returns this launch's generation; *dense_before = the previous launch reported non-diagonal tiles.
+// Returns this launch's generation; *dense_before = one of the last kHintWindow launches reported
+// non-diagonal tiles (a window, not just the previous launch: the host usually enqueues several calls
+// ahead of the GPU, so the word lags by the depth of the queue).
+constexpr int kHintWindow = 64;
 int hint_next_generation(bool* dense_before)
 {
     const int gen = g_hint_gen.fetch_add(1) + 1;
     int* h = g_hint_host.load();
-    *dense_before = h != nullptr && gen > 1 && *reinterpret_cast<volatile int*>(h) == gen - 1;
+    const int seen = h != nullptr ? *reinterpret_cast<volatile int*>(h) : 0;
+    *dense_before = seen > 0 && gen - seen <= kHintWindow;
     return gen;
 }
 
@@ -142,7 +146,7 @@ static int fwd_dispatch(int kind, dqq::FwdArgs& a, void* workspace, size_t works
     a.ws = static_cast<int*>(workspace);
     bool needs_fallback = true;
     int fuse = g_fuse.load();
-    if (fuse < 0 && kind <= dqq::kKindQCQP && dqq::fwd_lane_dense_supported(a.N)) {
+    if (fuse < 0 && dqq::fwd_lane_dense_supported(a.N)) {
         a.hint = hint_device_pointer();
         if (a.hint != nullptr) {
             bool dense_before = false;

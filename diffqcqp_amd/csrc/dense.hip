@@ -127,10 +127,9 @@ static hipError_t launch_fwd_wave(const FwdArgs& a, bool use_worklist, hipStream
 hipError_t launch_fwd_dense(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
-    // the lane- and workgroup-per-problem kernels exist for QP / QCQP; the box kinds use the wave kernel
-    if (kind <= kKindQCQP && fwd_lane_dense_supported(a.N) && g_lane_dense.load() != 0)
+    if (fwd_lane_dense_supported(a.N) && g_lane_dense.load() != 0)
         return launch_fwd_lane_dense(kind, a, use_worklist, s);
-    if (kind <= kKindQCQP && fwd_dense_block_supported(a.N) && g_dense_block.load() != 0)
+    if (fwd_dense_block_supported(a.N) && g_dense_block.load() != 0)
         return launch_fwd_dense_block(kind, a, use_worklist, s);
     switch (kind) {
     case 0: return launch_fwd_wave<0>(a, use_worklist, s);

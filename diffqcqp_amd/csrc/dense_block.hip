@@ -278,14 +278,17 @@ template <int KIND, int N>
 __global__ __launch_bounds__(256, N == 32 ? 3 : 2) void fwd_dense_block_kernel(const double* __restrict__ P,
                                                               const double* __restrict__ q,
                                                               const double* __restrict__ l_n,
-                                                              const double* __restrict__ mu_c, double* __restrict__ x,
+                                                              const double* __restrict__ mu_c,
+                                                              const double* __restrict__ v_sign, double* __restrict__ x,
                                                               long B, double eps, double mu, int max_iter, int adaptive,
                                                               int* __restrict__ iters, int* __restrict__ ws,
                                                               int use_worklist)
 {
+    // KIND 2 / 3 (box / signed box QP, Solver.cpp:198-261 / 374-439): l_n = l_min, mu_c = l_max per coordinate
     using G = BlockGeom<N>;
     using WR = WaveRows<N>;
     constexpr int CW = WR::CW;
+    constexpr bool QP_LIKE = (KIND != 1);
     static_assert(WR::LDS_DOUBLES == G::VEC, "exchange area size");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* X = smem;                 // region 0: W / L -> M^-1 (row-major, stride LD)
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(256, N == 32 ? 3 : 2) void fwd_dense_block_kernel(c
             const double s = WR::sum_rows(v * v);
             if (s > 0) v = v / sqrt(s);
         }
-        const int pi_steps = (KIND == 0) ? 10 : 100;
+        const int pi_steps = QP_LIKE ? 10 : 100;
         for (int k = 0; k < pi_steps; ++k) {
             const double Av = wr.matvec(m, v);
             const double s = WR::sum_rows(Av * Av);
@@ -342,6 +345,12 @@ __global__ __launch_bounds__(256, N == 32 ? 3 : 2) void fwd_dense_block_kernel(c
         const double qi = q[prob * N + row];
         double rad = 0.0;
         if (KIND == 1) rad = l_n[prob * (N / 2) + row / 2] * mu_c[prob * (N / 2) + row / 2];
+        double blo = 0.0, bhi = 0.0, bsg = 0.0;
+        if (KIND >= 2) {
+            blo = l_n[prob * N + row];
+            bhi = mu_c[prob * N + row];
+            if (KIND == 3) { const double vv = v_sign[prob * N + row]; bsg = (double)((vv > 0) - (vv < 0)); } // :395
+        }
         double qp = qi, l2 = 0.0, l2p = 0.0, u = 0.0;
         int rho_up = 0, cpt = 0, it_done = 0;
         bool need_refactor = true;
@@ -354,6 +363,14 @@ __global__ __launch_bounds__(256, N == 32 ? 3 : 2) void fwd_dense_block_kernel(c
             double z = kAlpha * l + (1 - kAlpha) * l2 + u * inv_rho;     // :82 / :541 (inv_rho = 1/rho)
             if (KIND == 0) {
                 z = z < 0 ? 0 : z;
+            } else if (KIND >= 2) {
+                z = z < blo ? blo : z;                                   // cwiseMax(l_min), :219 / :396
+                z = bhi < z ? bhi : z;                                   // cwiseMin(l_max), :220 / :397
+                if (KIND == 3) {                                         // v o min(v o l_2, 0), :398
+                    double mm = bsg * z;
+                    mm = 0 < mm ? 0 : mm;
+                    z = bsg * mm;
+                }
             } else {                                                     // prox_circle, :505-519
                 const double other = partner<1>(z);                      // row ^ 1
                 const double a = (row & 1) ? other : z, b = (row & 1) ? z : other;
@@ -362,12 +379,12 @@ __global__ __launch_bounds__(256, N == 32 ? 3 : 2) void fwd_dense_block_kernel(c
             }
             l2 = z;
             u += rho * (kAlpha * l + (1 - kAlpha) * l2p - l2);           // :83 / :543
-            const double rd_i = (KIND == 0) ? fabs(rho * (l2 - l2p)) : fabs(l2 - l2p);
+            const double rd_i = QP_LIKE ? fabs(rho * (l2 - l2p)) : fabs(l2 - l2p);
             const double rp_i = fabs(l2 - (kAlpha * l + (1 - kAlpha) * l2p));
             l2p = l2;
             double rdm, res_prim;
             wr.max2_rows(rd_i, rp_i, rdm, res_prim);
-            const double res_dual = (KIND == 0) ? rdm : rho * rdm;
+            const double res_dual = QP_LIKE ? rdm : rho * rdm;
             bool stop = res_dual < eps;                                  // :88
             if (KIND == 1) stop = (res_prim < eps + kEpsRel * sqrt(WR::sum_rows(l * l))) && stop; // :548
             if (stop) break;
@@ -376,7 +393,7 @@ __global__ __launch_bounds__(256, N == 32 ? 3 : 2) void fwd_dense_block_kernel(c
                     if (cpt % 5 == 0) {
                         if (rho_up == -1) {
                             tau_inc = 1 + .8 * (tau_inc - 1);
-                            if (KIND == 0) tau_dec = 1 + .8 * (tau_dec - 1);
+                            if (QP_LIKE) tau_dec = 1 + .8 * (tau_dec - 1);
                         }
                         mdiag += rho * (tau_inc - 1);
                         rho *= tau_inc;
@@ -387,7 +404,7 @@ __global__ __launch_bounds__(256, N == 32 ? 3 : 2) void fwd_dense_block_kernel(c
                 } else if (res_dual > kMuThresh * res_prim) {            // :106 / :566
                     if (cpt % 5 == 0) {
                         if (rho_up == 1) {
-                            if (KIND == 0) tau_inc = 1 + .8 * (tau_inc - 1);
+                            if (QP_LIKE) tau_inc = 1 + .8 * (tau_inc - 1);
                             tau_dec = 1 + .8 * (tau_dec - 1);
                         }
                         mdiag += rho * (1. / tau_dec - 1);
@@ -424,7 +441,7 @@ static hipError_t launch_block(const FwdArgs& a, bool use_worklist, hipStream_t 
     if (e != hipSuccess) return e;
     const long cap = 256L * (N == 32 ? 3 : 2) * 2; // persistent: 2 (N=64, LDS) or 3 (N=32, VGPRs) workgroups per CU, x2 for balance
     const unsigned grid = use_worklist ? 512u : (unsigned)(a.B < cap ? (a.B > 0 ? a.B : 1) : cap);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), G::LDS_BYTES, s, a.P, a.q, a.l_n, a.mu, a.x, a.B, a.eps, a.mu_prox,
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), G::LDS_BYTES, s, a.P, a.q, a.l_n, a.mu, a.v, a.x, a.B, a.eps, a.mu_prox,
                        a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0);
     return hipGetLastError();
 }
@@ -434,8 +451,18 @@ bool fwd_dense_block_supported(int N) { return N == 32 || N == 64; }
 hipError_t launch_fwd_dense_block(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
-    if (a.N == 64) return kind == 0 ? launch_block<0, 64>(a, use_worklist, s) : launch_block<1, 64>(a, use_worklist, s);
-    if (a.N == 32) return kind == 0 ? launch_block<0, 32>(a, use_worklist, s) : launch_block<1, 32>(a, use_worklist, s);
+#define DQQ_CASE(NN)                                                            \
+    if (a.N == NN) {                                                            \
+        switch (kind) {                                                         \
+        case 0: return launch_block<0, NN>(a, use_worklist, s);                 \
+        case 1: return launch_block<1, NN>(a, use_worklist, s);                 \
+        case 2: return launch_block<2, NN>(a, use_worklist, s);                 \
+        case 3: return launch_block<3, NN>(a, use_worklist, s);                 \
+        default: return hipErrorInvalidValue;                                   \
+        }                                                                       \
+    }
+    DQQ_CASE(64) DQQ_CASE(32)
+#undef DQQ_CASE
     return hipErrorInvalidValue;
 }
 

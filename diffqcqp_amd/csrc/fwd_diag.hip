@@ -187,14 +187,16 @@ static const int* lpp_choices(int N, int& count)
 // Built-in choice.  Fewer lanes per problem = fewer VALU instructions per problem (the scalar
 // rho/tau/stop logic and the pow() prologue are replicated on every lane of a problem), but the
 // kernel is latency-bound with a single wave per SIMD, so take the smallest LPP that still puts
-// about two waves on each of the chip's 1024 SIMDs (measurements: DESIGN.md).
+// about two waves on each of the chip's 1024 SIMDs -- four for N >= 32, where a wave first streams
+// 32+ KiB of P and more resident waves overlap that stream with other waves' arithmetic
+// (B=32768, N=32: 73 us at LPP 4, 66 us at LPP 8).  Measurements: DESIGN.md.
 int fwd_diag_default_lpp(int N, long B)
 {
     int count = 0;
     const int* c = lpp_choices(N, count);
     if (count == 0) return 0;
     for (int i = 0; i < count; ++i)
-        if (B * c[i] / 64 >= 2048) return c[i];
+        if (B * c[i] / 64 >= (N >= 32 ? 4096 : 2048)) return c[i];
     return c[count - 1];
 }
 

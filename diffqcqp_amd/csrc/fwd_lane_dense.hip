@@ -70,12 +70,15 @@ template <int KIND, int N>
 __global__ __launch_bounds__(64, 1) void fwd_lane_dense_kernel(const double* __restrict__ P,
                                                                const double* __restrict__ q,
                                                                const double* __restrict__ l_n,
-                                                               const double* __restrict__ mu_c, double* __restrict__ x,
+                                                               const double* __restrict__ mu_c,
+                                                               const double* __restrict__ v_sign, double* __restrict__ x,
                                                                long B, double eps, double mu, int max_iter,
                                                                int adaptive, int* __restrict__ iters,
                                                                int* __restrict__ ws, int use_worklist)
 {
+    // KIND 2 / 3 (box / signed box QP, Solver.cpp:198-261 / 374-439): l_n = l_min, mu_c = l_max per coordinate
     static_assert(N % 2 == 0, "even N");
+    constexpr bool QP_LIKE = (KIND != 1);
     const long count = use_worklist ? (long)ws[kWsCount] : B;
     const long slot = (long)blockIdx.x * 64 + threadIdx.x;
     const bool valid = slot < count;
@@ -118,6 +121,23 @@ __global__ __launch_bounds__(64, 1) void fwd_lane_dense_kernel(const double* __r
 #pragma unroll
     for (int c = 0; c < N / 2; ++c)
         rad[c] = (KIND == 1 && valid) ? l_n[prob * (N / 2) + c] * mu_c[prob * (N / 2) + c] : 1.0;
+    constexpr int NB = (KIND >= 2) ? N : 1;
+    double blo[NB], bhi[NB], bsg[NB];
+    if constexpr (KIND >= 2) {
+#pragma unroll
+        for (int i = 0; i < N; i += 2) {
+            const double2 a = valid ? *reinterpret_cast<const double2*>(l_n + prob * N + i) : make_double2(0.0, 0.0);
+            const double2 b = valid ? *reinterpret_cast<const double2*>(mu_c + prob * N + i) : make_double2(0.0, 0.0);
+            blo[i] = a.x; blo[i + 1] = a.y;
+            bhi[i] = b.x; bhi[i + 1] = b.y;
+            bsg[i] = bsg[i + 1] = 0.0;
+            if (KIND == 3) {
+                const double2 c = valid ? *reinterpret_cast<const double2*>(v_sign + prob * N + i) : make_double2(0.0, 0.0);
+                bsg[i] = (double)((c.x > 0) - (c.x < 0));                      // cwiseSign, :395
+                bsg[i + 1] = (double)((c.y > 0) - (c.y < 0));
+            }
+        }
+    }
 
     // ---- power_iteration, Solver.cpp:46-59
     double Lmax;
@@ -132,7 +152,7 @@ __global__ __launch_bounds__(64, 1) void fwd_lane_dense_kernel(const double* __r
 #pragma unroll
             for (int i = 0; i < N; ++i) v[i] = v[i] / nn;
         }
-        const int pi_steps = (KIND == 0) ? 10 : 100;
+        const int pi_steps = QP_LIKE ? 10 : 100;
         for (int k = 0; k < pi_steps; ++k) {
             double Av[N];
             s = 0.0;
@@ -193,6 +213,19 @@ __global__ __launch_bounds__(64, 1) void fwd_lane_dense_kernel(const double* __r
             if (KIND == 0) {
 #pragma unroll
                 for (int i = 0; i < N; ++i) z[i] = fmax(z[i], 0.0);
+            } else if constexpr (KIND >= 2) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    double t = z[i];
+                    t = t < blo[i] ? blo[i] : t;                                  // cwiseMax(l_min), :219 / :396
+                    t = bhi[i] < t ? bhi[i] : t;                                  // cwiseMin(l_max), :220 / :397
+                    if (KIND == 3) {                                              // v o min(v o l_2, 0), :398
+                        double m = bsg[i] * t;
+                        m = 0 < m ? 0 : m;
+                        t = bsg[i] * m;
+                    }
+                    z[i] = t;
+                }
             } else {
 #pragma unroll
                 for (int c = 0; c < N / 2; ++c) {                                 // prox_circle, :505-519
@@ -230,7 +263,7 @@ __global__ __launch_bounds__(64, 1) void fwd_lane_dense_kernel(const double* __r
                 if (fire) {
                     if (rho_up == (inc ? -1 : 1)) {
                         const double ti = 1 + .8 * (tau_inc - 1), td = 1 + .8 * (tau_dec - 1);
-                        if (KIND == 0) { tau_inc = ti; tau_dec = td; }
+                        if (QP_LIKE) { tau_inc = ti; tau_dec = td; }
                         else if (inc) tau_inc = ti;
                         else tau_dec = td;
                     }
@@ -270,7 +303,7 @@ static hipError_t launch_lane(const FwdArgs& a, bool use_worklist, hipStream_t s
 {
     const long nw = (a.B + 63) / 64;
     if (nw == 0) return hipSuccess;
-    hipLaunchKernelGGL((fwd_lane_dense_kernel<KIND, N>), dim3((unsigned)nw), dim3(64), 0, s, a.P, a.q, a.l_n, a.mu, a.x,
+    hipLaunchKernelGGL((fwd_lane_dense_kernel<KIND, N>), dim3((unsigned)nw), dim3(64), 0, s, a.P, a.q, a.l_n, a.mu, a.v, a.x,
                        a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0);
     return hipGetLastError();
 }
@@ -279,8 +312,16 @@ bool fwd_lane_dense_supported(int N) { return N == 2 || N == 4 || N == 6 || N ==
 
 hipError_t launch_fwd_lane_dense(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s)
 {
-#define DQQ_CASE(NN) \
-    if (a.N == NN) return kind == 0 ? launch_lane<0, NN>(a, use_worklist, s) : launch_lane<1, NN>(a, use_worklist, s);
+#define DQQ_CASE(NN)                                                           \
+    if (a.N == NN) {                                                           \
+        switch (kind) {                                                        \
+        case 0: return launch_lane<0, NN>(a, use_worklist, s);                 \
+        case 1: return launch_lane<1, NN>(a, use_worklist, s);                 \
+        case 2: return launch_lane<2, NN>(a, use_worklist, s);                 \
+        case 3: return launch_lane<3, NN>(a, use_worklist, s);                 \
+        default: return hipErrorInvalidValue;                                  \
+        }                                                                      \
+    }
     DQQ_CASE(2) DQQ_CASE(4) DQQ_CASE(6) DQQ_CASE(8)
 #undef DQQ_CASE
     return hipErrorInvalidValue;
