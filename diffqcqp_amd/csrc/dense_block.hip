@@ -9,8 +9,8 @@
 //   refactor      blocked (16-column panels) right-looking Cholesky in LDS, L^-1 by blocked forward
 //                 substitution and M^-1 = L^-T L^-1 as tile products -- all 16x16 tile products run on
 //                 the f64 matrix cores (v_mfma_f64_16x16x4_f64); only the 16x16 diagonal blocks are
-//                 factored / inverted by one wave in registers (v_readlane broadcasts).  Three
-//                 workgroup barriers per panel.
+//                 factored / inverted in registers (v_readlane broadcasts), redundantly by every wave.
+//                 Two workgroup barriers per panel, none in the inverse.
 //   iteration     every wave keeps ALL rows (one per lane) and a quarter of the columns of M^-1 in
 //                 registers; one barrier per ADMM iteration (see WaveRows below).
 // The factorisation sums in a different order than the reference's left-looking LLT and column-wise
@@ -54,24 +54,40 @@ DQQ_D v4d tile_mma(v4d acc, const double* a, int ars, int acs, const double* b, 
 {
     const double* ap = a + (l & 15) * ars + (l >> 4) * acs;
     const double* bp = b + (l >> 4) * brs + (l & 15) * bcs;
-    for (int k = 0; k < K; k += 4) {
-        const double av = ap[k * acs];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(negate_a ? -av : av, bp[k * brs], acc, 0, 0, 0);
+    // 16 columns of K per trip: all eight operands are loaded before the first of the four dependent MFMAs
+    // is issued (one LDS latency per trip instead of four), and two accumulators halve the dependent chain
+    v4d acc2 = {0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < K; k += 16) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            av[u] = ap[(k + 4 * u) * acs];
+            bv[u] = bp[(k + 4 * u) * brs];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double x = negate_a ? -av[u] : av[u];
+            if (u & 1) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, bv[u], acc2, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, bv[u], acc, 0, 0, 0);
+        }
     }
-    return acc;
+    return acc + acc2;
 }
 
-// Diagonal block kb of the blocked factorisation, by ONE wave in registers (lanes 0-15 = rows of the
-// block): right-looking Cholesky of the 16x16 block of W in place, then its inverse (column c per lane c)
-// into the diagonal block of LinvT (LinvT[c][i] = (L^-1)[i][c]).  Broadcasts via v_readlane, no LDS
-// round trips inside.
+// Diagonal block kb of the blocked factorisation, in registers (lanes 0-15 = rows of the block; the other
+// lanes mirror them): right-looking Cholesky of the 16x16 block of W, then its inverse (column c per lane
+// c) into the diagonal block of LinvT (LinvT[c][i] = (L^-1)[i][c]).  Broadcasts via v_readlane, no LDS
+// round trips inside.  EVERY wave of the workgroup runs this on the same input and stores the same bits
+// to the same place: nobody has to wait for a designated wave, and a wave only needs its own stores to
+// be visible (wave_lds_fence) before it reads the block back.  The factor L11 itself is not stored --
+// nothing downstream reads it (the panel solve, the inverse and the product use L11^-1).
 template <int N>
-DQQ_D void diag_block_factor(double* W, double* LinvT, int kb, int l, bool& bad)
+DQQ_D void diag_block_factor(const double* W, double* LinvT, int kb, int l, bool& bad)
 {
     using G = BlockGeom<N>;
     const int row = (l & 15);
     double w[16], rinv[16];
-    double* wrow = W + (16 * kb + row) * G::LD + 16 * kb;
+    const double* wrow = W + (16 * kb + row) * G::LD + 16 * kb;
 #pragma unroll
     for (int j = 0; j < 16; ++j) w[j] = wrow[j];
 #pragma unroll
@@ -95,28 +111,34 @@ DQQ_D void diag_block_factor(double* W, double* LinvT, int kb, int l, bool& bad)
     if (l < 16) {
         double* yrow = LinvT + (16 * kb + row) * G::LD + 16 * kb;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            wrow[j] = w[j];
-            yrow[j] = y[j];
-        }
+        for (int j = 0; j < 16; ++j) yrow[j] = y[j];
     }
 }
 
-// Blocked (16-column panels) right-looking Cholesky of W in place + L^-1 (as LinvT), 256 threads.
-// Per panel: diagonal block in registers (wave 0), panel solve and trailing update as 16x16x16 tile
-// products on the f64 matrix cores; 3 workgroup barriers per panel instead of 3 per column.
-template <int N>
+// Blocked (16-column panels) right-looking Cholesky of W + L^-1 (as LinvT), 256 threads.  Per panel: the
+// diagonal block in registers (every wave, see above), panel solve and trailing update as 16x16x16 tile
+// products on the f64 matrix cores; two workgroup barriers per panel.  The off-diagonal blocks of L^-1
+// are then built column by column, one block column per wave, which needs no workgroup barrier at all:
+//   Linv[i][j] = -Linv[i][i] * sum_{k=j}^{i-1} L[i][k] * Linv[k][j]     (Linv[a][b] lives at LinvT[b][a])
+// only depends on L (complete), the diagonal blocks (every wave has them) and blocks of the same column.
+// On return (after a barrier) LinvT holds L^-T on and right of its diagonal blocks; the blocks left of
+// them are scratch.  W's diagonal blocks keep the input, its strict lower blocks hold L.
+template <int N, bool DIAG_ALL_WAVES = false>
 DQQ_D void block_cholesky_and_inverse(double* W, double* LinvT, double* fail_flag, int t, bool& bad)
 {
     using G = BlockGeom<N>;
     constexpr int NT = N / 16;
     const int wave = t >> 6, l = t & 63;
     for (int kb = 0; kb < NT; ++kb) {
-        if (wave == 0) {
+        if (kb > 0) __syncthreads(); // the trailing update of panel kb-1 is complete
+        if (DIAG_ALL_WAVES) {
             diag_block_factor<N>(W, LinvT, kb, l, bad);
-            if (l == 0 && bad) *fail_flag = 1.0; // non-positive pivot: poison the result (NaN)
+            wave_lds_fence();
+        } else {
+            if (wave == 0) diag_block_factor<N>(W, LinvT, kb, l, bad);
+            __syncthreads();
         }
-        __syncthreads();
+        if (kb == NT - 1) break;
         // panel: L[ib][kb] = A[ib][kb] * L11^-T ; (L11^-T)[k][j] = Linv11[j][k] = LinvT[16kb+k][16kb+j]
         for (int ib = kb + 1 + wave; ib < NT; ib += 4) {
             v4d acc = {0.0, 0.0, 0.0, 0.0};
@@ -140,15 +162,13 @@ DQQ_D void block_cholesky_and_inverse(double* W, double* LinvT, double* fail_fla
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg) W[(16 * ib + (l >> 4) + 4 * rg) * G::LD + 16 * jb + (l & 15)] = acc[rg];
             }
-        __syncthreads();
     }
-    // off-diagonal blocks of L^-1, block row by block row:
-    //   Linv[i][j] = -Linv[i][i] * sum_{k=j}^{i-1} L[i][k] * Linv[k][j];   Linv[a][b] lives at LinvT[b][a]
-    // Per-wave 16x16 scratch tile: a block of LinvT LEFT of the diagonal (last block row, block column
-    // `wave`) -- those blocks are untouched until the zero fill below, and at most NT-1 waves are active.
-    double* T = LinvT + (16 * (NT - 1)) * G::LD + 16 * (wave < NT - 1 ? wave : 0);
-    for (int i = 1; i < NT; ++i) {
-        for (int j = wave; j < i; j += 4) {
+    if (t == 0 && bad) *fail_flag = 1.0; // non-positive pivot: poison the result (NaN)
+    // block column j of L^-1 by wave j.  Per-wave 16x16 scratch tile: a block of LinvT LEFT of the diagonal
+    // (last block row, block column j) -- nothing else ever touches those blocks.
+    for (int j = wave; j < NT - 1; j += 4) {
+        double* T = LinvT + (16 * (NT - 1)) * G::LD + 16 * j;
+        for (int i = j + 1; i < NT; ++i) {
             v4d acc = {0.0, 0.0, 0.0, 0.0};
             // A = L[16i.., 16j..16i), B[k][c] = Linv[16j+k][16j+c] = LinvT[(16j+c)*LD + 16j+k]
             acc = tile_mma(acc, W + (16 * i) * G::LD + 16 * j, G::LD, 1, LinvT + (16 * j) * G::LD + 16 * j, 1, G::LD,
@@ -164,12 +184,6 @@ DQQ_D void block_cholesky_and_inverse(double* W, double* LinvT, double* fail_fla
                 LinvT[(16 * j + (l & 15)) * G::LD + 16 * i + (l >> 4) + 4 * rg] = res[rg];
             wave_lds_fence();
         }
-        __syncthreads();
-    }
-    // zero the blocks of LinvT left of the diagonal (the MFMA product sums over all k)
-    for (int idx = t; idx < N * N; idx += G::T) {
-        const int c = idx / N, k = idx % N;
-        if ((k >> 4) < (c >> 4)) LinvT[c * G::LD + k] = 0.0;
     }
     __syncthreads();
 }
@@ -192,8 +206,18 @@ DQQ_D void block_inverse_product(const double* LinvT, double* out, int t)
         const double* arow = LinvT + (16 * ti + (l & 15)) * G::LD + (l >> 4);
         const double* brow = LinvT + (16 * tj + (l & 15)) * G::LD + (l >> 4);
         const int s0 = FULL ? 0 : 4 * (ti > tj ? ti : tj);
-#pragma unroll 4
-        for (int s = s0; s < N / 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[4 * s], brow[4 * s], acc, 0, 0, 0);
+        v4d acc2 = {0.0, 0.0, 0.0, 0.0};
+        for (int s = s0; s < N / 4; s += 4) { // 16 columns of k per trip (s0 is a multiple of 4)
+            double av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { av[u] = arow[4 * (s + u)]; bv[u] = brow[4 * (s + u)]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (u & 1) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc2, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+            }
+        }
+        acc = acc + acc2;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             const int row = 16 * ti + (l >> 4) + 4 * rg, col = 16 * tj + (l & 15);
