@@ -10,6 +10,7 @@ namespace dqq {
 extern std::atomic<int> g_dense_block;
 extern std::atomic<int> g_lane_dense;
 extern std::atomic<int> g_dense_teams;
+extern std::atomic<int> g_small_bwd;
 }
 
 namespace {
@@ -27,7 +28,8 @@ Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback"
                       {"fuse_fallback", &g_fuse},
                       {"dense_block", &dqq::g_dense_block},
                       {"lane_dense", &dqq::g_lane_dense},
-                      {"dense_teams", &dqq::g_dense_teams}};
+                      {"dense_teams", &dqq::g_dense_teams},
+                      {"small_bwd", &dqq::g_small_bwd}};
 
 // Performance hint of the AUTO layout (never affects results): a host-mapped word into which the
 // forward fast path stores the generation number of its launch when it meets a non-diagonal tile.  If

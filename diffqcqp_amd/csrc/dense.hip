@@ -11,6 +11,7 @@ namespace dqq {
 std::atomic<int> g_dense_block{1}; // 0: always the wave-per-problem kernel (option "dense_block")
 std::atomic<int> g_lane_dense{1};  // 0: never the lane-per-problem kernel of N <= 8 (option "lane_dense")
 std::atomic<int> g_dense_teams{1}; // 0: backward always one problem per wave (option "dense_teams")
+std::atomic<int> g_small_bwd{1};   // 0: never the statically sized team backward of N <= 8 (option "small_bwd")
 
 // Last wave out re-zeroes the work-list header for the next call.  With an empty work-list (the
 // common case: every tile was diagonal) there is nothing to reset and nobody touches the ticket --
@@ -177,6 +178,7 @@ static hipError_t launch_bwd_kind(const BwdArgs& a, bool use_worklist, hipStream
 hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
+    if (bwd_small_supported(kind, a.N) && g_small_bwd.load() != 0) return launch_bwd_small(kind, a, use_worklist, s);
     if (bwd_dense_block_supported(kind, a.N) && g_dense_block.load() != 0)
         return launch_bwd_dense_block(kind, a, use_worklist, s);
     if (kind == kKindBox) return launch_bwd_kind<2>(a, use_worklist, s);

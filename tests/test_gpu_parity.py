@@ -44,6 +44,7 @@ def ops():
     _capi.set_option("dense_block", 1)
     _capi.set_option("lane_dense", 1)
     _capi.set_option("dense_teams", 1)
+    _capi.set_option("small_bwd", 1)
 
 
 def dev(d):
@@ -313,6 +314,26 @@ def test_dense_backward_teams_agree_with_one_problem_per_wave(oracle, ops, kind,
     _capi.set_option("dense_teams", 1)
     for a, b in zip(out[0][0], out[1][0]):
         assert torch.equal(a, b)  # identical operation order -> identical bits
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("N,B", [(8, 1500), (6, 300), (4, 400), (2, 130)])
+def test_small_dense_backward_is_bit_exact_and_matches_the_wave_kernel(oracle, ops, kind, N, B):
+    """N <= 8, dense P: the statically sized team kernel (bwd_small.hip, default) keeps the reference's
+    operation order -- inactive multipliers are decoupled zero slots -- so it reproduces the oracle bit for bit
+    on identical x, like the run-time sized kernel behind it."""
+    from diffqcqp_amd import _capi
+    d = make_problem(kind, B, N, 700 + N, "dense")
+    g = dev(d)
+    xo, _ = oracle_fwd(oracle, kind, d)
+    ref = oracle_bwd(oracle, kind, d, xo)
+    out = {}
+    for opt in (1, 0):
+        _capi.set_option("small_bwd", opt)
+        out[opt] = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
+    _capi.set_option("small_bwd", 1)
+    check_backward_exact(out[1][0], out[1][1], ref, exact=True)
+    check_backward_exact(out[0][0], out[0][1], ref, exact=False)
 
 
 @pytest.mark.parametrize("N", [3, 5, 7])
