@@ -27,6 +27,7 @@ UNITS = {
     "bwd_small.hip": ["-ffp-contract=off"],
     "dense_block.hip": ["-ffp-contract=fast"],
     "fwd_lane_dense.hip": ["-ffp-contract=fast"],
+    "fwd_small.hip": ["-ffp-contract=fast"],
     "capi.hip": ["-ffp-contract=off", "-fvisibility=default"],
 }
 

@@ -11,6 +11,7 @@ extern std::atomic<int> g_dense_block;
 extern std::atomic<int> g_lane_dense;
 extern std::atomic<int> g_dense_teams;
 extern std::atomic<int> g_small_bwd;
+extern std::atomic<int> g_small_fwd;
 }
 
 namespace {
@@ -29,7 +30,8 @@ Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback"
                       {"dense_block", &dqq::g_dense_block},
                       {"lane_dense", &dqq::g_lane_dense},
                       {"dense_teams", &dqq::g_dense_teams},
-                      {"small_bwd", &dqq::g_small_bwd}};
+                      {"small_bwd", &dqq::g_small_bwd},
+                      {"small_fwd", &dqq::g_small_fwd}};
 
 // Performance hint of the AUTO layout (never affects results): a host-mapped word into which the
 // forward fast path stores the generation number of its launch when it meets a non-diagonal tile.  If
@@ -148,7 +150,7 @@ static int fwd_dispatch(int kind, dqq::FwdArgs& a, void* workspace, size_t works
     a.ws = static_cast<int*>(workspace);
     bool needs_fallback = true;
     int fuse = g_fuse.load();
-    if (fuse < 0 && dqq::fwd_lane_dense_supported(a.N)) {
+    if (fuse < 0 && (dqq::fwd_lane_dense_supported(a.N) || dqq::fwd_small_supported(a.N))) {
         a.hint = hint_device_pointer();
         if (a.hint != nullptr) {
             bool dense_before = false;
