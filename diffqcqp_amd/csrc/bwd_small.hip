@@ -1,5 +1,6 @@
-// bwd_small.hip -- general (dense P) backward for small N (2, 4, 6, 8): a dense 8x8 Delassus matrix is
-// what a real contact problem presents, and its backward is three to five times the work of its forward.
+// bwd_small.hip -- general (dense P) backward for small N (even, <= 16: up to 8 contacts): a dense Delassus
+// matrix is what a real contact problem presents, and its backward is three to five times the work of its
+// forward.
 //
 // Same composition as dense_core.h / the reference (pybindings.cpp:24-30, 39-45, 62-71 ->
 // Solver::dualFromPrimal*, solveDerivatives*, iterative_refinement, Solver.cpp:15-44, 125-196, 263-371,
@@ -363,7 +364,7 @@ static DQQ_D void small_bwd_problem(const double* __restrict__ P, const double* 
 }
 
 template <int KIND, int N>
-__global__ __launch_bounds__(256) void bwd_small_kernel(
+__global__ __launch_bounds__(256, (SmallSys<KIND, N>::M > 16 ? 1 : 2)) void bwd_small_kernel(
     const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ aux0,
     const double* __restrict__ aux1, const double* __restrict__ x, const double* __restrict__ grad_x,
     double* __restrict__ grad_P, double* __restrict__ grad_q, double* __restrict__ gout0, double* __restrict__ gout1,
@@ -419,7 +420,7 @@ static hipError_t launch_small(const BwdArgs& a, bool use_worklist, hipStream_t 
 bool bwd_small_supported(int kind, int N)
 {
     if (kind == kKindBox) return N == 2;
-    return (kind == kKindQP || kind == kKindQCQP) && (N == 2 || N == 4 || N == 6 || N == 8);
+    return (kind == kKindQP || kind == kKindQCQP) && N >= 2 && N <= 16 && N % 2 == 0;
 }
 
 hipError_t launch_bwd_small(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)
@@ -430,12 +431,12 @@ hipError_t launch_bwd_small(int kind, const BwdArgs& a, bool use_worklist, hipSt
         switch (kind) {                                                   \
         case 0: return launch_small<0, NN>(a, use_worklist, s);           \
         case 1: return launch_small<1, NN>(a, use_worklist, s);           \
-        case 2: return launch_small<2, NN>(a, use_worklist, s);           \
-        default: return hipErrorInvalidValue;                             \
+        default: break;                                                   \
         }                                                                 \
     }
-    DQQ_CASE(2) DQQ_CASE(4) DQQ_CASE(6) DQQ_CASE(8)
+    DQQ_CASE(2) DQQ_CASE(4) DQQ_CASE(6) DQQ_CASE(8) DQQ_CASE(10) DQQ_CASE(12) DQQ_CASE(14) DQQ_CASE(16)
 #undef DQQ_CASE
+    if (kind == kKindBox && a.N == 2) return launch_small<2, 2>(a, use_worklist, s);
     return hipErrorInvalidValue;
 }
 

@@ -93,7 +93,7 @@ hipError_t launch_fwd_small(int kind, const FwdArgs& a, bool use_worklist, hipSt
 bool fwd_dense_block_supported(int N);
 hipError_t launch_fwd_dense_block(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s);
 hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);
-// statically sized team backward for N = 2, 4, 6, 8, kinds 0-2 (bwd_small.hip); launch_bwd_dense routes to it
+// statically sized team backward for even N <= 16, QP / QCQP (bwd_small.hip); launch_bwd_dense routes to it
 bool bwd_small_supported(int kind, int N);
 hipError_t launch_bwd_small(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);
 // workgroup-per-problem QP backward for N = 32, 64 (dense_block.hip); launch_bwd_dense routes to it

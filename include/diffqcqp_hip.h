@@ -154,7 +154,7 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
  *                    problem per wave (0)
  *   "small_fwd"      general path, N = 10..16 forward: team-per-problem kernel (1, default) or the
  *                    wave-per-problem kernel (0)
- *   "small_bwd"      general path, N = 2..8 backward: statically sized team kernel (1, default) or the
+ *   "small_bwd"      general path, even N <= 16 backward (QP, QCQP): statically sized team kernel (1, default) or the
  *                    wave / team kernel with run-time sizes (0)
  *   "lane_dense"     general path, N = 2..8 forward: lane-per-problem kernel (1, default) or the
  *                    wave-per-problem kernel (0)

@@ -317,9 +317,9 @@ def test_dense_backward_teams_agree_with_one_problem_per_wave(oracle, ops, kind,
 
 
 @pytest.mark.parametrize("kind", ["qp", "qcqp"])
-@pytest.mark.parametrize("N,B", [(8, 1500), (6, 300), (4, 400), (2, 130)])
+@pytest.mark.parametrize("N,B", [(8, 1500), (6, 300), (4, 400), (2, 130), (10, 90), (12, 120), (16, 70)])
 def test_small_dense_backward_is_bit_exact_and_matches_the_wave_kernel(oracle, ops, kind, N, B):
-    """N <= 8, dense P: the statically sized team kernel (bwd_small.hip, default) keeps the reference's
+    """Even N <= 16, dense P: the statically sized team kernel (bwd_small.hip, default) keeps the reference's
     operation order -- inactive multipliers are decoupled zero slots -- so it reproduces the oracle bit for bit
     on identical x, like the run-time sized kernel behind it."""
     from diffqcqp_amd import _capi
