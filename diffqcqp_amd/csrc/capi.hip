@@ -12,6 +12,7 @@ extern std::atomic<int> g_lane_dense;
 extern std::atomic<int> g_dense_teams;
 extern std::atomic<int> g_small_bwd;
 extern std::atomic<int> g_small_fwd;
+extern std::atomic<int> g_block_bwd;
 }
 
 namespace {
@@ -31,7 +32,8 @@ Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback"
                       {"lane_dense", &dqq::g_lane_dense},
                       {"dense_teams", &dqq::g_dense_teams},
                       {"small_bwd", &dqq::g_small_bwd},
-                      {"small_fwd", &dqq::g_small_fwd}};
+                      {"small_fwd", &dqq::g_small_fwd},
+                      {"block_bwd", &dqq::g_block_bwd}};
 
 // Performance hint of the AUTO layout (never affects results): a host-mapped word into which the
 // forward fast path stores the generation number of its launch when it meets a non-diagonal tile.  If
@@ -170,7 +172,8 @@ static int bwd_dispatch(int kind, dqq::BwdArgs& a, void* workspace, size_t works
     if (a.B == 0) return 0;
     (void)hipGetLastError();
     const bool fast_ok = dqq::bwd_diag_supported(a.N);
-    const bool dense_ok = a.N <= dqq::dense_max_n(kind == 0 ? 0 : (kind == dqq::kKindBox ? 3 : 2));
+    const bool dense_ok = a.N <= dqq::dense_max_n(kind == 0 ? 0 : (kind == dqq::kKindBox ? 3 : 2)) ||
+                          dqq::bwd_block_sys_supported(kind, a.N);
     hipError_t e;
     if (a.layout == DQQ_P_DIAG) {
         if (!fast_ok) return DQQ_E_UNSUPPORTED_N;

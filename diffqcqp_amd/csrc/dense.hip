@@ -12,6 +12,7 @@ std::atomic<int> g_dense_block{1}; // 0: always the wave-per-problem kernel (opt
 std::atomic<int> g_lane_dense{1};  // 0: never the lane-per-problem kernel of N <= 8 (option "lane_dense")
 std::atomic<int> g_dense_teams{1}; // 0: backward always one problem per wave (option "dense_teams")
 std::atomic<int> g_small_fwd{1};   // 0: never the team-per-problem forward of N = 10..16 (option "small_fwd")
+std::atomic<int> g_block_bwd{0};   // 1: workgroup QCQP / box backward also where the wave kernel would do (option "block_bwd")
 std::atomic<int> g_small_bwd{1};   // 0: never the statically sized team backward of N <= 8 (option "small_bwd")
 
 // Last wave out re-zeroes the work-list header for the next call.  With an empty work-list (the
@@ -183,6 +184,12 @@ hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipSt
     if (bwd_small_supported(kind, a.N) && g_small_bwd.load() != 0) return launch_bwd_small(kind, a, use_worklist, s);
     if (bwd_dense_block_supported(kind, a.N) && g_dense_block.load() != 0)
         return launch_bwd_dense_block(kind, a, use_worklist, s);
+    // QCQP N = 32 / 64, box N = 16 / 32: workgroup kernel on the matrix cores.  It is the only general kernel
+    // beyond the wave kernel's 64 rows (QCQP N > 42, box N > 21); below that the wave kernel stays the default
+    // because it keeps the reference's summation order and these Tikhonov systems amplify rounding by up to
+    // cond(K) ~ 1e9 (option "block_bwd" = 1 prefers the 10x faster workgroup kernel).
+    if (bwd_block_sys_supported(kind, a.N) && (g_block_bwd.load() != 0 || a.N > dense_max_n(kind == kKindBox ? 3 : 2)))
+        return launch_bwd_block_sys(kind, a, use_worklist, s);
     if (kind == kKindBox) return launch_bwd_kind<2>(a, use_worklist, s);
     return kind == 0 ? launch_bwd_kind<0>(a, use_worklist, s) : launch_bwd_kind<1>(a, use_worklist, s);
 }

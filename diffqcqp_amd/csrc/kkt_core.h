@@ -297,12 +297,23 @@ struct BoxCoord {
 
     DQQ_HD void setup_dual(double p, double q, double x, double lo, double hi, double eps)
     {
+        setup_dual_rhs((-p) * x - q, x, lo, hi, eps);                  // -P*l - q, :301 (diagonal P)
+    }
+    // general P: rhs = (-P*l - q)_i computed by the caller; the dual system itself never involves P
+    DQQ_HD void setup_dual_rhs(double rhs, double x, double lo, double hi, double eps)
+    {
         aL = !(x - lo > eps);                                          // :268-274
         aU = !(x - hi < -eps);                                         // :275-282
         // the coordinate's row of Id2 (:291-300): -1 in the lower multiplier's column, +1 in the upper one's
         const double At[3][3] = {{aL ? -1.0 : 0.0, aU ? 1.0 : 0.0, 0.0}, {0, 0, 0}, {0, 0, 0}};
-        const double b[3] = {(-p) * x - q, 0.0, 0.0};                  // -P*l - q, :301
+        const double b[3] = {rhs, 0.0, 0.0};
         ir.setup(At, b);
+    }
+    // multipliers once the dual refinement loop has ended (:302-304)
+    DQQ_HD void finish_dual()
+    {
+        gamma_lo = aL ? ir.xs[0] : 0.0;
+        gamma_hi = aU ? ir.xs[1] : 0.0;
     }
     DQQ_HD void step_dual(double (&dsq)[3]) { ir.step(dsq); }           // dsq[2] is always 0
     DQQ_HD void setup_derivative(double p, double g)

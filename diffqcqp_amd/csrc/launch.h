@@ -96,6 +96,9 @@ hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipSt
 // statically sized team backward for even N <= 16, QP / QCQP (bwd_small.hip); launch_bwd_dense routes to it
 bool bwd_small_supported(int kind, int N);
 hipError_t launch_bwd_small(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);
+// workgroup-per-problem QCQP (N = 32, 64) / box QP (N = 16, 32) backward (bwd_block.hip)
+bool bwd_block_sys_supported(int kind, int N);
+hipError_t launch_bwd_block_sys(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);
 // workgroup-per-problem QP backward for N = 32, 64 (dense_block.hip); launch_bwd_dense routes to it
 bool bwd_dense_block_supported(int kind, int N);
 hipError_t launch_bwd_dense_block(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);

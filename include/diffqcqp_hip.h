@@ -138,7 +138,7 @@ int dqq_signedboxqp_fwd_f64(const double* P, const double* q, const double* l_mi
  * Any output may be NULL.  gamma / dgamma (B,2N: lower multipliers | upper multipliers, may be NULL) are the
  * reference's per-problem return values: gamma, and blgamma[0:2N]; blgamma[2N:3N] = -grad_q.
  * ir_steps (B,2 ints, may be NULL): refinement steps of the dual recovery and of the derivative system.
- * General (non-diagonal) P: N <= dqq_max_n(3) = 21 this round. */
+ * General (non-diagonal) P: N <= dqq_max_n(3) = 21, and N = 32. */
 int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, const double* l_max, const double* x,
                       const double* grad_x, double* grad_P, double* grad_q, double* grad_l_min, double* grad_l_max,
                       double* gamma, double* dgamma, int64_t B, int N, double epsilon, int p_layout, int* ir_steps,
@@ -152,6 +152,9 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
  *                    for the dense kernel launched behind it (0), or decide from B (-1, default)
  *   "dense_teams"    general path, backward: pack 64/T problems per wave for small N (1, default) or one
  *                    problem per wave (0)
+ *   "block_bwd"      general path, QCQP N = 32 / box QP N = 16 backward: workgroup kernel on the matrix cores
+ *                    (1) or the wave kernel in the reference's summation order (0, default).  QCQP N = 64 and
+ *                    box QP N = 32 always use the workgroup kernel (no other kernel holds their systems).
  *   "small_fwd"      general path, N = 10..16 forward: team-per-problem kernel (1, default) or the
  *                    wave-per-problem kernel (0)
  *   "small_bwd"      general path, even N <= 16 backward (QP, QCQP): statically sized team kernel (1, default) or the

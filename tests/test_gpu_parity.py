@@ -91,7 +91,7 @@ def check_forward(xh, ith, xo, ito, min_match=0.999):
     assert np.median(diff.max(axis=(1, 2))) < 1e-11
 
 
-def check_end_to_end(grads, steps, ref, max_flip=0.08):
+def check_end_to_end(grads, steps, ref, max_flip=0.08, tol=1e-6):
     """x came from the HIP forward: compare where the refinement exit agrees (see module docstring)."""
     *gref, sref = ref
     same = npy(steps) == sref
@@ -100,7 +100,7 @@ def check_end_to_end(grads, steps, ref, max_flip=0.08):
         a, b = npy(a)[same], b[same]
         if a.size:
             scale = np.maximum(1.0, np.abs(b).reshape(b.shape[0], -1).max(1)).reshape((-1,) + (1,) * (b.ndim - 1))
-            assert (np.abs(a - b) / scale).max() <= 1e-6
+            assert (np.abs(a - b) / scale).max() <= tol
 
 
 def check_backward_exact(grads, steps, ref, exact=True, rtol=1e-9):
@@ -336,6 +336,38 @@ def test_small_dense_backward_is_bit_exact_and_matches_the_wave_kernel(oracle, o
     check_backward_exact(out[0][0], out[0][1], ref, exact=False)
 
 
+@pytest.mark.parametrize("kind,N,B", [("qcqp", 32, 96), ("qcqp", 64, 40), ("box", 16, 128), ("box", 32, 48)])
+def test_workgroup_backward_for_large_systems(oracle, ops, kind, N, B):
+    """QCQP at N = 32 / 64 and box QP at N = 16 / 32 (48 / 96 unknowns): workgroup-per-problem backward on the
+    matrix cores (bwd_block.hip) -- the only kernel for QCQP N = 64 / box N = 32, opt-in ("block_bwd") below.
+    Its tile products associate sums differently from the oracle's loops; the Tikhonov systems of this
+    backward have cond(K) up to ~1e9 (active contacts: K has eigenvalues next to mu = 1e-7), which turns 1e-16
+    into up to ~1e-5 relative on a few problems -- the reference itself would show the same against another
+    BLAS.  Hence: gradients within 1e-4 where the refinement exits agree, median error below 1e-7."""
+    from diffqcqp_amd import _capi
+    d = make_problem(kind, B, N, 730 + N, "dense")
+    g = dev(d)
+    _capi.set_option("block_bwd", 1)
+    try:
+        if kind == "qcqp":
+            xo, _ = oracle_fwd(oracle, kind, d)
+            ref = oracle_bwd(oracle, kind, d, xo)
+            grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
+            check_end_to_end(grads, st, ref, max_flip=0.2, tol=1e-4)
+            same = npy(st) == ref[-1]
+            assert np.median(np.abs(npy(grads[1]) - ref[1])[same].max(axis=(1, 2))) < 1e-7
+        else:
+            xo, _ = oracle.boxqp_fwd_batch(d["P"].numpy(), d["q"].numpy(), d["l_min"].numpy(), d["l_max"].numpy(), 1e-7,
+                                           1000, nthreads=8)
+            ref, out, duals = _box_bwd(oracle, ops, d, xo, layout=_capi.P_DENSE)
+            assert np.array_equal(npy(out[4])[:, 0], ref[5][:, 0])      # dual recovery: per-coordinate blocks, exact
+            assert np.array_equal(npy(duals[0]), ref[4])
+            check_end_to_end(list(out[:4]), out[4][:, 1], (ref[0], ref[1], ref[2], ref[3], ref[5][:, 1]), max_flip=0.2,
+                             tol=1e-4)
+    finally:
+        _capi.set_option("block_bwd", 0)
+
+
 @pytest.mark.parametrize("N", [3, 5, 7])
 def test_dense_kernel_odd_n_qp(oracle, ops, N):
     d = make_problem("qp", 60, N, 600 + N, "dense")
@@ -541,7 +573,7 @@ def test_box_end_to_end_and_unsupported_n(oracle, ops):
     ref, out, _ = _box_bwd(oracle, ops, d, npy(xh))
     check_end_to_end(list(out[:4]), out[4][:, 1], (ref[0], ref[1], ref[2], ref[3], ref[5][:, 1]))
     assert _capi.lib().dqq_max_n(3) == 21
-    big = dev(make_problem("box", 4, 32, 891, "dense"))
+    big = dev(make_problem("box", 4, 24, 891, "dense"))  # 22..31 and > 32: no general box backward
     with pytest.raises(ValueError, match="UNSUPPORTED_N"):
         ops.boxqp_backward(big["P"], big["q"], big["l_min"], big["l_max"], big["q"], big["grad_x"], layout=_capi.P_DENSE)
 
