@@ -321,19 +321,30 @@ def main():
             "algo_GBps": ALGO_BYTES[name] * B_PER_GPU / (mean_ms * 1e-3) / 1e9,
         }
     dom = max(kernels, key=lambda k: kernels[k]["mean_us"])
-    traffic = None
+    traffic, valu = None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
+            pmc = json.load(open(pmc_path)).get(dom, {})
+            traffic = pmc.get("hbm_bytes_per_launch")
+            if "SQ_INSTS_VALU" in pmc:
+                # second ceiling of the same kernel: FP64 VALU issue.  Wave-level VALU instructions of one launch
+                # (SQ_INSTS_VALU, rocprofv3 PMC pass) spread over the chip's 1024 SIMDs, at the measured issue
+                # floor of a wave64 fp64 instruction (tools/ubench/fp64_issue.hip: 2.08 ns; 4 cycles at 2.4 GHz
+                # would be 1.67 ns).  Almost every VALU instruction of this kernel is fp64.
+                floor_us = pmc["SQ_INSTS_VALU"] / 1024.0 * 2.08e-3
+                valu = {"valu_insts_per_launch": pmc["SQ_INSTS_VALU"], "valu_insts_per_wave": pmc.get("valu_insts_per_wave"),
+                        "issue_floor_ns_per_wave_inst": 2.08, "floor_us": floor_us,
+                        "frac": floor_us / kernels[dom]["mean_us"]}
         except Exception:
-            traffic = None
+            traffic, valu = None, None
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["algo_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": kernels[dom]["algo_GBps"] / HBM_PEAK_GBS, "traffic": traffic,
         "frac_vs_measured_copy_bw_6290": kernels[dom]["algo_GBps"] / 6290.0,
         "step_algo_GBps": sum(ALGO_BYTES.values()) * B_PER_GPU / (sum(k["mean_us"] for k in kernels.values()) * 1e-6) / 1e9,
         "step_algo_GBps_as_timed": sum(ALGO_BYTES.values()) * B_PER_GPU / (elapsed / args.steps) / 1e9,
+        "fp64_valu_issue": valu,
     }
 
     if rank != 0:

@@ -65,6 +65,9 @@ def main():
         key = bench_key(k)
         if key and "hbm_bytes_per_launch" in v:
             latest[key] = {"kernel": k, "hbm_bytes_per_launch": v["hbm_bytes_per_launch"]}
+            for extra in ("SQ_INSTS_VALU", "SQ_WAVES", "valu_insts_per_wave"):
+                if extra in v:
+                    latest[key][extra] = v[extra]
     json.dump(pmc, open(os.path.join(outdir, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
     json.dump(latest, open(os.path.join(outdir, "pmc_latest.json"), "w"), indent=1, sort_keys=True)
     for r in rows[:10]:
