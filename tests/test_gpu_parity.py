@@ -792,3 +792,40 @@ def test_full_size_config4_per_gpu_shard(oracle, ops):
     check_forward(x[idx.cuda()], it[idx.cuda()], xo, ito)
     gs, sts = hip_bwd(ops, "qp", dev(ds), torch.from_numpy(xo).cuda())
     check_backward_exact(gs, sts, oracle_bwd(oracle, "qp", ds, xo))
+
+
+def test_full_size_config5_dense_n64(oracle, ops):
+    """configs[4] at its full size: B=65536, N=64, dense P = S S^T/64 + 0.1 I (generated on the device), QP
+    forward + backward.  Size-independent properties: feasibility, the natural KKT residual |min(x, Px+q)|,
+    grad_P = grad_q (x) x; plus the oracle on a sample of the batch."""
+    B, N = 65536, 64
+    gen = torch.Generator(device="cuda").manual_seed(1005)
+    S = torch.rand(B, N, N, generator=gen, dtype=torch.float64, device="cuda")
+    P = torch.bmm(S, S.transpose(1, 2)) / N
+    del S
+    P.diagonal(dim1=1, dim2=2).add_(0.1)
+    q = 2 * torch.rand(B, N, 1, generator=gen, dtype=torch.float64, device="cuda") - 1
+    gx = torch.randn(B, N, 1, generator=gen, dtype=torch.float64, device="cuda")
+    x, it = ops.qp_forward(P, q, 1e-7, 1000, return_iters=True)
+    assert int(it.max()) < 1000 and bool((x >= 0).all())
+    r = torch.bmm(P, x) + q
+    # Reference quirk (Solver.cpp:88): the loop stops on the dual residual rho*|l_2 - l_2_pred| alone, so an
+    # iterate that the projection maps to the same point twice in a row (typically x = 0) is returned whatever
+    # its primal residual is.  A handful of problems in 65536 end that way; they must be exactly what the
+    # oracle returns, and every other problem must satisfy the KKT conditions.
+    nat = torch.minimum(x, r).abs().amax(dim=(1, 2))               # complementarity / dual feasibility
+    odd = torch.nonzero(nat > 1e-5)[:, 0]
+    assert odd.numel() <= B // 1000
+    if odd.numel():
+        dq = {"P": P[odd].cpu(), "q": q[odd].cpu()}
+        xq, itq = oracle_fwd(oracle, "qp", dq)
+        assert np.array_equal(npy(it[odd]), itq) and np.abs(npy(x[odd]) - xq).max() <= 1e-9
+    gP, gq, st = ops.qp_backward(P, q, x, gx, return_steps=True)
+    assert torch.equal(gP, gq * x.transpose(1, 2))                  # qcqp.py:48-51
+    assert int(st.max()) <= 10 and bool(torch.isfinite(gq).all())
+    idx = torch.arange(0, B, 2048, device="cuda")
+    d = {"P": P[idx].cpu(), "q": q[idx].cpu(), "grad_x": gx[idx].cpu()}
+    xo, ito = oracle_fwd(oracle, "qp", d)
+    check_forward(x[idx], it[idx], xo, ito, min_match=0.9)
+    gs, sts = hip_bwd(ops, "qp", dev(d), torch.from_numpy(xo).cuda())
+    check_backward_exact(gs, sts, oracle_bwd(oracle, "qp", d, xo), exact=False)
