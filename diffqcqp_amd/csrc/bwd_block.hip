@@ -1,5 +1,6 @@
-// bwd_block.hip -- general (dense P) backward for the systems too large for one wave: QCQP at N = 32 / 64
-// (48 / 96 unknowns) and box QP at N = 16 / 32 (48 / 96 unknowns).  One 256-thread workgroup per problem,
+// bwd_block.hip -- general (dense P) backward for the systems too large for one wave (more than 64 unknowns:
+// QCQP 42 < N <= 64, box QP 21 < N <= 32) and, on request, for QCQP N = 32 / box QP N = 16.  The system is
+// padded with decoupled zero slots to MP = 48, 80 or 96 unknowns.  One 256-thread workgroup per problem,
 // the normal-equations solve of Solver::iterative_refinement (Solver.cpp:15-44) on the f64 matrix cores
 // (block_core.h), as in the QP backward of dense_block.hip.
 //
@@ -19,27 +20,29 @@
 
 namespace dqq {
 
-template <int KIND, int N>
+template <int MP>
 struct BlockSys {
-    static constexpr int NC = N / 2;
-    static constexpr int M = (KIND == 1) ? N + NC : 3 * N;
-    using G = BlockGeom<M>;
-    static constexpr int VEC = 8 * M;
+    using G = BlockGeom<MP>;
+    static constexpr int VEC = 8 * MP;
     static constexpr size_t LDS_BYTES = sizeof(double) * (2 * G::REGION + VEC + 2);
-    static_assert(M % 16 == 0 && M <= 96, "48 or 96 unknowns");
+    static_assert(MP % 16 == 0 && MP <= 96, "at most 96 unknowns");
 };
 
-template <int KIND, int N>
+// MP: padded number of unknowns (multiple of 16); N (run time): N + N/2 <= MP (QCQP) or 3N <= MP (box QP).
+// Slots beyond the problem's own unknowns are zero rows / columns of A (K = mu_ir there).
+template <int KIND, int MP>
 __global__ __launch_bounds__(256, 1) void bwd_block_kernel(
     const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ aux0,
     const double* __restrict__ aux1, const double* __restrict__ x, const double* __restrict__ grad_x,
     double* __restrict__ grad_P, double* __restrict__ grad_q, double* __restrict__ gout0, double* __restrict__ gout1,
-    double* __restrict__ gamma_out, double* __restrict__ dgamma_out, long B, double dual_eps, int* __restrict__ ir_steps,
-    int* __restrict__ ws, int use_worklist)
+    double* __restrict__ gamma_out, double* __restrict__ dgamma_out, long B, int N, double dual_eps,
+    int* __restrict__ ir_steps, int* __restrict__ ws, int use_worklist)
 {
-    using S = BlockSys<KIND, N>;
+    using S = BlockSys<MP>;
     using G = typename S::G;
-    constexpr int M = S::M, NC = S::NC, LD = G::LD;
+    constexpr int M = MP, LD = G::LD;
+    const int NC = N / 2;
+    const int MU = (KIND == 1) ? N + NC : 3 * N; // unknowns in use
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* X = smem;                 // K -> L -> K^-1
     double* Y = X + G::REGION;        // A -> LinvT
@@ -98,7 +101,9 @@ __global__ __launch_bounds__(256, 1) void bwd_block_kernel(
             for (int idx = t; idx < M * M; idx += 256) {
                 const int r = idx / M, c = idx % M;
                 double val = 0.0;
-                if (r < NC) {
+                if (r >= MU || c >= MU) {
+                    // padding slot
+                } else if (r < NC) {
                     if (vact[r] != 0.0) {
                         if (c == r) val = vS[r];
                         else if (c == NC + 2 * r || c == NC + 2 * r + 1) val = vgam[r] * (2 * vx[c - NC]);
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(256, 1) void bwd_block_kernel(
                 }
                 Y[r * LD + c] = val;
             }
-            if (has) vb[t] = (t < NC) ? 0.0 : grad_x[prob * N + (t - NC)];    // :659-667
+            if (has) vb[t] = (t < NC || t >= MU) ? 0.0 : grad_x[prob * N + (t - NC)];    // :659-667
         } else {
             double* vgam = vw;          // 2N, slots (2i lower, 2i+1 upper)
             double* vact = vw + 2 * N;  // 2N
@@ -150,7 +155,9 @@ __global__ __launch_bounds__(256, 1) void bwd_block_kernel(
             for (int idx = t; idx < M * M; idx += 256) {
                 const int r = idx / M, c = idx % M;
                 double val = 0.0;
-                if (r < 2 * N) {
+                if (r >= MU || c >= MU) {
+                    // padding slot
+                } else if (r < 2 * N) {
                     if (c == 2 * N + r / 2 && vact[r] != 0.0) val = vgam[r] * ((r & 1) ? 1.0 : -1.0);
                 } else {
                     const int i = r - 2 * N;
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256, 1) void bwd_block_kernel(
                 }
                 Y[r * LD + c] = val;
             }
-            if (has) vb[t] = (t < 2 * N) ? 0.0 : grad_x[prob * N + (t - 2 * N)]; // :352-360
+            if (has) vb[t] = (t < 2 * N || t >= MU) ? 0.0 : grad_x[prob * N + (t - 2 * N)]; // :352-360
         }
         __syncthreads();
         // A^T_t b = A b (:19); iterative_refinement is handed A^T (transposeInPlace, :351 / :658)
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(256, 1) void bwd_block_kernel(
         }
         // vxs holds the solution: multipliers' slots first, then dl
         const bool failed = *fail_flag != 0.0;
-        constexpr int L0 = (KIND == 1) ? NC : 2 * N; // first dl slot
+        const int L0 = (KIND == 1) ? NC : 2 * N; // first dl slot
         if constexpr (KIND == 1) {
             if (t < NC) {
                 const double ln = aux0[prob * NC + t], mc = aux1[prob * NC + t];
@@ -250,37 +257,46 @@ __global__ __launch_bounds__(256, 1) void bwd_block_kernel(
     }
 }
 
-template <int KIND, int N>
+template <int KIND, int MP>
 static hipError_t launch_bwd_block_sys(const BwdArgs& a, bool use_worklist, hipStream_t s)
 {
-    using S = BlockSys<KIND, N>;
-    auto kernel = bwd_block_kernel<KIND, N>;
+    using S = BlockSys<MP>;
+    auto kernel = bwd_block_kernel<KIND, MP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
     if (e != hipSuccess) return e;
     const long cap = 256L * 8;
     const unsigned grid = use_worklist ? 512u : (unsigned)(a.B < cap ? (a.B > 0 ? a.B : 1) : cap);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), S::LDS_BYTES, s, a.P, a.q, a.l_n, a.mu, a.x, a.grad_x, a.grad_P,
-                       a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.epsilon, a.ir_steps, a.ws,
+                       a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.N, a.epsilon, a.ir_steps, a.ws,
                        use_worklist ? 1 : 0);
     return hipGetLastError();
 }
 
+// unknowns of the derivative system
+static int block_sys_unknowns(int kind, int N) { return kind == kKindQCQP ? N + N / 2 : 3 * N; }
+
 bool bwd_block_sys_supported(int kind, int N)
 {
-    if (kind == kKindQCQP) return N == 32 || N == 64;
-    if (kind == kKindBox) return N == 16 || N == 32;
-    return false;
+    if (kind != kKindQCQP && kind != kKindBox) return false;
+    if (kind == kKindQCQP && (N % 2) != 0) return false;
+    const int m = block_sys_unknowns(kind, N);
+    return N >= 1 && m <= 96 && m >= 33; // below that the wave kernel is the faster faithful choice anyway
 }
 
 hipError_t launch_bwd_block_sys(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
-    if (kind == kKindQCQP && a.N == 32) return launch_bwd_block_sys<1, 32>(a, use_worklist, s);
-    if (kind == kKindQCQP && a.N == 64) return launch_bwd_block_sys<1, 64>(a, use_worklist, s);
-    if (kind == kKindBox && a.N == 16) return launch_bwd_block_sys<2, 16>(a, use_worklist, s);
-    if (kind == kKindBox && a.N == 32) return launch_bwd_block_sys<2, 32>(a, use_worklist, s);
-    return hipErrorInvalidValue;
+    if (!bwd_block_sys_supported(kind, a.N)) return hipErrorInvalidValue;
+    const int m = block_sys_unknowns(kind, a.N);
+    if (kind == kKindQCQP) {
+        if (m <= 48) return launch_bwd_block_sys<1, 48>(a, use_worklist, s);
+        if (m <= 80) return launch_bwd_block_sys<1, 80>(a, use_worklist, s);
+        return launch_bwd_block_sys<1, 96>(a, use_worklist, s);
+    }
+    if (m <= 48) return launch_bwd_block_sys<2, 48>(a, use_worklist, s);
+    if (m <= 80) return launch_bwd_block_sys<2, 80>(a, use_worklist, s);
+    return launch_bwd_block_sys<2, 96>(a, use_worklist, s);
 }
 
 } // namespace dqq

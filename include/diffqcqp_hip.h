@@ -62,8 +62,9 @@ extern "C" {
  * streams. */
 size_t dqq_workspace_bytes(int64_t B);
 
-/* Largest N accepted by the general kernels: kind 0 = QP forward/backward and the box forwards, 1 = QCQP
- * forward, 2 = QCQP backward, 3 = box QP backward. */
+/* Largest N the wave-per-problem general kernels hold: kind 0 = QP forward/backward and the box forwards
+ * (64), 1 = QCQP forward (64), 2 = QCQP backward (42), 3 = box QP backward (21).  The workgroup-per-problem
+ * backward takes over beyond 2 and 3: QCQP backward accepts every even N <= 64, box QP backward N <= 32. */
 int dqq_max_n(int kind);
 
 /* Replaces the loop qcqp.py:29-31 (QPFn2.forward -> diffqcqp.solveQP,
@@ -138,7 +139,7 @@ int dqq_signedboxqp_fwd_f64(const double* P, const double* q, const double* l_mi
  * Any output may be NULL.  gamma / dgamma (B,2N: lower multipliers | upper multipliers, may be NULL) are the
  * reference's per-problem return values: gamma, and blgamma[0:2N]; blgamma[2N:3N] = -grad_q.
  * ir_steps (B,2 ints, may be NULL): refinement steps of the dual recovery and of the derivative system.
- * General (non-diagonal) P: N <= dqq_max_n(3) = 21, and N = 32. */
+ * General (non-diagonal) P: N <= 32 (wave kernel up to dqq_max_n(3) = 21, workgroup kernel beyond). */
 int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, const double* l_max, const double* x,
                       const double* grad_x, double* grad_P, double* grad_q, double* grad_l_min, double* grad_l_max,
                       double* gamma, double* dgamma, int64_t B, int N, double epsilon, int p_layout, int* ir_steps,
@@ -152,9 +153,9 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
  *                    for the dense kernel launched behind it (0), or decide from B (-1, default)
  *   "dense_teams"    general path, backward: pack 64/T problems per wave for small N (1, default) or one
  *                    problem per wave (0)
- *   "block_bwd"      general path, QCQP N = 32 / box QP N = 16 backward: workgroup kernel on the matrix cores
- *                    (1) or the wave kernel in the reference's summation order (0, default).  QCQP N = 64 and
- *                    box QP N = 32 always use the workgroup kernel (no other kernel holds their systems).
+ *   "block_bwd"      general path, QCQP 22 <= N <= 42 / box QP 11 <= N <= 21 backward: workgroup kernel on the
+ *                    matrix cores (1) or the wave kernel in the reference's summation order (0, default).
+ *                    Larger systems (QCQP N <= 64, box QP N <= 32) always use the workgroup kernel.
  *   "small_fwd"      general path, N = 10..16 forward: team-per-problem kernel (1, default) or the
  *                    wave-per-problem kernel (0)
  *   "small_bwd"      general path, even N <= 16 backward (QP, QCQP): statically sized team kernel (1, default) or the

@@ -336,10 +336,11 @@ def test_small_dense_backward_is_bit_exact_and_matches_the_wave_kernel(oracle, o
     check_backward_exact(out[0][0], out[0][1], ref, exact=False)
 
 
-@pytest.mark.parametrize("kind,N,B", [("qcqp", 32, 96), ("qcqp", 64, 40), ("box", 16, 128), ("box", 32, 48)])
+@pytest.mark.parametrize("kind,N,B", [("qcqp", 32, 96), ("qcqp", 64, 40), ("box", 16, 128), ("box", 32, 48),
+                                      ("qcqp", 50, 24), ("qcqp", 44, 24), ("box", 26, 30), ("box", 22, 30)])
 def test_workgroup_backward_for_large_systems(oracle, ops, kind, N, B):
-    """QCQP at N = 32 / 64 and box QP at N = 16 / 32 (48 / 96 unknowns): workgroup-per-problem backward on the
-    matrix cores (bwd_block.hip) -- the only kernel for QCQP N = 64 / box N = 32, opt-in ("block_bwd") below.
+    """Systems of up to 96 unknowns, padded to 48 / 80 / 96 slots: workgroup-per-problem backward on the matrix
+    cores (bwd_block.hip) -- the only kernel for QCQP 42 < N <= 64 / box 21 < N <= 32, opt-in ("block_bwd") below.
     Its tile products associate sums differently from the oracle's loops; the Tikhonov systems of this
     backward have cond(K) up to ~1e9 (active contacts: K has eigenvalues next to mu = 1e-7), which turns 1e-16
     into up to ~1e-5 relative on a few problems -- the reference itself would show the same against another
@@ -573,7 +574,7 @@ def test_box_end_to_end_and_unsupported_n(oracle, ops):
     ref, out, _ = _box_bwd(oracle, ops, d, npy(xh))
     check_end_to_end(list(out[:4]), out[4][:, 1], (ref[0], ref[1], ref[2], ref[3], ref[5][:, 1]))
     assert _capi.lib().dqq_max_n(3) == 21
-    big = dev(make_problem("box", 4, 24, 891, "dense"))  # 22..31 and > 32: no general box backward
+    big = dev(make_problem("box", 4, 40, 891, "dense"))  # 3N > 96 unknowns: no general box backward
     with pytest.raises(ValueError, match="UNSUPPORTED_N"):
         ops.boxqp_backward(big["P"], big["q"], big["l_min"], big["l_max"], big["q"], big["grad_x"], layout=_capi.P_DENSE)
 
