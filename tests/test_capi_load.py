@@ -51,8 +51,10 @@ def test_argument_validation_without_gpu(lib):
     assert f(one, one, one, 0, 8, 1e-7, 1e-7, 10, 1, 0, None, None, None, None, 0, None) == 0   # empty batch: no-op
     g = lib.dqq_qcqp_fwd_f64
     assert g(one, one, one, one, one, 4, 7, 1e-7, 1e-7, 10, 1, 0, None, None, None, None, 0, None) == -2  # odd N
-    assert lib.dqq_qcqp_bwd_f64(one, one, one, one, one, one, None, None, None, None, None, None, 4, 48, 1e-10, 1,
+    assert lib.dqq_qcqp_bwd_f64(one, one, one, one, one, one, None, None, None, None, None, None, 4, 66, 1e-10, 1,
                                 None, None, None, None, 0, None) == -3
+    assert lib.dqq_boxqp_bwd_f64(one, one, one, one, one, one, None, None, None, None, None, None, 4, 34, 1e-10, 1,
+                                 None, None, None, None, 0, None) == -3  # 3N > 96 unknowns
     assert lib.dqq_set_option(b"no_such_knob", 1) == -6
 
 
