@@ -77,3 +77,15 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "liboracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/diffqcqp_hip.h is the C ABI: it must compile as C99 (no C++ or torch types) and link against
+    the library by name."""
+    import subprocess
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "diffqcqp_hip.h"\n'
+                   "int main(void) { return dqq_max_n(0) == 64 && dqq_workspace_bytes(0) >= 16 ? 0 : 1; }\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                           "-c", str(src), "-o", str(tmp_path / "use_header.o")])
