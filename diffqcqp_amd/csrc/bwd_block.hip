@@ -248,13 +248,7 @@ __global__ __launch_bounds__(256, 1) void bwd_block_kernel(
             }
         }
     }
-    if (use_worklist && count > 0 && t == 0) {
-        const int tk = atomicAdd(&ws[kWsTicket], 1);
-        if (tk == (int)gridDim.x - 1) {
-            ws[kWsCount] = 0;
-            ws[kWsTicket] = 0;
-        }
-    }
+    if (use_worklist && t == 0) worklist_release(ws, count, (int)gridDim.x);
 }
 
 template <int KIND, int MP>

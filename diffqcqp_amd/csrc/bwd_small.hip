@@ -384,13 +384,7 @@ __global__ __launch_bounds__(256, (SmallSys<KIND, N>::M > 16 ? 1 : 2)) void bwd_
         small_bwd_problem<KIND, N>(P, q, aux0, aux1, x, grad_x, grad_P, grad_q, gout0, gout1, gamma_out, dgamma_out,
                                    ir_steps, prob, dual_eps, sw, tl);
     }
-    if (use_worklist && count > 0 && lane == 0) { // last wave out re-zeroes the work-list header
-        const int tk = atomicAdd(&ws[kWsTicket], 1);
-        if (tk == (int)(gridDim.x * wpb) - 1) {
-            ws[kWsCount] = 0;
-            ws[kWsTicket] = 0;
-        }
-    }
+    if (use_worklist && lane == 0) worklist_release(ws, count, (int)(gridDim.x * wpb));
 }
 
 template <int KIND, int N>

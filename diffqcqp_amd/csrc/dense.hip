@@ -15,19 +15,6 @@ std::atomic<int> g_small_fwd{1};   // 0: never the team-per-problem forward of N
 std::atomic<int> g_block_bwd{0};   // 1: workgroup QCQP / box backward also where the wave kernel would do (option "block_bwd")
 std::atomic<int> g_small_bwd{1};   // 0: never the statically sized team backward of N <= 8 (option "small_bwd")
 
-// Last wave out re-zeroes the work-list header for the next call.  With an empty work-list (the
-// common case: every tile was diagonal) there is nothing to reset and nobody touches the ticket --
-// hundreds of same-address atomics would otherwise serialise into ~13 us of an otherwise empty launch.
-static DQQ_D void worklist_release(int* ws, int lane, long count, int nwaves)
-{
-    if (count > 0 && lane == 0) {
-        const int t = atomicAdd(&ws[kWsTicket], 1);
-        if (t == nwaves - 1) {
-            ws[kWsCount] = 0;
-            ws[kWsTicket] = 0;
-        }
-    }
-}
 
 // Workgroups hold `wpb` independent waves (wave-private LDS slices, no workgroup barrier): more waves
 // per dispatched workgroup keeps the launch cheap when the work-list turns out to be empty.
@@ -49,7 +36,7 @@ __global__ __launch_bounds__(256) void fwd_dense_kernel(const double* __restrict
         const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
         dense_fwd_problem<KIND>(P, q, l_n, mu_c, v_sign, x, iters, prob, n, eps, mu, max_iter, adaptive, sw, lane);
     }
-    if (use_worklist) worklist_release(ws, lane, count, (int)nwaves);
+    if (use_worklist && lane == 0) worklist_release(ws, count, (int)nwaves);
 }
 
 // Backward: 64/T problems per wave (dense_core.h: team width T), each team in its own LDS slice.
@@ -73,7 +60,7 @@ __global__ __launch_bounds__(256) void bwd_dense_kernel(
         dense_bwd_problem<KIND, T>(P, q, l_n, mu_c, x, grad_x, grad_P, grad_q, grad_l_n, grad_mu, gamma_out, dgamma_out,
                                    ir_steps, prob, n, dual_eps, sw, tl);
     }
-    if (use_worklist) worklist_release(ws, lane, count, (int)(gridDim.x * wpb));
+    if (use_worklist && lane == 0) worklist_release(ws, count, (int)(gridDim.x * wpb));
 }
 
 // ---------------------------------------------------------------- launchers

@@ -253,13 +253,7 @@ __global__ __launch_bounds__(256, N == 32 ? 3 : 2) void fwd_dense_block_kernel(c
         if (iters != nullptr && t == 0) iters[prob] = it_done;
     }
     // last workgroup out re-zeroes the work-list header (nothing to do when the list was empty)
-    if (use_worklist && count > 0 && t == 0) {
-        const int tk = atomicAdd(&ws[kWsTicket], 1);
-        if (tk == (int)gridDim.x - 1) {
-            ws[kWsCount] = 0;
-            ws[kWsTicket] = 0;
-        }
-    }
+    if (use_worklist && t == 0) worklist_release(ws, count, (int)gridDim.x);
 }
 
 template <int KIND, int N>
@@ -408,13 +402,7 @@ __global__ __launch_bounds__(256, 2) void bwd_dense_block_qp_kernel(const double
         if (ir_steps != nullptr && t == 0) ir_steps[prob] = steps;
         __syncthreads(); // X / Y / the failure flag are free for the next problem
     }
-    if (use_worklist && count > 0 && t == 0) {
-        const int tk = atomicAdd(&ws[kWsTicket], 1);
-        if (tk == (int)gridDim.x - 1) {
-            ws[kWsCount] = 0;
-            ws[kWsTicket] = 0;
-        }
-    }
+    if (use_worklist && t == 0) worklist_release(ws, count, (int)gridDim.x);
 }
 
 template <int N>

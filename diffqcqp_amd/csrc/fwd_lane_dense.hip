@@ -87,13 +87,7 @@ __global__ __launch_bounds__(64, 1) void fwd_lane_dense_kernel(const double* __r
     const long slot = (long)blockIdx.x * 64 + threadIdx.x;
     const bool valid = slot < count;
     if ((long)blockIdx.x * 64 >= count) { // a wave beyond the end of the work-list: only the reset ticket
-        if (use_worklist && count > 0 && threadIdx.x == 0) {
-            const int tk = atomicAdd(&ws[kWsTicket], 1);
-            if (tk == (int)gridDim.x - 1) {
-                ws[kWsCount] = 0;
-                ws[kWsTicket] = 0;
-            }
-        }
+        if (use_worklist && threadIdx.x == 0) worklist_release(ws, count, (int)gridDim.x);
         return;
     }
     const long prob = valid ? (use_worklist ? (long)ws[kWsEntries + slot] : slot) : 0;
@@ -293,14 +287,7 @@ __global__ __launch_bounds__(64, 1) void fwd_lane_dense_kernel(const double* __r
                 make_double2(bad ? NAN : l2[i], bad ? NAN : l2[i + 1]);
         if (iters != nullptr) iters[prob] = it_done;
     }
-    // work-list mode: the last wave out re-zeroes the header (nothing to do for an empty list)
-    if (use_worklist && count > 0 && threadIdx.x == 0) {
-        const int tk = atomicAdd(&ws[kWsTicket], 1);
-        if (tk == (int)gridDim.x - 1) {
-            ws[kWsCount] = 0;
-            ws[kWsTicket] = 0;
-        }
-    }
+    if (use_worklist && threadIdx.x == 0) worklist_release(ws, count, (int)gridDim.x);
 }
 
 template <int KIND, int N>

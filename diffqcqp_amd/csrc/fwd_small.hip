@@ -118,13 +118,7 @@ __global__ __launch_bounds__(256, N >= 14 ? 1 : 2) void fwd_small_kernel(const d
     const long count = use_worklist ? (long)ws[kWsCount] : B;
     const long slot = ((long)blockIdx.x * wpb + wave) * TP + team;
     if (((long)blockIdx.x * wpb + wave) * TP >= count) { // a wave beyond the end of the list: only the reset ticket
-        if (use_worklist && count > 0 && lane == 0) {
-            const int tk = atomicAdd(&ws[kWsTicket], 1);
-            if (tk == (int)(gridDim.x * wpb) - 1) {
-                ws[kWsCount] = 0;
-                ws[kWsTicket] = 0;
-            }
-        }
+        if (use_worklist && lane == 0) worklist_release(ws, count, (int)(gridDim.x * wpb));
         return;
     }
     const bool valid = slot < count;
@@ -262,13 +256,7 @@ __global__ __launch_bounds__(256, N >= 14 ? 1 : 2) void fwd_small_kernel(const d
         x[prob * N + i] = bad ? NAN : l2;
         if (iters != nullptr && tl == 0) iters[prob] = it_done;
     }
-    if (use_worklist && count > 0 && lane == 0) { // the last wave out re-zeroes the work-list header
-        const int tk = atomicAdd(&ws[kWsTicket], 1);
-        if (tk == (int)(gridDim.x * wpb) - 1) {
-            ws[kWsCount] = 0;
-            ws[kWsTicket] = 0;
-        }
-    }
+    if (use_worklist && lane == 0) worklist_release(ws, count, (int)(gridDim.x * wpb));
 }
 
 template <int KIND, int N>

@@ -15,6 +15,24 @@ constexpr int kWsTicket = 1;
 constexpr int kWsHintGen = 2; // generation of the last launch that already reported a non-diagonal tile
 constexpr int kWsEntries = 4;
 
+
+#if defined(__HIPCC__)
+// Work-list mode of the general kernels: the last participant (wave or workgroup) out re-zeroes the
+// work-list header for the next call.  Call from ONE lane per participant; `participants` = how many call.
+// With an empty list nothing is touched: hundreds of same-address atomics would otherwise serialise into
+// ~13 us of an otherwise empty launch.
+static DQQ_D void worklist_release(int* ws, long count, int participants)
+{
+    if (count > 0) {
+        const int tk = atomicAdd(&ws[kWsTicket], 1);
+        if (tk == participants - 1) {
+            ws[kWsCount] = 0;
+            ws[kWsTicket] = 0;
+        }
+    }
+}
+#endif
+
 struct FwdArgs {
     const double* P;
     const double* q;
