@@ -64,6 +64,57 @@ DQQ_HD double fast_rcp(double x)
 #endif
 }
 
+// The rho adaptation of the reference's ADMM loops (Solver.cpp:90-120, 228-258, 405-435, 550-580) as one
+// step of a small state machine: rho is increased when the primal residual dominates, decreased when the
+// dual one does, at most once every 5 imbalanced iterations (the reference's `cpt % 5 == 0; cpt++`, kept
+// here modulo 5); when the direction flips the step factors are damped -- both for the QP-like loops
+// (:94-97, :108-111), only the one in use for the QCQP (:554-556, :568-570).
+// update() returns true when rho changed; `delta` is what the reference adds to the diagonal of the
+// shifted matrix (:98 / :112).  FAST: rho /= tau_dec as a multiplication by a 1-ulp reciprocal (fast paths);
+// otherwise the reference's exact expressions.
+struct RhoSchedule {
+    double rho, tau_inc, tau_dec;
+    int rho_up, cpt;
+
+    DQQ_HD void init(double L, double mu)
+    {
+        rho = sqrt(mu * L) * pow(L / mu, .4);        // :72 / :531
+        tau_inc = pow(L / mu, .15);                  // :73 / :532
+        tau_dec = tau_inc;
+        rho_up = 0;
+        cpt = 0;
+    }
+    template <bool QP_LIKE, bool FAST>
+    DQQ_HD bool update(double res_prim, double res_dual, double& delta)
+    {
+        const bool inc = res_prim > kMuThresh * res_dual;               // :92 / :552
+        const bool dec = !inc && (res_dual > kMuThresh * res_prim);     // :106 / :566
+        const bool imb = inc || dec;
+        const bool fire = imb && (cpt == 0);                            // cpt % 5 == 0
+        cpt = imb ? (cpt == 4 ? 0 : cpt + 1) : cpt;                     // cpt++ (kept mod 5)
+        if (!fire) return false;
+        if (rho_up == (inc ? -1 : 1)) {                                 // direction flipped: damp tau
+            const double ti = 1 + .8 * (tau_inc - 1), td = 1 + .8 * (tau_dec - 1);
+            if (QP_LIKE) { tau_inc = ti; tau_dec = td; }
+            else if (inc) tau_inc = ti;
+            else tau_dec = td;
+        }
+        if (FAST) {
+            const double f = inc ? tau_inc : fast_rcp(tau_dec);
+            delta = rho * (f - 1);
+            rho = rho * f;
+        } else if (inc) {
+            delta = rho * (tau_inc - 1);                                // :98
+            rho *= tau_inc;                                             // :99
+        } else {
+            delta = rho * (1. / tau_dec - 1);                           // :112
+            rho /= tau_dec;                                             // :113
+        }
+        rho_up = inc ? 1 : -1;
+        return true;
+    }
+};
+
 // One lane owns the whole problem: reductions are the identity.
 struct HostGroup {
     static DQQ_HD double sum(double v) { return v; }

@@ -153,8 +153,9 @@ __global__ __launch_bounds__(256, N == 32 ? 3 : 2) void fwd_dense_block_kernel(c
         const double Lmax = WR::sum_rows(v * wr.matvec(m, v));
         bool bad = false;
         if (t == 0) *fail_flag = 0.0;
-        double rho = sqrt(mu * Lmax) * pow(Lmax / mu, .4);       // :72 / :531
-        double tau_inc = pow(Lmax / mu, .15), tau_dec = tau_inc; // :73 / :532
+        RhoSchedule sched;
+        sched.init(Lmax, mu);                                    // :72-73 / :531-532
+        double rho = sched.rho;
         double mdiag = Pg[row * N + row] + (rho + mu);           // accumulated shifted diagonal, :75
 
         auto refactor = [&]() { // llt() + solveInPlace(Identity) of P + shift, Solver.cpp:76-77
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256, N == 32 ? 3 : 2) void fwd_dense_block_kernel(c
             if (KIND == 3) { const double vv = v_sign[prob * N + row]; bsg = (double)((vv > 0) - (vv < 0)); } // :395
         }
         double qp = qi, l2 = 0.0, l2p = 0.0, u = 0.0;
-        int rho_up = 0, cpt = 0, it_done = 0;
+        int it_done = 0;
         bool need_refactor = true;
         double inv_rho = 1.0 / rho;
         for (int it = 0; it < max_iter; ++it) {
@@ -220,30 +221,11 @@ __global__ __launch_bounds__(256, N == 32 ? 3 : 2) void fwd_dense_block_kernel(c
             if (KIND == 1) stop = (res_prim < eps + kEpsRel * sqrt(WR::sum_rows(l * l))) && stop; // :548
             if (stop) break;
             if (adaptive) {
-                if (res_prim > kMuThresh * res_dual) {                   // :92 / :552
-                    if (cpt % 5 == 0) {
-                        if (rho_up == -1) {
-                            tau_inc = 1 + .8 * (tau_inc - 1);
-                            if (QP_LIKE) tau_dec = 1 + .8 * (tau_dec - 1);
-                        }
-                        mdiag += rho * (tau_inc - 1);
-                        rho *= tau_inc;
-                        rho_up = 1;
-                        need_refactor = true;
-                    }
-                    cpt++;
-                } else if (res_dual > kMuThresh * res_prim) {            // :106 / :566
-                    if (cpt % 5 == 0) {
-                        if (rho_up == 1) {
-                            if (QP_LIKE) tau_inc = 1 + .8 * (tau_inc - 1);
-                            tau_dec = 1 + .8 * (tau_dec - 1);
-                        }
-                        mdiag += rho * (1. / tau_dec - 1);
-                        rho /= tau_dec;
-                        rho_up = -1;
-                        need_refactor = true;
-                    }
-                    cpt++;
+                double delta = 0.0;
+                if (sched.template update<QP_LIKE, false>(res_prim, res_dual, delta)) { // :90-120 / :550-580
+                    mdiag += delta;
+                    rho = sched.rho;
+                    need_refactor = true;
                 }
             }
         }

@@ -158,8 +158,9 @@ static DQQ_D void dense_fwd_problem(const double* __restrict__ P, const double* 
         Lmax = s;
         DQQ_SYNC();
     }
-    double rho = sqrt(mu * Lmax) * pow(Lmax / mu, .4);              // :72 / :531
-    double tau_inc = pow(Lmax / mu, .15), tau_dec = tau_inc;        // :73 / :532
+    RhoSchedule sched;
+    sched.init(Lmax, mu);                                           // :72-73 / :531-532
+    double rho = sched.rho;
     double mdiag = act ? A[lane * ld + lane] + (rho + mu) : 0.0;    // :75 / :534 (accumulated diagonal)
     if (act) A[lane * ld + lane] = mdiag;
     DQQ_SYNC();
@@ -175,7 +176,7 @@ static DQQ_D void dense_fwd_problem(const double* __restrict__ P, const double* 
         if (KIND == 3) { const double vv = v_sign[prob * n + lane]; bsg = (double)((vv > 0) - (vv < 0)); } // :395
     }
     double qp = qi, l2 = 0.0, l2p = 0.0, u = 0.0;
-    int rho_up = 0, cpt = 0, it_done = 0;
+    int it_done = 0;
     for (int it = 0; it < max_iter; ++it) {
         it_done = it + 1;
         if (act) va[lane] = rho * l2 - u - qp;
@@ -220,31 +221,11 @@ static DQQ_D void dense_fwd_problem(const double* __restrict__ P, const double* 
         DQQ_SYNC();
         if (stop) break;
         if (adaptive) {
-            bool upd = false;
-            if (res_prim > kMuThresh * res_dual) {                   // :92 / :552
-                if (cpt % 5 == 0) {
-                    if (rho_up == -1) {
-                        tau_inc = 1 + .8 * (tau_inc - 1);
-                        if (QP_LIKE) tau_dec = 1 + .8 * (tau_dec - 1);
-                    }
-                    mdiag += rho * (tau_inc - 1);
-                    rho *= tau_inc;
-                    rho_up = 1;
-                    upd = true;
-                }
-                cpt++;
-            } else if (res_dual > kMuThresh * res_prim) {            // :106 / :566
-                if (cpt % 5 == 0) {
-                    if (rho_up == 1) {
-                        if (QP_LIKE) tau_inc = 1 + .8 * (tau_inc - 1);
-                        tau_dec = 1 + .8 * (tau_dec - 1);
-                    }
-                    mdiag += rho * (1. / tau_dec - 1);
-                    rho /= tau_dec;
-                    rho_up = -1;
-                    upd = true;
-                }
-                cpt++;
+            double delta = 0.0;
+            const bool upd = sched.template update<QP_LIKE, false>(res_prim, res_dual, delta); // :90-120 / :550-580
+            if (upd) {
+                mdiag += delta;
+                rho = sched.rho;
             }
             if (upd) { // llt() of the shifted matrix + explicit inverse
                 load_matrix(A, ld, Pg, n, lane);

@@ -178,8 +178,9 @@ __global__ __launch_bounds__(64, 1) void fwd_lane_dense_kernel(const double* __r
     }
 
     // ---- Solver.cpp:72-77 / 531-536
-    double rho = sqrt(mu * Lmax) * pow(Lmax / mu, .4);
-    double tau_inc = pow(Lmax / mu, .15), tau_dec = tau_inc;
+    RhoSchedule sched;
+    sched.init(Lmax, mu);
+    double rho = sched.rho;
     double inv_rho = fast_rcp(rho);
     bool bad = !(rho > 0.0) || !(rho < 1.79e308);
     double md[N], Minv[N][N];
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(64, 1) void fwd_lane_dense_kernel(const double* __r
 #pragma unroll
     for (int i = 0; i < N; ++i) { qp[i] = qv[i]; l2[i] = 0.0; u[i] = 0.0; }
 
-    int rho_up = 0, cpt = 0, it_done = 0;
+    int it_done = 0;
     bool done = !valid;
     for (int it = 0; it < max_iter; ++it) {
         if (!done) {
@@ -254,22 +255,9 @@ __global__ __launch_bounds__(64, 1) void fwd_lane_dense_kernel(const double* __r
             }
             done = stop;
             if (!stop && adaptive) {
-                const bool inc = res_prim > kMuThresh * res_dual;                 // :92 / :552
-                const bool dec = !inc && (res_dual > kMuThresh * res_prim);       // :106 / :566
-                const bool imb = inc || dec;
-                const bool fire = imb && (cpt == 0);
-                cpt = imb ? (cpt == 4 ? 0 : cpt + 1) : cpt;
-                if (fire) {
-                    if (rho_up == (inc ? -1 : 1)) {
-                        const double ti = 1 + .8 * (tau_inc - 1), td = 1 + .8 * (tau_dec - 1);
-                        if (QP_LIKE) { tau_inc = ti; tau_dec = td; }
-                        else if (inc) tau_inc = ti;
-                        else tau_dec = td;
-                    }
-                    const double f = inc ? tau_inc : fast_rcp(tau_dec);
-                    const double delta = rho * (f - 1);
-                    rho = rho * f;
-                    rho_up = inc ? 1 : -1;
+                double delta;
+                if (sched.template update<QP_LIKE, true>(res_prim, res_dual, delta)) { // Solver.cpp:90-120 / 550-580
+                    rho = sched.rho;
                     inv_rho = fast_rcp(rho);
 #pragma unroll
                     for (int i = 0; i < N; ++i) md[i] += delta;
