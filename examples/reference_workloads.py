@@ -8,6 +8,12 @@
      max_iter=1e6 -- forward and backward wall time through `QCQPFn2` (mean of 10, like timeit there),
      and the same problem family at B = 1 ... 65536 to show where a GPU batch pays.
 
+  3. the finite-difference check the reference's C++ driver runs for the box QP (`Solver.cpp:802-853`:
+     G = R R^T, l_min in [-1.5,-0.5], l_max in [0.5,1.5], gradient of x[1] w.r.t. q, l_min, l_max), through
+     `BoxQPFn2` -- whose backward does not run in the reference's Python.  The
+     analytic values are the reference's Tikhonov-regularised solve (mu_ir = 1e-7, Solver.cpp:15-44): they
+     track the finite differences to a percent or so when a bound is active, by construction.
+
 Published CPU numbers read off the figure: forward ~9e-5 s, backward ~2.7e-4 s at B=1.
 """
 import os
@@ -17,7 +23,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from diffqcqp_amd.qcqp import QCQPFn2, QPFn2  # noqa: E402  (sets the default dtype to float64)
+from diffqcqp_amd.qcqp import BoxQPFn2, QCQPFn2, QPFn2  # noqa: E402  (sets the default dtype to float64)
 
 
 def fd_check():
@@ -39,6 +45,33 @@ def fd_check():
                 d[0, i, j] = 1e-8
                 num[i, j] = (QPFn2.apply(P + d, q, ws, 1e-12, 10000)[0, 1] - QPFn2.apply(P - d, q, ws, 1e-12, 10000)[0, 1]).item() / 2e-8
     print("grad_num ", num.flatten().tolist())
+
+
+def box_fd_check():
+    torch.manual_seed(7)
+    n = 4
+    R = 2 * torch.rand(1, n, n) - 1
+    P = (torch.bmm(R, R.transpose(1, 2)) + torch.eye(n)).cuda()
+    leaves = {"q": (0.9 * torch.rand(1, n, 1) - 0.45).cuda().requires_grad_(True),
+              "l_min": (-(torch.rand(1, n, 1) + 0.5) * 0.25).cuda().requires_grad_(True),
+              "l_max": ((torch.rand(1, n, 1) + 0.5) * 0.25).cuda().requires_grad_(True)}
+    ws = torch.zeros(1, n, 1).cuda()
+
+    def solve(**over):
+        a = {k: over.get(k, v) for k, v in leaves.items()}
+        return BoxQPFn2.apply(P, a["q"], a["l_min"], a["l_max"], ws, 1e-12, 100000)
+
+    x = solve()
+    x[0, 1].backward()
+    print("box x    ", x.detach().cpu().flatten().tolist())
+    with torch.no_grad():
+        for name, t in leaves.items():
+            num = []
+            for i in range(n):
+                d = torch.zeros_like(t)
+                d[0, i, 0] = 1e-6
+                num.append((solve(**{name: t + d})[0, 1] - solve(**{name: t - d})[0, 1]).item() / 2e-6)
+            print("grad %-6s" % name, [round(v, 6) for v in t.grad.cpu().flatten().tolist()], " FD", [round(v, 6) for v in num])
 
 
 def figure_workload():
@@ -75,4 +108,5 @@ def figure_workload():
 
 if __name__ == "__main__":
     fd_check()
+    box_fd_check()
     figure_workload()
