@@ -150,22 +150,77 @@ __global__ __launch_bounds__(64, 1) void fwd_lane_dense_kernel(const double* __r
 #pragma unroll
             for (int i = 0; i < N; ++i) v[i] = v[i] / nn;
         }
-        const int pi_steps = QP_LIKE ? 10 : 100;
-        for (int k = 0; k < pi_steps; ++k) {
-            double Av[N];
+        if constexpr (QP_LIKE) {
+            for (int k = 0; k < 10; ++k) {
+                double Av[N];
+                s = 0.0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) t += Pm[i][j] * v[j];
+                    Av[i] = t;
+                    s += t * t;
+                }
+                // normalise after the last step only (see the note above the kernel)
+                const double inv = (k == 9 && s > 0) ? fast_rsqrt(s) : 1.0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) v[i] = Av[i] * inv;
+            }
+        } else {
+            // 100 steps: P^100 v0 = P^64 (P^32 (P^4 v0)) -- six matrix squarings (N mat-vecs' worth each) and three
+            // mat-vecs instead of a hundred mat-vecs.  Every squared matrix and vector is rescaled by an exact
+            // power of two (taken from the largest diagonal entry, which bounds every entry of a power of a
+            // symmetric positive definite matrix), so nothing overflows and no rounding is added by the scaling.
+            double Q[N][N];
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) Q[i][j] = Pm[i][j];
+#pragma unroll 1
+            for (int sq = 1; sq <= 6; ++sq) {
+                double T2[N][N];
+                double dmax = 0.0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int k = 0; k < N; ++k) t += Q[i][k] * Q[k][j];
+                        T2[i][j] = t;
+                    }
+                    dmax = fmax(dmax, fabs(T2[i][i]));
+                }
+                int e = 0;
+                if (dmax > 0.0 && dmax < 1.79e308) (void)frexp(dmax, &e);
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+#pragma unroll
+                    for (int j = 0; j < N; ++j) Q[i][j] = ldexp(T2[i][j], -e);
+                if (sq == 2 || sq == 5 || sq == 6) { // Q = P^4, P^32, P^64 (up to a power of two)
+                    double Av[N];
+                    double vm = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int j = 0; j < N; ++j) t += Q[i][j] * v[j];
+                        Av[i] = t;
+                        vm = fmax(vm, fabs(t));
+                    }
+                    int ev = 0;
+                    if (vm > 0.0 && vm < 1.79e308) (void)frexp(vm, &ev);
+#pragma unroll
+                    for (int i = 0; i < N; ++i) v[i] = ldexp(Av[i], -ev);
+                }
+            }
             s = 0.0;
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-                double t = 0.0;
+            for (int i = 0; i < N; ++i) s += v[i] * v[i];
+            const double inv = (s > 0) ? fast_rsqrt(s) : 1.0;
 #pragma unroll
-                for (int j = 0; j < N; ++j) t += Pm[i][j] * v[j];
-                Av[i] = t;
-                s += t * t;
-            }
-            // normalise every 10th step only (see the note above the kernel)
-            const double inv = ((k % 10) == 9 && s > 0) ? fast_rsqrt(s) : 1.0;
-#pragma unroll
-            for (int i = 0; i < N; ++i) v[i] = Av[i] * inv;
+            for (int i = 0; i < N; ++i) v[i] = v[i] * inv;
         }
         Lmax = 0.0;
 #pragma unroll
