@@ -26,6 +26,7 @@ UNITS = {
     "dense.hip": ["-ffp-contract=off"],
     "bwd_small.hip": ["-ffp-contract=off"],
     "dense_block.hip": ["-ffp-contract=fast"],
+    "dense_wave64.hip": ["-ffp-contract=fast"],
     "bwd_block.hip": ["-ffp-contract=off"],
     "fwd_lane_dense.hip": ["-ffp-contract=fast"],
     "fwd_small.hip": ["-ffp-contract=fast"],

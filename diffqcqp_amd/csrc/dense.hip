@@ -9,6 +9,7 @@
 namespace dqq {
 
 std::atomic<int> g_dense_block{1}; // 0: always the wave-per-problem kernel (option "dense_block")
+std::atomic<int> g_dense_wave64{1}; // 0: never the register-resident wave-per-problem forward of N = 64 (option "dense_wave64")
 std::atomic<int> g_lane_dense{1};  // 0: never the lane-per-problem kernel of N <= 8 (option "lane_dense")
 std::atomic<int> g_dense_teams{1}; // 0: backward always one problem per wave (option "dense_teams")
 std::atomic<int> g_small_fwd{1};   // 0: never the team-per-problem forward of N = 10..16 (option "small_fwd")
@@ -120,6 +121,8 @@ hipError_t launch_fwd_dense(int kind, const FwdArgs& a, bool use_worklist, hipSt
     if (fwd_lane_dense_supported(a.N) && g_lane_dense.load() != 0)
         return launch_fwd_lane_dense(kind, a, use_worklist, s);
     if (fwd_small_supported(a.N) && g_small_fwd.load() != 0) return launch_fwd_small(kind, a, use_worklist, s);
+    if (fwd_dense_wave64_supported(a.N) && g_dense_wave64.load() != 0)
+        return launch_fwd_dense_wave64(kind, a, use_worklist, s);
     if (fwd_dense_block_supported(a.N) && g_dense_block.load() != 0)
         return launch_fwd_dense_block(kind, a, use_worklist, s);
     switch (kind) {

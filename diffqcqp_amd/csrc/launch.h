@@ -107,6 +107,9 @@ hipError_t launch_fwd_lane_dense(int kind, const FwdArgs& a, bool use_worklist, 
 // team-per-problem forward for N = 10, 12, 14, 16 (fwd_small.hip); launch_fwd_dense routes to it
 bool fwd_small_supported(int N);
 hipError_t launch_fwd_small(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s);
+// wave-per-problem, register-resident forward for N = 64 (dense_wave64.hip); launch_fwd_dense routes to it
+bool fwd_dense_wave64_supported(int N);
+hipError_t launch_fwd_dense_wave64(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s);
 // workgroup-per-problem forward for N = 32, 64 (dense_block.hip); launch_fwd_dense routes to it
 bool fwd_dense_block_supported(int N);
 hipError_t launch_fwd_dense_block(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s);

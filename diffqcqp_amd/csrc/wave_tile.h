@@ -1,0 +1,244 @@
+// wave_tile.h -- one wave64 owns one 64 x 64 symmetric matrix entirely in registers (gfx950).
+//
+// Storage ("tile layout"): the matrix is cut into 4 x 4 tiles of 16 x 16; tile (ti,tj) is a v4d per lane in
+// the accumulator layout of v_mfma_f64_16x16x4_f64:
+//     lane l = (g = l >> 4, n = l & 15), register r:   G[ti][tj][r] = S[16 ti + 4 r + g][16 tj + n]
+// 64 doubles (128 VGPRs) per lane, no LDS.  Two facts make that layout self-sufficient:
+//   * a tile in that layout is DIRECTLY an operand of the matrix core: register s supplies the k-slice
+//     {4s..4s+3} of the contraction index = the tile's ROW index, for the A and for the B port alike.  Hence
+//     every product of the form X^T Y (contraction over the rows of both) runs register to register;
+//     with symmetric matrices (S[I][K] = S[K][I]^T) that is all a block Gauss-Jordan sweep needs.
+//   * by symmetry lane (g,n) also holds row (16 tj + n) of S at the columns {16 ti + 4 r + g}: a mat-vec is
+//     64 v_fmac_f64 with a DPP row_newbcast operand (lane n' = 4 ti + r of each 16-lane row supplies
+//     x[16 ti + 4 r + g]) followed by a 3-step reduce-scatter over the four 16-lane rows
+//     (v_permlane32_swap / v_permlane16_swap), which leaves y[l] in lane l.
+// Vectors live one element per lane (lane l = element l).
+#pragma once
+
+#include "block_core.h" // v4d, lane_bcast
+#include "common.h"
+
+namespace dqq {
+
+// acc += (lane BC of this lane's 16-lane row of x) * m      (v_fmac_f64 with a DPP row_newbcast source)
+#define DQQ_FMAC_BCAST_ROW(TI, R)                                                                              \
+    asm("s_nop 1\n\t"                                                                                           \
+        "v_fmac_f64_dpp %0, %4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                              \
+        "v_fmac_f64_dpp %1, %4, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                              \
+        "v_fmac_f64_dpp %2, %4, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                              \
+        "v_fmac_f64_dpp %3, %4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"                                  \
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)                                                                \
+        : "v"(x0), "v"(G[TI][0][R]), "v"(G[TI][1][R]), "v"(G[TI][2][R]), "v"(G[TI][3][R]), "n"(4 * TI + R))
+
+struct u32x2 {
+    unsigned v[2];
+};
+
+// {a[0..31] | b[0..31]} and {a[32..63] | b[32..63]}   (v_permlane32_swap on both halves of a double)
+DQQ_D void swap32(double a, double b, double& lo_halves, double& hi_halves)
+{
+    const auto l = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    lo_halves = __hiloint2double(h[0], l[0]);
+    hi_halves = __hiloint2double(h[1], l[1]);
+}
+
+// {a.row0 | b.row0 | a.row2 | b.row2} and {a.row1 | b.row1 | a.row3 | b.row3}   (v_permlane16_swap)
+DQQ_D void swap16(double a, double b, double& even_rows, double& odd_rows)
+{
+    const auto l = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    even_rows = __hiloint2double(h[0], l[0]);
+    odd_rows = __hiloint2double(h[1], l[1]);
+}
+
+// value of v held by lane `src_lane` (per-lane index), through the LDS crossbar (no LDS memory)
+DQQ_D double lane_gather(double v, int src_lane)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+DQQ_D double wave_sum64(double v)
+{
+    const double m = LaneGroup<16>::sum(v);
+    return (lane_bcast(m, 0) + lane_bcast(m, 16)) + (lane_bcast(m, 32) + lane_bcast(m, 48));
+}
+
+// max over the wave of a and of b (both >= 0): one butterfly for both
+DQQ_D void wave_max2(double a, double b, double& ma, double& mb)
+{
+    double lo, hi;
+    swap32(a, b, lo, hi); // lo = {a[0..31] | b[0..31]}, hi = {a[32..63] | b[32..63]}
+    const double m = LaneGroup<16>::max(fmax(lo, hi));
+    ma = fmax(lane_bcast(m, 0), lane_bcast(m, 16));
+    mb = fmax(lane_bcast(m, 32), lane_bcast(m, 48));
+}
+
+struct WaveTile64 {
+    v4d G[4][4];
+
+    // y = S x for the symmetric S held in G (or y = A x when G holds the tile layout of A^T); x, y one
+    // element per lane.  xsrc = 4 (lane & 15) + (lane >> 4).
+    DQQ_D double matvec(double x, int xsrc) const
+    {
+        const double x0 = lane_gather(x, xsrc); // lane (g, n') <- x[4 n' + g]
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        DQQ_FMAC_BCAST_ROW(0, 0); DQQ_FMAC_BCAST_ROW(0, 1); DQQ_FMAC_BCAST_ROW(0, 2); DQQ_FMAC_BCAST_ROW(0, 3);
+        DQQ_FMAC_BCAST_ROW(1, 0); DQQ_FMAC_BCAST_ROW(1, 1); DQQ_FMAC_BCAST_ROW(1, 2); DQQ_FMAC_BCAST_ROW(1, 3);
+        DQQ_FMAC_BCAST_ROW(2, 0); DQQ_FMAC_BCAST_ROW(2, 1); DQQ_FMAC_BCAST_ROW(2, 2); DQQ_FMAC_BCAST_ROW(2, 3);
+        DQQ_FMAC_BCAST_ROW(3, 0); DQQ_FMAC_BCAST_ROW(3, 1); DQQ_FMAC_BCAST_ROW(3, 2); DQQ_FMAC_BCAST_ROW(3, 3);
+        // a[tj] of lane (g,n) = partial sum of y[16 tj + n] over the columns = g (mod 4): reduce over g,
+        // scattering tj = g
+        double p, q2, s02, s13, e, o;
+        swap32(a0, a2, p, q2);
+        s02 = p + q2; // rows 0,1: a0 summed over {g, g+2}; rows 2,3: a2
+        swap32(a1, a3, p, q2);
+        s13 = p + q2;
+        swap16(s02, s13, e, o);
+        return e + o;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------
+// 16 x 16 symmetric positive definite block, inverse by 16 symmetric sweeps, in registers.
+// In: T = the block in tile layout (T[r] of lane (g,n) = B[4r+g][n]).  Out: its inverse in tile layout.
+// Each 16-lane row of the wave works on the same block redundantly: lane (.,i) holds row i of the block in
+// 16 registers, a pivot column is handed to the other rows of the block as a DPP row_newbcast operand.
+// Sweep k on the stored rows a_i (true row = s_i * stored row, s_i = 1 until row i has been the pivot):
+//     d = a_kk, t_i = a_ik / d, b_i = s_i t_i (= true a_ik / d = true a_ki / d by symmetry)
+//     rows i != k:  a_ij -= a_ik b_j  (j != k),  a_ik = t_i
+//     row k: unchanged except a_kk = -1, s_k = 1/d      (deferring the scaling of the pivot row keeps the
+//     update of all rows the same instruction; scaling it in place would cost a second pass per sweep)
+// After 16 sweeps s_i * a_i = -B^-1.   bad: a pivot was not positive.
+#define DQQ_SWEEP5(J0, J1, J2, J3, J4)                                                                         \
+    asm("s_nop 1\n\t"                                                                                           \
+        "v_fmac_f64_dpp %0, %5, %6 row_newbcast:" #J0 " row_mask:0xf bank_mask:0xf\n\t"                         \
+        "v_fmac_f64_dpp %1, %5, %6 row_newbcast:" #J1 " row_mask:0xf bank_mask:0xf\n\t"                         \
+        "v_fmac_f64_dpp %2, %5, %6 row_newbcast:" #J2 " row_mask:0xf bank_mask:0xf\n\t"                         \
+        "v_fmac_f64_dpp %3, %5, %6 row_newbcast:" #J3 " row_mask:0xf bank_mask:0xf\n\t"                         \
+        "v_fmac_f64_dpp %4, %5, %6 row_newbcast:" #J4 " row_mask:0xf bank_mask:0xf"                              \
+        : "+v"(a[J0]), "+v"(a[J1]), "+v"(a[J2]), "+v"(a[J3]), "+v"(a[J4])                                       \
+        : "v"(b), "v"(nc))
+#define DQQ_SWEEP15(K, J0, J1, J2, J3, J4, J5, J6, J7, J8, J9, J10, J11, J12, J13, J14)                        \
+    do {                                                                                                        \
+        DQQ_SWEEP5(J0, J1, J2, J3, J4);                                                                         \
+        DQQ_SWEEP5(J5, J6, J7, J8, J9);                                                                         \
+        DQQ_SWEEP5(J10, J11, J12, J13, J14);                                                                    \
+    } while (0)
+
+template <int K>
+DQQ_D void sweep16_step(double (&a)[16], double& s, int n, bool& bad)
+{
+    const double d = __builtin_amdgcn_update_dpp(0.0, a[K], 0x150 + K, 0xf, 0xf, true); // a_kk of this 16-lane row
+    bad = bad || !(d > 0.0);
+    const double rd = fast_rcp(d);
+    const double c = a[K];
+    const double t = c * rd;
+    const double b = t * s;
+    const bool piv = (n == K);
+    const double nc = piv ? 0.0 : -c;
+    a[K] = piv ? -1.0 : t;
+    s = piv ? rd : s;
+    // the 15 columns j != K, the next pivot's column first
+    if constexpr (K == 0) DQQ_SWEEP15(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    if constexpr (K == 1) DQQ_SWEEP15(1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0);
+    if constexpr (K == 2) DQQ_SWEEP15(2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1);
+    if constexpr (K == 3) DQQ_SWEEP15(3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2);
+    if constexpr (K == 4) DQQ_SWEEP15(4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3);
+    if constexpr (K == 5) DQQ_SWEEP15(5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4);
+    if constexpr (K == 6) DQQ_SWEEP15(6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5);
+    if constexpr (K == 7) DQQ_SWEEP15(7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6);
+    if constexpr (K == 8) DQQ_SWEEP15(8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7);
+    if constexpr (K == 9) DQQ_SWEEP15(9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7, 8);
+    if constexpr (K == 10) DQQ_SWEEP15(10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9);
+    if constexpr (K == 11) DQQ_SWEEP15(11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10);
+    if constexpr (K == 12) DQQ_SWEEP15(12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11);
+    if constexpr (K == 13) DQQ_SWEEP15(13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12);
+    if constexpr (K == 14) DQQ_SWEEP15(14, 15, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13);
+    if constexpr (K == 15) DQQ_SWEEP15(15, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14);
+}
+
+DQQ_D v4d diag16_inverse(const v4d& T, int lane, bool& bad)
+{
+    const int n = lane & 15;
+    double a[16];
+    // all-gather over the four 16-lane rows: a[4r + g'] = T[r] of lane (g', n) = B[n][4r + g'] (symmetry)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double h0, h1;
+        swap32(T[r], T[r], h0, h1); // h0 = T[r] of rows (0,1,0,1), h1 = T[r] of rows (2,3,2,3)
+        swap16(h0, h0, a[4 * r + 0], a[4 * r + 1]);
+        swap16(h1, h1, a[4 * r + 2], a[4 * r + 3]);
+    }
+    double s = 1.0;
+    sweep16_step<0>(a, s, n, bad);  sweep16_step<1>(a, s, n, bad);  sweep16_step<2>(a, s, n, bad);
+    sweep16_step<3>(a, s, n, bad);  sweep16_step<4>(a, s, n, bad);  sweep16_step<5>(a, s, n, bad);
+    sweep16_step<6>(a, s, n, bad);  sweep16_step<7>(a, s, n, bad);  sweep16_step<8>(a, s, n, bad);
+    sweep16_step<9>(a, s, n, bad);  sweep16_step<10>(a, s, n, bad); sweep16_step<11>(a, s, n, bad);
+    sweep16_step<12>(a, s, n, bad); sweep16_step<13>(a, s, n, bad); sweep16_step<14>(a, s, n, bad);
+    sweep16_step<15>(a, s, n, bad);
+    // back to tile layout: D[r] of lane (g,n) = Binv[4r+g][n] = Binv[n][4r+g] = -s * a[4r+g].  All four 16-lane
+    // rows hold the same 16 values, so the choice by g is made by the swaps themselves (no per-lane select:
+    // `g & 1 ? a[i+1] : a[i]` is turned into a dynamically indexed load by the compiler, which sends the whole
+    // array to scratch)
+    v4d D;
+    const double ns = -s;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double lo, hi, pick, unused;
+        swap16(a[4 * r + 0], a[4 * r + 1], lo, unused); // rows 0,2: a[4r], rows 1,3: a[4r+1]
+        swap16(a[4 * r + 2], a[4 * r + 3], hi, unused); // rows 0,2: a[4r+2], rows 1,3: a[4r+3]
+        swap32(lo, hi, pick, unused);                   // rows 0,1: lo, rows 2,3: hi
+        D[r] = pick * ns;
+    }
+    return D;
+}
+
+// out (+)= X^T Y for two tiles in tile layout (contraction over their row index), on the matrix core
+DQQ_D v4d tile_xty(v4d acc, const v4d& X, const v4d& Y)
+{
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[s], Y[s], acc, 0, 0, 0);
+    return acc;
+}
+
+// In place: G (symmetric positive definite, tile layout) -> -G^-1, by four block sweeps:
+//   D = G_KK^-1;  B_J = D G_KJ;  G_IJ -= G_KI^T B_J (I, J != K);  G_JK = G_KJ^T D;  G_KJ = B_J;  G_KK = -D
+// Every product is an X^T Y (the matrix stays symmetric), 60 tile products = 240 MFMAs in all.
+template <int K>
+DQQ_D void block_sweep_step(v4d (&G)[4][4], int lane, bool& bad)
+{
+    const v4d zero = {0.0, 0.0, 0.0, 0.0};
+    const v4d D = diag16_inverse(G[K][K], lane, bad);
+    v4d Bt[4];
+#pragma unroll
+    for (int J = 0; J < 4; ++J)
+        if (J != K) Bt[J] = tile_xty(zero, D, G[K][J]);
+#pragma unroll
+    for (int I = 0; I < 4; ++I) {
+        if (I == K) continue;
+        const v4d nX = -G[K][I];
+#pragma unroll
+        for (int J = 0; J < 4; ++J)
+            if (J != K) G[I][J] = tile_xty(G[I][J], nX, Bt[J]);
+    }
+#pragma unroll
+    for (int J = 0; J < 4; ++J)
+        if (J != K) G[J][K] = tile_xty(zero, G[K][J], D);
+#pragma unroll
+    for (int J = 0; J < 4; ++J)
+        if (J != K) G[K][J] = Bt[J];
+    G[K][K] = -D;
+}
+
+DQQ_D void block_sweep_inverse(v4d (&G)[4][4], int lane, bool& bad)
+{
+    block_sweep_step<0>(G, lane, bad);
+    block_sweep_step<1>(G, lane, bad);
+    block_sweep_step<2>(G, lane, bad);
+    block_sweep_step<3>(G, lane, bad);
+}
+
+} // namespace dqq
