@@ -172,6 +172,8 @@ hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipSt
 {
     if (a.B == 0) return hipSuccess;
     if (bwd_small_supported(kind, a.N) && g_small_bwd.load() != 0) return launch_bwd_small(kind, a, use_worklist, s);
+    if (bwd_dense_wave64_supported(kind, a.N) && g_dense_wave64.load() != 0)
+        return launch_bwd_dense_wave64(kind, a, use_worklist, s);
     if (bwd_dense_block_supported(kind, a.N) && g_dense_block.load() != 0)
         return launch_bwd_dense_block(kind, a, use_worklist, s);
     // QCQP N = 32 / 64, box N = 16 / 32: workgroup kernel on the matrix cores.  It is the only general kernel

@@ -28,13 +28,15 @@ namespace dqq {
 // so that WaveTile64::matvec returns A x (no symmetry assumed).
 static DQQ_D void load_tiles_transposed(v4d (&G)[4][4], const double* __restrict__ A, int lane)
 {
-    const double* base = A + (lane & 15) * 64 + (lane >> 4);
+    // addressing: uniform base (SGPRs, advanced per tile) + one 32-bit per-lane offset for all 64 loads -- as a
+    // per-lane 64-bit pointer plus constants the compiler keeps dozens of address pairs alive and spills them
+    const unsigned lo = (lane & 15) * 64 + (lane >> 4);
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) G[ti][tj][r] = base[(16 * tj) * 64 + 16 * ti + 4 * r];
+            for (int r = 0; r < 4; ++r) G[ti][tj][r] = (A + ((16 * tj) * 64 + 16 * ti + 4 * r))[lo];
 }
 
 // G <- tile layout of the symmetric matrix whose lower triangle is A's (what LLT reads, Solver.cpp:76):
@@ -43,8 +45,8 @@ static DQQ_D void load_tiles_transposed(v4d (&G)[4][4], const double* __restrict
 static DQQ_D void load_tiles_lower_symmetric(v4d (&G)[4][4], const double* __restrict__ A, int lane)
 {
     const int g = lane >> 4, n = lane & 15;
-    const double* rowmajor = A + g * 64 + n;   // + (16ti + 4r) * 64 + 16tj : A[16ti+4r+g][16tj+n]
-    const double* colmajor = A + n * 64 + g;   // + (16tj) * 64 + 16ti + 4r : A[16tj+n][16ti+4r+g]
+    const unsigned rowmajor = g * 64 + n;   // + (16ti + 4r) * 64 + 16tj : A[16ti+4r+g][16tj+n]
+    const unsigned colmajor = n * 64 + g;   // + (16tj) * 64 + 16ti + 4r : A[16tj+n][16ti+4r+g]
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
@@ -52,9 +54,9 @@ static DQQ_D void load_tiles_lower_symmetric(v4d (&G)[4][4], const double* __res
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o_row = (16 * ti + 4 * r) * 64 + 16 * tj, o_col = (16 * tj) * 64 + 16 * ti + 4 * r;
-                if (ti > tj) G[ti][tj][r] = rowmajor[o_row];
-                else if (ti < tj) G[ti][tj][r] = colmajor[o_col];
-                else G[ti][tj][r] = (4 * r + g >= n) ? rowmajor[o_row] : colmajor[o_col];
+                if (ti > tj) G[ti][tj][r] = (A + o_row)[rowmajor];
+                else if (ti < tj) G[ti][tj][r] = (A + o_col)[colmajor];
+                else G[ti][tj][r] = (A + o_row)[(4 * r + g >= n) ? rowmajor : colmajor + (unsigned)(o_col - o_row)];
             }
 }
 
@@ -81,12 +83,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // KIND 2 / 3 (box / signed box QP): l_n = l_min, mu_c = l_max per coordinate
     constexpr int N = 64;
     constexpr bool QP_LIKE = (KIND != 1);
-    const int lane = threadIdx.x;
-    const int xsrc = 4 * (lane & 15) + (lane >> 4);
     const long count = use_worklist ? (long)ws[kWsCount] : B;
 
     for (long w = blockIdx.x; w < count; w += gridDim.x) {
-        const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
+        // everything derived from the lane index is recomputed per problem: hoisted out of this loop (which runs
+        // once per wave outside the work-list mode) those dozens of masks and offsets only occupy registers
+        int lane = threadIdx.x;
+        asm volatile("" : "+v"(lane));
+        const int xsrc = 4 * (lane & 15) + (lane >> 4);
+        // wave-uniform by construction; readfirstlane tells the compiler so (P's addressing then uses an SGPR base)
+        const long prob = __builtin_amdgcn_readfirstlane(use_worklist ? ws[kWsEntries + w] : (int)w);
         const double* Pg = P + prob * (long)(N * N);
         WaveTile64 W;
         // ---- power_iteration, Solver.cpp:46-59 (the normalisation by a 1-ulp reciprocal square root)
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (iters != nullptr && lane == 0) iters[prob] = it_done;
     }
     // last wave out re-zeroes the work-list header (nothing to do when the list was empty)
-    if (use_worklist && lane == 0) worklist_release(ws, count, (int)gridDim.x);
+    if (use_worklist && threadIdx.x == 0) worklist_release(ws, count, (int)gridDim.x);
 }
 
 template <int KIND>
@@ -199,6 +205,179 @@ hipError_t launch_fwd_dense_wave64(int kind, const FwdArgs& a, bool use_worklist
     case 3: return launch_wave64<3>(a, use_worklist, s);
     default: return hipErrorInvalidValue;
     }
+}
+
+// ---------------------------------------------------------------- backward (QP), N = 64
+// One wave per problem; the composition of pybindings.cpp:24-30 -> Solver::dualFromPrimalQP (Solver.cpp:125-134),
+// Solver::solveDerivativesQP (:136-196), Solver::iterative_refinement (:15-44) and the gradient assembly of
+// qcqp.py:48-51, on the system in the ORIGINAL index order with the active rows / columns masked
+// (A~[a][k] = P[a][k] if a and k are inactive, l_a if a = k is active, 0 otherwise -- a symmetric permutation of the
+// reference's blkdiag(diag(l_A), P_II), see dense_block.hip).
+//
+// P is streamed from L2 one tile-row at a time (32 registers) instead of being held: the registers belong to
+// K = A~ A~^T + mu I (accumulated on the matrix cores as sum_k T_k^T T_k while the tile-rows go by) and then to
+// -K^-1 (block sweep, in place).  The refinement residual K x - A^T b (:30), which needs K after it has been
+// overwritten by its inverse, is evaluated as A~ (A~^T x) + mu x from two more streams of P with the masks applied
+// to the vectors (x is exactly zero on the active set): same quantity, rounded differently (~1e-16 |K| |x|, against
+// exit thresholds of 1e-10).
+
+// tile-row TK of the tile layout of A^T:  T[ta][r] of lane (g,n) = A[16ta+n][16TK+4r+g]    (mat-vec: A x)
+template <int TK>
+static DQQ_D void load_tile_row_transposed(v4d (&T)[4], const double* __restrict__ A, int lane)
+{
+    const unsigned lo = (lane & 15) * 64 + (lane >> 4);
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[ta][r] = (A + ((16 * ta) * 64 + 16 * TK + 4 * r))[lo];
+}
+
+// tile-row TK of the tile layout of A:  T[tj][r] of lane (g,n) = A[16TK+4r+g][16tj+n]      (mat-vec: A^T x)
+template <int TK>
+static DQQ_D void load_tile_row_plain(v4d (&T)[4], const double* __restrict__ A, int lane)
+{
+    const unsigned lo = (lane >> 4) * 64 + (lane & 15);
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[tj][r] = (A + ((16 * TK + 4 * r) * 64 + 16 * tj))[lo];
+}
+
+template <int TK>
+static DQQ_D void bwd_qp_accumulate_row(v4d (&K)[4][4], MatvecStream& mv, const double* __restrict__ Pg,
+                                        unsigned long long am, double xi_act, int lane)
+{
+    const int g = lane >> 4, n = lane & 15;
+    v4d T[4];
+    load_tile_row_transposed<TK>(T, Pg, lane);
+    // A~: zero where the row a = 16ta+n or the column k = 16TK+4r+g is active; l_a on the diagonal of an active a
+    const double dk = lane_gather(xi_act, 16 * TK + n); // l_a where a = 16TK+n is active, else its P entry is kept
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool row_act = (am >> (16 * ta + n)) & 1ull, col_act = (am >> (16 * TK + 4 * r + g)) & 1ull;
+            double t = (row_act || col_act) ? 0.0 : T[ta][r];
+            if (ta == TK) t = (row_act && 4 * r + g == n) ? dk : t;
+            T[ta][r] = t;
+        }
+    mv.add_row<TK>(T);
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) K[ta][tb] = tile_xty(K[ta][tb], T[ta], T[tb]); // += sum_k A~[a][k] A~[b][k]
+    __builtin_amdgcn_sched_barrier(0); // keep the next tile-row's 32 loads behind this row's products (registers)
+}
+
+template <int TK, bool TRANSPOSED>
+static DQQ_D void stream_matvec_row(MatvecStream& mv, const double* __restrict__ Pg, int lane)
+{
+    v4d T[4];
+    if (TRANSPOSED) load_tile_row_transposed<TK>(T, Pg, lane);
+    else load_tile_row_plain<TK>(T, Pg, lane);
+    mv.add_row<TK>(T);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// P x (TRANSPOSED_LAYOUT = true) or P^T x, P streamed from memory
+template <bool TRANSPOSED_LAYOUT>
+static DQQ_D double stream_matvec(const double* __restrict__ Pg, double x, int xsrc, int lane)
+{
+    MatvecStream mv;
+    mv.begin(x, xsrc);
+    stream_matvec_row<0, TRANSPOSED_LAYOUT>(mv, Pg, lane);
+    stream_matvec_row<1, TRANSPOSED_LAYOUT>(mv, Pg, lane);
+    stream_matvec_row<2, TRANSPOSED_LAYOUT>(mv, Pg, lane);
+    stream_matvec_row<3, TRANSPOSED_LAYOUT>(mv, Pg, lane);
+    return mv.finish();
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_dense_wave64_qp_kernel(
+    const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ x,
+    const double* __restrict__ grad_x, double* __restrict__ grad_P, double* __restrict__ grad_q, long B, double dual_eps,
+    int* __restrict__ ir_steps, int* __restrict__ ws, int use_worklist)
+{
+    constexpr int N = 64;
+    const long count = use_worklist ? (long)ws[kWsCount] : B;
+
+    for (long w = blockIdx.x; w < count; w += gridDim.x) {
+        int lane = threadIdx.x;
+        asm volatile("" : "+v"(lane)); // see the forward kernel: nothing lane-derived is hoisted out of the loop
+        const int g = lane >> 4, n = lane & 15;
+        const int xsrc = 4 * n + g;
+        // wave-uniform by construction; readfirstlane tells the compiler so (P's addressing then uses an SGPR base)
+        const long prob = __builtin_amdgcn_readfirstlane(use_worklist ? ws[kWsEntries + w] : (int)w);
+        const double* Pg = P + prob * (long)(N * N);
+        const double xi = x[prob * N + lane], gi = grad_x[prob * N + lane], qi = q[prob * N + lane];
+        // dualFromPrimalQP, Solver.cpp:125-134, and the active set of solveDerivativesQP, :139-147
+        double gamma = -(stream_matvec<true>(Pg, xi, xsrc, lane) + qi);
+        if (xi > dual_eps) gamma = 0;
+        const bool is_act = gamma < -kActiveEps;
+        const unsigned long long am = __ballot(is_act);
+        // A^T b (:19) with b = [0; grad_I], and K = A~ A~^T + mu_ir I (:20-21), in one stream of P
+        WaveTile64 W;
+        const v4d zero = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) W.G[a][b] = zero;
+        MatvecStream mv;
+        mv.begin(is_act ? 0.0 : gi, xsrc);
+        bwd_qp_accumulate_row<0>(W.G, mv, Pg, am, xi, lane);
+        bwd_qp_accumulate_row<1>(W.G, mv, Pg, am, xi, lane);
+        bwd_qp_accumulate_row<2>(W.G, mv, Pg, am, xi, lane);
+        bwd_qp_accumulate_row<3>(W.G, mv, Pg, am, xi, lane);
+        double Ab = mv.finish();
+        if (is_act) Ab = 0.0;
+        {
+            const bool on_diag = (n & 3) == g;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) W.G[t][t][r] += (on_diag && (n >> 2) == r) ? kMuIr : 0.0;
+        }
+        bool bad = false;
+        block_sweep_inverse(W.G, lane, bad);                                  // :22-23; W.G = -K^-1
+        const double KinvAb = -W.matvec(Ab, xsrc);                            // :27
+        double xs = 0.0;
+        IrControl ctl;
+        ctl.init();
+        int steps = 0;
+        for (int it = 0; it < kIrMaxIter; ++it) {
+            steps = it + 1;
+            xs = KinvAb - kMuIr * W.matvec(xs, xsrc);                         // :29
+            // K xs - A^T b (:30) = A~ (A~^T xs) + mu xs - Ab; xs is exactly zero on the active set
+            double wv = stream_matvec<false>(Pg, is_act ? 0.0 : xs, xsrc, lane);
+            wv = is_act ? 0.0 : wv;
+            double y = stream_matvec<true>(Pg, wv, xsrc, lane);
+            y = is_act ? (xi * xi) * xs : y;
+            const double d = (y + kMuIr * xs) - Ab;
+            const double res = sqrt(wave_sum64(d * d));                       // :31
+            if (ctl.update(res)) break;                                       // :32-41
+        }
+        const double dl = bad ? NAN : (is_act ? 0.0 : xs);                    // :187-191
+        if (grad_q != nullptr) grad_q[prob * N + lane] = -dl;                // qcqp.py:49
+        if (grad_P != nullptr) {                                              // qcqp.py:48: -(dl l^T)
+            double* Gp = grad_P + prob * (long)(N * N);
+#pragma unroll 8
+            for (int k = 0; k < N; ++k) __builtin_nontemporal_store(-(lane_bcast(dl, k) * xi), Gp + k * N + lane);
+        }
+        if (ir_steps != nullptr && lane == 0) ir_steps[prob] = steps;
+    }
+    if (use_worklist && threadIdx.x == 0) worklist_release(ws, count, (int)gridDim.x);
+}
+
+bool bwd_dense_wave64_supported(int kind, int N) { return kind == 0 && N == 64; }
+
+hipError_t launch_bwd_dense_wave64(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)
+{
+    if (a.B == 0) return hipSuccess;
+    if (kind != 0 || a.N != 64) return hipErrorInvalidValue;
+    const long cap = 1L << 22;
+    const unsigned grid = use_worklist ? 2048u : (unsigned)(a.B < cap ? a.B : cap);
+    hipLaunchKernelGGL(bwd_dense_wave64_qp_kernel, dim3(grid), dim3(64), 0, s, a.P, a.q, a.x, a.grad_x, a.grad_P, a.grad_q,
+                       a.B, a.epsilon, a.ir_steps, a.ws, use_worklist ? 1 : 0);
+    return hipGetLastError();
 }
 
 } // namespace dqq

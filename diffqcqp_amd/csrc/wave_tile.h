@@ -30,9 +30,15 @@ namespace dqq {
         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)                                                                \
         : "v"(x0), "v"(G[TI][0][R]), "v"(G[TI][1][R]), "v"(G[TI][2][R]), "v"(G[TI][3][R]), "n"(4 * TI + R))
 
-struct u32x2 {
-    unsigned v[2];
-};
+// the same for one tile-row T[0..3] streamed from memory: acc[tj] += T[tj][R] * (lane BC of the row of x0)
+#define DQQ_FMAC_BCAST_TROW(T, R, BC)                                                                          \
+    asm("s_nop 1\n\t"                                                                                           \
+        "v_fmac_f64_dpp %0, %4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                              \
+        "v_fmac_f64_dpp %1, %4, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                              \
+        "v_fmac_f64_dpp %2, %4, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                              \
+        "v_fmac_f64_dpp %3, %4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"                                  \
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)                                                                \
+        : "v"(x0), "v"(T[0][R]), "v"(T[1][R]), "v"(T[2][R]), "v"(T[3][R]), "n"(BC))
 
 // {a[0..31] | b[0..31]} and {a[32..63] | b[32..63]}   (v_permlane32_swap on both halves of a double)
 DQQ_D void swap32(double a, double b, double& lo_halves, double& hi_halves)
@@ -101,6 +107,35 @@ struct WaveTile64 {
     }
 };
 
+// The same mat-vec with the matrix streamed one tile-row at a time (T[tj] = tiles (TK, tj) of the layout):
+//     MatvecStream mv; mv.begin(x, xsrc); for TK: mv.add_row<TK>(T); y = mv.finish();
+struct MatvecStream {
+    double x0, a0, a1, a2, a3;
+    DQQ_D void begin(double x, int xsrc)
+    {
+        x0 = lane_gather(x, xsrc);
+        a0 = a1 = a2 = a3 = 0.0;
+    }
+    template <int TK>
+    DQQ_D void add_row(const v4d (&T)[4])
+    {
+        DQQ_FMAC_BCAST_TROW(T, 0, 4 * TK + 0);
+        DQQ_FMAC_BCAST_TROW(T, 1, 4 * TK + 1);
+        DQQ_FMAC_BCAST_TROW(T, 2, 4 * TK + 2);
+        DQQ_FMAC_BCAST_TROW(T, 3, 4 * TK + 3);
+    }
+    DQQ_D double finish() const
+    {
+        double p, q2, s02, s13, e, o;
+        swap32(a0, a2, p, q2);
+        s02 = p + q2;
+        swap32(a1, a3, p, q2);
+        s13 = p + q2;
+        swap16(s02, s13, e, o);
+        return e + o;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------------
 // 16 x 16 symmetric positive definite block, inverse by 16 symmetric sweeps, in registers.
 // In: T = the block in tile layout (T[r] of lane (g,n) = B[4r+g][n]).  Out: its inverse in tile layout.
@@ -132,7 +167,7 @@ template <int K>
 DQQ_D void sweep16_step(double (&a)[16], double& s, int n, bool& bad)
 {
     const double d = __builtin_amdgcn_update_dpp(0.0, a[K], 0x150 + K, 0xf, 0xf, true); // a_kk of this 16-lane row
-    bad = bad || !(d > 0.0);
+    bad = bad || __ballot(!(d > 0.0)) != 0; // decided here (scalar), or all 64 pivots stay alive for a late test
     const double rd = fast_rcp(d);
     const double c = a[K];
     const double t = c * rd;
