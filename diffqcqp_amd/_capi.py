@@ -19,7 +19,7 @@ P_AUTO, P_DENSE, P_DIAG = 0, 1, 2
 _ERRORS = {
     -1: "DQQ_E_NULLPTR: a required pointer is NULL",
     -2: "DQQ_E_BAD_SIZE: B < 0, N < 1, or odd N for a QCQP",
-    -3: "DQQ_E_UNSUPPORTED_N: N is larger than the kernels hold in LDS (see dqq_max_n)",
+    -3: "DQQ_E_UNSUPPORTED_N: the compact diagonal layout (DQQ_P_DIAG) takes N in {2, 4, 8, 16, 32, 64} only",
     -4: "DQQ_E_BAD_LAYOUT: unknown p_layout",
     -5: "DQQ_E_WORKSPACE: workspace missing or too small",
     -6: "DQQ_E_BAD_OPTION: unknown option name",

@@ -24,6 +24,7 @@ UNITS = {
     "fwd_diag.hip": ["-ffp-contract=fast"],
     "bwd_diag.hip": ["-ffp-contract=off"],
     "dense.hip": ["-ffp-contract=off"],
+    "general_any.hip": ["-ffp-contract=off"],
     "bwd_small.hip": ["-ffp-contract=off"],
     "dense_block.hip": ["-ffp-contract=fast"],
     "dense_wave64.hip": ["-ffp-contract=fast"],

@@ -265,10 +265,9 @@ static hipError_t launch_one(const BwdArgs& a, hipStream_t s)
     const long ntiles = (a.B + T - 1) / T;
     const long nblocks = (ntiles + WPB - 1) / WPB;
     if (nblocks == 0) return hipSuccess;
-    hipLaunchKernelGGL((bwd_diag_kernel<KIND, N, WPB, FUSE>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q, a.l_n,
+    return launch((bwd_diag_kernel<KIND, N, WPB, FUSE>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q, a.l_n,
                        a.mu, a.x, a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.epsilon, a.layout,
                        a.ir_steps, a.ws, a.pdiag, a.flags);
-    return hipGetLastError();
 }
 
 template <int KIND, int N>
@@ -299,12 +298,17 @@ static hipError_t launch_kind(const BwdArgs& a, int wpb, bool fuse, hipStream_t 
     }
 }
 
+bool bwd_diag_will_fuse(int kind, int N, long B, int layout, int fuse_opt)
+{
+    return layout != DQQ_P_DIAG && bwd_diag_supported(N) && bwd_diag_fuses(N) && kind != kKindBox &&
+           (fuse_opt < 0 ? bwd_diag_fuses_fallback(N, B) : fuse_opt != 0);
+}
+
 hipError_t launch_bwd_diag(int kind, const BwdArgs& a, int wpb, int fuse_opt, hipStream_t s, bool* needs_fallback)
 {
     if (wpb != 1 && wpb != 4) wpb = 4;
     // the box QP's general routine needs 3N rows of LDS: never fused, always queued for the dense kernel
-    const bool fuse = a.layout != DQQ_P_DIAG && bwd_diag_fuses(a.N) && kind != kKindBox &&
-                      (fuse_opt < 0 ? bwd_diag_fuses_fallback(a.N, a.B) : fuse_opt != 0);
+    const bool fuse = bwd_diag_will_fuse(kind, a.N, a.B, a.layout, fuse_opt);
     if (needs_fallback) *needs_fallback = (a.layout == DQQ_P_AUTO) && !fuse;
     if (kind == kKindBox) return launch_kind<2>(a, wpb, false, s);
     return kind == 0 ? launch_kind<0>(a, wpb, fuse, s) : launch_kind<1>(a, wpb, fuse, s);

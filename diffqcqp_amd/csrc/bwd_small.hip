@@ -403,10 +403,9 @@ static hipError_t launch_small(const BwdArgs& a, bool use_worklist, hipStream_t 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * WPB), lds_bytes, s, a.P, a.q, a.l_n, a.mu, a.x, a.grad_x, a.grad_P,
+    return launch(kernel, dim3(grid), dim3(64 * WPB), lds_bytes, s, a.P, a.q, a.l_n, a.mu, a.x, a.grad_x, a.grad_P,
                        a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.epsilon, a.ir_steps, a.ws,
                        use_worklist ? 1 : 0);
-    return hipGetLastError();
 }
 
 // The box QP instantiations (M = 3N: 24 unknowns at N = 8) exist and are correct, but run out of registers

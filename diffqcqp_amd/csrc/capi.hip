@@ -37,54 +37,6 @@ Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback"
                       {"small_fwd", &dqq::g_small_fwd},
                       {"block_bwd", &dqq::g_block_bwd}};
 
-// Performance hint of the AUTO layout (never affects results): a host-mapped word into which the
-// forward fast path stores the generation number of its launch when it meets a non-diagonal tile.  If
-// the previous AUTO call left its generation there, this batch is probably dense as well, and queueing
-// its tiles for the lane-per-problem kernel (~0.1 ms per 65536 dense 8x8 problems) beats solving them
-// one wave at a time inside the fast kernel (~1.2 ms); otherwise the in-kernel fallback saves a launch.
-// Read without synchronisation: it lags when calls are enqueued faster than the GPU runs them.
-std::atomic<int*> g_hint_host{nullptr};
-std::atomic<int*> g_hint_dev{nullptr};
-std::atomic<int> g_hint_gen{0};
-std::atomic<int> g_last_auto_dense{0}; // decision of the most recent AUTO forward, reused by the backward
-
-int* hint_device_pointer()
-{
-    int* d = g_hint_dev.load();
-    if (d != nullptr) return d;
-    int* h = nullptr;
-    if (hipHostMalloc(reinterpret_cast<void**>(&h), 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    *h = 0;
-    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        (void)hipHostFree(h);
-        return nullptr;
-    }
-    int* expected = nullptr;
-    if (!g_hint_dev.compare_exchange_strong(expected, d)) { // another thread won the race
-        (void)hipHostFree(h);
-        return expected;
-    }
-    g_hint_host.store(h);
-    return d;
-}
-
-// Returns this launch's generation; *dense_before = one of the last kHintWindow launches reported
-// non-diagonal tiles (a window, not just the previous launch: the host usually enqueues several calls
-// ahead of the GPU, so the word lags by the depth of the queue).
-constexpr int kHintWindow = 64;
-int hint_next_generation(bool* dense_before)
-{
-    const int gen = g_hint_gen.fetch_add(1) + 1;
-    int* h = g_hint_host.load();
-    const int seen = h != nullptr ? *reinterpret_cast<volatile int*>(h) : 0;
-    *dense_before = seen > 0 && gen - seen <= kHintWindow;
-    return gen;
-}
-
 int check_common(int64_t B, int N, int p_layout, bool qcqp)
 {
     if (B < 0 || N < 1 || B > 0x7fffffffLL) return DQQ_E_BAD_SIZE;
@@ -131,52 +83,39 @@ int dqq_get_option(const char* name, int* value)
     return DQQ_E_BAD_OPTION;
 }
 
+// Routing is a function of (kind, N, B, p_layout) and the process-wide tuning knobs only: two calls with the same
+// arguments launch the same kernels, whatever ran before them, on whatever thread or stream.
 static int fwd_dispatch(int kind, dqq::FwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t s)
 {
     if (a.B == 0) return 0;
-    (void)hipGetLastError(); // drop any stale error of the calling thread: ours are read after each launch
     const bool fast_ok = dqq::fwd_diag_supported(a.N);
-    const bool dense_ok = a.N <= dqq::dense_max_n(kind == dqq::kKindQCQP ? 1 : 0);
-    hipError_t e;
+    const bool dense_ok = dqq::fwd_dense_supported(kind, a.N);
     if (a.layout == DQQ_P_DIAG) {
         if (!fast_ok) return DQQ_E_UNSUPPORTED_N;
-        e = dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), g_fuse.load(), s, nullptr);
-        return (int)e;
+        return (int)dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), g_fuse.load(), s, nullptr);
     }
     if (a.layout == DQQ_P_DENSE || !fast_ok) {
         if (!dense_ok) return DQQ_E_UNSUPPORTED_N;
-        e = dqq::launch_fwd_dense(kind, a, false, s);
-        return (int)e;
+        return (int)dqq::launch_fwd_dense(kind, a, false, s);
     }
     // DQQ_P_AUTO: fast path over every tile; non-diagonal tiles are solved inside it (small N) or
     // queued for the dense kernel launched right behind it
     if (int rc = check_ws(workspace, workspace_bytes, a.B)) return rc;
     a.ws = static_cast<int*>(workspace);
+    const bool fused = dqq::fwd_diag_will_fuse(a.N, a.B, a.layout, g_fuse.load());
+    if (!fused && !dense_ok) return DQQ_E_UNSUPPORTED_N; // a queued tile would never be solved: refuse up front
     bool needs_fallback = true;
-    int fuse = g_fuse.load();
-    if (fuse < 0 && (dqq::fwd_lane_dense_supported(a.N) || dqq::fwd_small_supported(a.N))) {
-        a.hint = hint_device_pointer();
-        if (a.hint != nullptr) {
-            bool dense_before = false;
-            a.hint_gen = hint_next_generation(&dense_before);
-            if (dense_before) fuse = 0; // dense batch: queue the tiles for the lane-per-problem kernel
-            g_last_auto_dense.store(dense_before ? 1 : 0);
-        }
-    }
-    e = dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), fuse, s, &needs_fallback);
+    hipError_t e = dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), g_fuse.load(), s, &needs_fallback);
     if (e != hipSuccess) return (int)e;
-    if (needs_fallback && dense_ok && g_auto_fallback.load() != 0) e = dqq::launch_fwd_dense(kind, a, true, s);
+    if (needs_fallback && g_auto_fallback.load() != 0) e = dqq::launch_fwd_dense(kind, a, true, s);
     return (int)e;
 }
 
 static int bwd_dispatch(int kind, dqq::BwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t s)
 {
     if (a.B == 0) return 0;
-    (void)hipGetLastError();
     const bool fast_ok = dqq::bwd_diag_supported(a.N);
-    const bool dense_ok = a.N <= dqq::dense_max_n(kind == 0 ? 0 : (kind == dqq::kKindBox ? 3 : 2)) ||
-                          dqq::bwd_block_sys_supported(kind, a.N);
-    hipError_t e;
+    const bool dense_ok = dqq::bwd_dense_supported(kind, a.N);
     if (a.layout == DQQ_P_DIAG) {
         if (!fast_ok) return DQQ_E_UNSUPPORTED_N;
         return (int)dqq::launch_bwd_diag(kind, a, g_wpb.load(), g_fuse.load(), s, nullptr);
@@ -187,12 +126,12 @@ static int bwd_dispatch(int kind, dqq::BwdArgs& a, void* workspace, size_t works
     }
     if (int rc = check_ws(workspace, workspace_bytes, a.B)) return rc;
     a.ws = static_cast<int*>(workspace);
+    const bool fused = dqq::bwd_diag_will_fuse(kind, a.N, a.B, a.layout, g_fuse.load());
+    if (!fused && !dense_ok) return DQQ_E_UNSUPPORTED_N; // (box QP, N > 32): nothing could drain the work-list
     bool needs_fallback = true;
-    int fuse = g_fuse.load();
-    if (fuse < 0 && g_last_auto_dense.load() != 0) fuse = 0; // the forward found a dense batch: packed general kernel
-    e = dqq::launch_bwd_diag(kind, a, g_wpb.load(), fuse, s, &needs_fallback);
+    hipError_t e = dqq::launch_bwd_diag(kind, a, g_wpb.load(), g_fuse.load(), s, &needs_fallback);
     if (e != hipSuccess) return (int)e;
-    if (needs_fallback && dense_ok && g_auto_fallback.load() != 0) e = dqq::launch_bwd_dense(kind, a, true, s);
+    if (needs_fallback && g_auto_fallback.load() != 0) e = dqq::launch_bwd_dense(kind, a, true, s);
     return (int)e;
 }
 
@@ -204,7 +143,7 @@ int dqq_qp_fwd_f64(const double* P, const double* q, double* x, int64_t B, int N
     if (B > 0 && (P == nullptr || q == nullptr || x == nullptr)) return DQQ_E_NULLPTR;
     const bool keep = p_layout == DQQ_P_AUTO && dqq::fwd_diag_supported(N);
     dqq::FwdArgs a{P,        q,     nullptr, nullptr, nullptr, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0,
-                   p_layout, iters, nullptr, keep ? pdiag_out : nullptr, keep ? diag_flags_out : nullptr, nullptr, 0};
+                   p_layout, iters, nullptr, keep ? pdiag_out : nullptr, keep ? diag_flags_out : nullptr};
     if (!keep && diag_flags_out != nullptr && B > 0) { // nothing will be verified: flag every problem 0
         hipError_t e = hipMemsetAsync(diag_flags_out, 0, (size_t)B, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return (int)e;
@@ -222,7 +161,7 @@ int dqq_qcqp_fwd_f64(const double* P, const double* q, const double* l_n, const 
         return DQQ_E_NULLPTR;
     const bool keep = p_layout == DQQ_P_AUTO && dqq::fwd_diag_supported(N);
     dqq::FwdArgs a{P,     q,       l_n, mu, nullptr, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0, p_layout,
-                   iters, nullptr, keep ? pdiag_out : nullptr, keep ? diag_flags_out : nullptr, nullptr, 0};
+                   iters, nullptr, keep ? pdiag_out : nullptr, keep ? diag_flags_out : nullptr};
     if (!keep && diag_flags_out != nullptr && B > 0) {
         hipError_t e = hipMemsetAsync(diag_flags_out, 0, (size_t)B, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return (int)e;
@@ -242,7 +181,7 @@ static int box_fwd(const double* P, const double* q, const double* l_min, const 
         return DQQ_E_NULLPTR;
     const bool keep = p_layout == DQQ_P_AUTO && dqq::fwd_diag_supported(N);
     dqq::FwdArgs a{P,        q,     l_min,   l_max, v, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0,
-                   p_layout, iters, nullptr, keep ? pdiag_out : nullptr, keep ? diag_flags_out : nullptr, nullptr, 0};
+                   p_layout, iters, nullptr, keep ? pdiag_out : nullptr, keep ? diag_flags_out : nullptr};
     if (!keep && diag_flags_out != nullptr && B > 0) {
         hipError_t e = hipMemsetAsync(diag_flags_out, 0, (size_t)B, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return (int)e;

@@ -33,8 +33,9 @@ constexpr int kIrMaxIter = 10;
 constexpr double kActiveEps = 1e-10;
 
 // 1/sqrt(x) and 1/x to ~1 ulp: hardware seed (v_rsq_f64 / v_rcp_f64, ~2^-24
-// relative) + two Newton steps -- about a third of the instructions of the
-// IEEE sqrt + divide sequences they stand in for in the forward fast path.
+// relative) + one third-order step (rsqrt) / two Newton steps (rcp) -- about a
+// third of the instructions of the IEEE sqrt + divide sequences they stand in
+// for in the forward fast path.
 DQQ_HD double fast_rsqrt(double x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -72,6 +72,11 @@ int dense_max_n(int kind)
     return kDenseMaxRows;
 }
 
+// what the general path can take at all (include/diffqcqp_hip.h: dqq_max_n)
+// what the general path can take at all: everything (beyond dqq_max_n: the global-memory kernels of general_any.hip)
+bool fwd_dense_supported(int kind, int N) { return N >= 1 && !(kind == kKindQCQP && (N & 1)); }
+bool bwd_dense_supported(int kind, int N) { return N >= 1 && !(kind == kKindQCQP && (N & 1)); }
+
 template <typename K>
 static hipError_t set_lds(K kernel, size_t bytes)
 {
@@ -109,15 +114,15 @@ static hipError_t launch_fwd_wave(const FwdArgs& a, bool use_worklist, hipStream
     const DenseGeom g = dense_geom(dense_fwd_lds_doubles(a.N), a.B, use_worklist);
     hipError_t e = set_lds(fwd_dense_kernel<KIND>, g.lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fwd_dense_kernel<KIND>, dim3(g.grid), dim3(64 * g.wpb), g.lds_bytes, s, a.P, a.q, a.l_n, a.mu, a.v,
+    return launch(fwd_dense_kernel<KIND>, dim3(g.grid), dim3(64 * g.wpb), g.lds_bytes, s, a.P, a.q, a.l_n, a.mu, a.v,
                        a.x, a.B, a.N, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0,
                        g.lds_per_wave);
-    return hipGetLastError();
 }
 
 hipError_t launch_fwd_dense(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
+    if (a.N > dense_max_n(kind == kKindQCQP ? 1 : 0)) return launch_fwd_any(kind, a, use_worklist, s);
     if (fwd_lane_dense_supported(a.N) && g_lane_dense.load() != 0)
         return launch_fwd_lane_dense(kind, a, use_worklist, s);
     if (fwd_small_supported(a.N) && g_small_fwd.load() != 0) return launch_fwd_small(kind, a, use_worklist, s);
@@ -150,10 +155,9 @@ static hipError_t launch_bwd_team(const BwdArgs& a, bool use_worklist, hipStream
     auto kernel = bwd_dense_kernel<KIND, T>;
     hipError_t e = set_lds(kernel, lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * wpb), lds_bytes, s, a.P, a.q, a.l_n, a.mu, a.x, a.grad_x, a.grad_P,
+    return launch(kernel, dim3(grid), dim3(64 * wpb), lds_bytes, s, a.P, a.q, a.l_n, a.mu, a.x, a.grad_x, a.grad_P,
                        a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.N, a.epsilon, a.ir_steps, a.ws,
                        use_worklist ? 1 : 0, lds_per_team);
-    return hipGetLastError();
 }
 
 template <int KIND>
@@ -176,12 +180,13 @@ hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipSt
         return launch_bwd_dense_wave64(kind, a, use_worklist, s);
     if (bwd_dense_block_supported(kind, a.N) && g_dense_block.load() != 0)
         return launch_bwd_dense_block(kind, a, use_worklist, s);
-    // QCQP N = 32 / 64, box N = 16 / 32: workgroup kernel on the matrix cores.  It is the only general kernel
-    // beyond the wave kernel's 64 rows (QCQP N > 42, box N > 21); below that the wave kernel stays the default
-    // because it keeps the reference's summation order and these Tikhonov systems amplify rounding by up to
-    // cond(K) ~ 1e9 (option "block_bwd" = 1 prefers the 10x faster workgroup kernel).
-    if (bwd_block_sys_supported(kind, a.N) && (g_block_bwd.load() != 0 || a.N > dense_max_n(kind == kKindBox ? 3 : 2)))
-        return launch_bwd_block_sys(kind, a, use_worklist, s);
+    // Systems beyond the wave kernel's 64 rows (QP N > 64, QCQP N > 42, box N > 21): the global-memory kernel in the
+    // reference's summation order.  The workgroup kernel on the matrix cores (QCQP N <= 64, box N <= 32) is several
+    // times faster but associates the sums of these Tikhonov systems differently -- cond(K) ~ 1e9 turns that into up
+    // to 1e-5 relative on a few problems -- so it is the opt-in (option "block_bwd" = 1), also where the wave
+    // kernel would do (QCQP 22 <= N <= 42, box 11 <= N <= 21).
+    if (bwd_block_sys_supported(kind, a.N) && g_block_bwd.load() != 0) return launch_bwd_block_sys(kind, a, use_worklist, s);
+    if (a.N > dense_max_n(kind == kKindQP ? 0 : (kind == kKindBox ? 3 : 2))) return launch_bwd_any(kind, a, use_worklist, s);
     if (kind == kKindBox) return launch_bwd_kind<2>(a, use_worklist, s);
     return kind == 0 ? launch_bwd_kind<0>(a, use_worklist, s) : launch_bwd_kind<1>(a, use_worklist, s);
 }

@@ -98,10 +98,6 @@ struct WaveRows {
     }
 };
 
-// The reference normalises the power-iteration vector after every step (Solver.cpp:53); a normalisation only
-// rescales the vector, so here it is applied every 10th step (and after the last one): the direction --
-// hence the Rayleigh quotient the reference returns -- is the same up to rounding (~1e-15 relative), and a
-// factor lambda_max^10 between normalisations cannot overflow for any P whose solve makes sense.
 template <int KIND, int N>
 __global__ __launch_bounds__(256, N == 32 ? 3 : 2) void fwd_dense_block_kernel(const double* __restrict__ P,
                                                               const double* __restrict__ q,
@@ -144,11 +140,8 @@ __global__ __launch_bounds__(256, N == 32 ? 3 : 2) void fwd_dense_block_kernel(c
         const int pi_steps = QP_LIKE ? 10 : 100;
         for (int k = 0; k < pi_steps; ++k) {
             const double Av = wr.matvec(m, v);
-            v = Av;
-            if ((k % 10) == 9) { // normalise every 10th step only (see the note above the kernel)
-                const double s = WR::sum_rows(Av * Av);
-                if (s > 0) v = Av / sqrt(s);
-            }
+            const double s = WR::sum_rows(Av * Av); // normalised every step like the reference (:53)
+            v = s > 0 ? Av / sqrt(s) : Av;
         }
         const double Lmax = WR::sum_rows(v * wr.matvec(m, v));
         bool bad = false;
@@ -248,9 +241,8 @@ static hipError_t launch_block(const FwdArgs& a, bool use_worklist, hipStream_t 
     if (e != hipSuccess) return e;
     const long cap = 256L * (N == 32 ? 3 : 2) * 2; // persistent: 2 (N=64, LDS) or 3 (N=32, VGPRs) workgroups per CU, x2 for balance
     const unsigned grid = use_worklist ? 512u : (unsigned)(a.B < cap ? (a.B > 0 ? a.B : 1) : cap);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), G::LDS_BYTES, s, a.P, a.q, a.l_n, a.mu, a.v, a.x, a.B, a.eps, a.mu_prox,
+    return launch(kernel, dim3(grid), dim3(256), G::LDS_BYTES, s, a.P, a.q, a.l_n, a.mu, a.v, a.x, a.B, a.eps, a.mu_prox,
                        a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0);
-    return hipGetLastError();
 }
 
 bool fwd_dense_block_supported(int N) { return N == 32 || N == 64; }
@@ -397,9 +389,8 @@ static hipError_t launch_block_bwd(const BwdArgs& a, bool use_worklist, hipStrea
     if (e != hipSuccess) return e;
     const long cap = 256L * 2 * 4;
     const unsigned grid = use_worklist ? 512u : (unsigned)(a.B < cap ? (a.B > 0 ? a.B : 1) : cap);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), G::LDS_BYTES, s, a.P, a.q, a.x, a.grad_x, a.grad_P, a.grad_q, a.B,
+    return launch(kernel, dim3(grid), dim3(256), G::LDS_BYTES, s, a.P, a.q, a.x, a.grad_x, a.grad_P, a.grad_q, a.B,
                        a.epsilon, a.ir_steps, a.ws, use_worklist ? 1 : 0);
-    return hipGetLastError();
 }
 
 bool bwd_dense_block_supported(int kind, int N) { return kind == 0 && (N == 32 || N == 64); }

@@ -187,9 +187,8 @@ static hipError_t launch_wave64(const FwdArgs& a, bool use_worklist, hipStream_t
     // work-list mode: a fixed grid of 8 waves per CU strides over the list
     const long cap = 1L << 22;
     const unsigned grid = use_worklist ? 2048u : (unsigned)(a.B < cap ? a.B : cap);
-    hipLaunchKernelGGL(fwd_dense_wave64_kernel<KIND>, dim3(grid), dim3(64), 0, s, a.P, a.q, a.l_n, a.mu, a.v, a.x, a.B,
+    return launch(fwd_dense_wave64_kernel<KIND>, dim3(grid), dim3(64), 0, s, a.P, a.q, a.l_n, a.mu, a.v, a.x, a.B,
                        a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0);
-    return hipGetLastError();
 }
 
 bool fwd_dense_wave64_supported(int N) { return N == 64; }
@@ -375,9 +374,8 @@ hipError_t launch_bwd_dense_wave64(int kind, const BwdArgs& a, bool use_worklist
     if (kind != 0 || a.N != 64) return hipErrorInvalidValue;
     const long cap = 1L << 22;
     const unsigned grid = use_worklist ? 2048u : (unsigned)(a.B < cap ? a.B : cap);
-    hipLaunchKernelGGL(bwd_dense_wave64_qp_kernel, dim3(grid), dim3(64), 0, s, a.P, a.q, a.x, a.grad_x, a.grad_P, a.grad_q,
+    return launch(bwd_dense_wave64_qp_kernel, dim3(grid), dim3(64), 0, s, a.P, a.q, a.x, a.grad_x, a.grad_P, a.grad_q,
                        a.B, a.epsilon, a.ir_steps, a.ws, use_worklist ? 1 : 0);
-    return hipGetLastError();
 }
 
 } // namespace dqq

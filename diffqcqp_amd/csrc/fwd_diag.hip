@@ -32,7 +32,7 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
                                                             const double* __restrict__ v_sign, double* __restrict__ x,
                                                             long B, double eps, double mu_prox, int max_iter,
                                                             int adaptive, int layout, int* __restrict__ iters,
-                                                            int* __restrict__ ws, int* __restrict__ hint, int hint_gen,
+                                                            int* __restrict__ ws,
                                                             double* __restrict__ pdiag_out,
                                                             unsigned char* __restrict__ flags_out)
 {
@@ -73,10 +73,6 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
                                             : stream_tile_diag<N, NCH, true>(Pw, limit, sd, lane);
         if (__any(nz != 0)) { // wave-uniform
             if (flags_out != nullptr && valid && (lane % LPP) == 0) flags_out[first + pl] = 0;
-            // tell the host (performance hint only, read without synchronisation before the NEXT call) that
-            // this launch met a non-diagonal tile: one posted store per launch, de-duplicated in L2
-            if (hint != nullptr && lane == 0 && atomicMax(&ws[kWsHintGen], hint_gen) < hint_gen)
-                __hip_atomic_store(hint, hint_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if constexpr (FUSE) {
                 for (int j = 0; j < nvalid; ++j)
                     dense_fwd_problem<KIND>(P, q, l_n, mu_c, v_sign, x, iters, first + j, N, eps, mu_prox, max_iter,
@@ -152,10 +148,9 @@ static hipError_t launch_one(const FwdArgs& a, hipStream_t s)
     const long ntiles = (a.B + PPW - 1) / PPW;
     const long nblocks = (ntiles + WPB - 1) / WPB;
     if (nblocks == 0) return hipSuccess;
-    hipLaunchKernelGGL((fwd_diag_kernel<KIND, N, LPP, WPB, FUSE>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q,
-                       a.l_n, a.mu, a.v, a.x, a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.layout, a.iters, a.ws, a.hint, a.hint_gen,
+    return launch((fwd_diag_kernel<KIND, N, LPP, WPB, FUSE>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q,
+                       a.l_n, a.mu, a.v, a.x, a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.layout, a.iters, a.ws,
                        a.pdiag_out, a.flags_out);
-    return hipGetLastError();
 }
 
 template <int KIND, int N, int LPP>
@@ -222,6 +217,12 @@ static bool launch_kind(const FwdArgs& a, int lpp, int wpb, bool fuse, hipStream
 // batch is large enough to want more than two waves per SIMD; below that it saves the extra launch.
 bool fwd_diag_fuses_fallback(int N, long B) { return fwd_diag_supported(N) && fwd_diag_fuses(N) && B <= 131072; }
 
+bool fwd_diag_will_fuse(int N, long B, int layout, int fuse_opt)
+{
+    return layout != DQQ_P_DIAG && fwd_diag_supported(N) && fwd_diag_fuses(N) &&
+           (fuse_opt < 0 ? fwd_diag_fuses_fallback(N, B) : fuse_opt != 0);
+}
+
 // lpp / wpb == 0 -> built-in choice; an lpp the kernel is not instantiated for falls back to the
 // built-in one.  *needs_fallback: the caller must launch the dense kernel in work-list mode next.
 hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fuse_opt, hipStream_t s,
@@ -229,8 +230,7 @@ hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fus
 {
     if (wpb != 1 && wpb != 4) wpb = 4;
     if (lpp <= 0) lpp = fwd_diag_default_lpp(a.N, a.B);
-    const bool fuse = a.layout != DQQ_P_DIAG && fwd_diag_fuses(a.N) &&
-                      (fuse_opt < 0 ? fwd_diag_fuses_fallback(a.N, a.B) : fuse_opt != 0);
+    const bool fuse = fwd_diag_will_fuse(a.N, a.B, a.layout, fuse_opt);
     if (needs_fallback) *needs_fallback = (a.layout == DQQ_P_AUTO) && !fuse;
     hipError_t e = hipErrorInvalidValue;
     auto dispatch = [&](int l) {

@@ -66,10 +66,9 @@ DQQ_D void lane_chol_inverse(const double (&Plow)[N][N], const double (&d)[N], d
     }
 }
 
-// The reference normalises the power-iteration vector after every step (Solver.cpp:53); a normalisation only
-// rescales the vector, so here it is applied every 10th step (and after the last one): the direction --
-// hence the Rayleigh quotient the reference returns -- is the same up to rounding (~1e-15 relative), and a
-// factor lambda_max^10 between normalisations cannot overflow for any P whose solve makes sense.
+// The power-iteration vector is normalised after every step, like the reference (Solver.cpp:53), by a 1-ulp
+// reciprocal square root: lambda_max^10 between two normalisations would leave the double range for
+// |lambda_max| beyond ~1e15 or below ~1e-15, which the diagonal fast path (exact power-of-two scaling) handles.
 template <int KIND, int N>
 __global__ __launch_bounds__(64, 1) void fwd_lane_dense_kernel(const double* __restrict__ P,
                                                                const double* __restrict__ q,
@@ -162,8 +161,9 @@ __global__ __launch_bounds__(64, 1) void fwd_lane_dense_kernel(const double* __r
                     Av[i] = t;
                     s += t * t;
                 }
-                // normalise after the last step only (see the note above the kernel)
-                const double inv = (k == 9 && s > 0) ? fast_rsqrt(s) : 1.0;
+                // normalised every step like the reference (Solver.cpp:53): lambda_max^10 between two
+                // normalisations would overflow / underflow for |lambda_max| beyond ~1e15 / below ~1e-15
+                const double inv = s > 0 ? fast_rsqrt(s) : 1.0;
 #pragma unroll
                 for (int i = 0; i < N; ++i) v[i] = Av[i] * inv;
             }
@@ -338,9 +338,8 @@ static hipError_t launch_lane(const FwdArgs& a, bool use_worklist, hipStream_t s
 {
     const long nw = (a.B + 63) / 64;
     if (nw == 0) return hipSuccess;
-    hipLaunchKernelGGL((fwd_lane_dense_kernel<KIND, N>), dim3((unsigned)nw), dim3(64), 0, s, a.P, a.q, a.l_n, a.mu, a.v, a.x,
+    return launch((fwd_lane_dense_kernel<KIND, N>), dim3((unsigned)nw), dim3(64), 0, s, a.P, a.q, a.l_n, a.mu, a.v, a.x,
                        a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0);
-    return hipGetLastError();
 }
 
 bool fwd_lane_dense_supported(int N) { return N == 2 || N == 4 || N == 6 || N == 8; }

@@ -95,10 +95,9 @@ struct TeamSolve {
     }
 };
 
-// The reference normalises the power-iteration vector after every step (Solver.cpp:53); a normalisation only
-// rescales the vector, so here it is applied every 10th step (and after the last one): the direction --
-// hence the Rayleigh quotient the reference returns -- is the same up to rounding (~1e-15 relative), and a
-// factor lambda_max^10 between normalisations cannot overflow for any P whose solve makes sense.
+// The power-iteration vector is normalised after every step, like the reference (Solver.cpp:53), by a 1-ulp
+// reciprocal square root: lambda_max^10 between two normalisations would leave the double range for
+// |lambda_max| beyond ~1e15 or below ~1e-15, which the diagonal fast path (exact power-of-two scaling) handles.
 template <int KIND, int N>
 __global__ __launch_bounds__(256, N >= 14 ? 1 : 2) void fwd_small_kernel(const double* __restrict__ P, const double* __restrict__ q,
                                                         const double* __restrict__ l_n,
@@ -163,11 +162,8 @@ __global__ __launch_bounds__(256, N >= 14 ? 1 : 2) void fwd_small_kernel(const d
         for (int k = 0; k < pi_steps; ++k) {
             double Av = ts.matvec(Prow, v);
             if (!actn) Av = 0.0;
-            v = Av;
-            if ((k % 10) == 9) { // normalise every 10th step only (see the note above the kernel)
-                const double s = G::sum(Av * Av);
-                if (s > 0) v = Av * fast_rsqrt(s);
-            }
+            const double s = G::sum(Av * Av);
+            v = s > 0 ? Av * fast_rsqrt(s) : Av;
         }
         double Av = ts.matvec(Prow, v);
         if (!actn) Av = 0.0;
@@ -256,9 +252,8 @@ static hipError_t launch_small_fwd(const FwdArgs& a, bool use_worklist, hipStrea
     const long per_block = (long)WPB * TP;
     const long nb = (a.B + per_block - 1) / per_block;
     if (nb == 0) return hipSuccess;
-    hipLaunchKernelGGL((fwd_small_kernel<KIND, N>), dim3((unsigned)nb), dim3(64 * WPB), lds_bytes, s, a.P, a.q, a.l_n, a.mu,
+    return launch((fwd_small_kernel<KIND, N>), dim3((unsigned)nb), dim3(64 * WPB), lds_bytes, s, a.P, a.q, a.l_n, a.mu,
                        a.v, a.x, a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0);
-    return hipGetLastError();
 }
 
 bool fwd_small_supported(int N) { return N == 10 || N == 12 || N == 14 || N == 16; }

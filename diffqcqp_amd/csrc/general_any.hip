@@ -1,0 +1,109 @@
+// general_any.hip -- the general (dense P) kernels without a size limit: one 256-thread workgroup per problem,
+// matrices in a per-workgroup slice of global memory (any_core.h).  Takes every N the register / LDS kernels do
+// not hold (forward and QP backward N > 64, QCQP backward N > 42, box QP backward N > 21) in the reference's
+// operation order.  The scratch slices come from the stream-ordered allocator (hipMallocAsync / hipFreeAsync on
+// the caller's stream: no synchronisation, and the only entry points that allocate).
+#include "any_core.h"
+#include "launch.h"
+
+namespace dqq {
+
+template <int KIND>
+__global__ __launch_bounds__(kAnyT) void fwd_any_kernel(const double* __restrict__ P, const double* __restrict__ q,
+                                                        const double* __restrict__ l_n, const double* __restrict__ mu_c,
+                                                        const double* __restrict__ v_sign, double* __restrict__ x, long B,
+                                                        int n, double eps, double mu, int max_iter, int adaptive,
+                                                        int* __restrict__ iters, int* __restrict__ ws, int use_worklist,
+                                                        double* __restrict__ scratch, long scratch_stride)
+{
+    __shared__ double red[kAnyT];
+    const int t = threadIdx.x;
+    double* scr = scratch + (long)blockIdx.x * scratch_stride;
+    const long count = use_worklist ? (long)ws[kWsCount] : B;
+    for (long w = blockIdx.x; w < count; w += gridDim.x) {
+        const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
+        any_fwd_problem<KIND>(P, q, l_n, mu_c, v_sign, x, iters, prob, n, eps, mu, max_iter, adaptive, scr, red, t);
+    }
+    if (use_worklist && t == 0) worklist_release(ws, count, (int)gridDim.x);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(kAnyT) void bwd_any_kernel(
+    const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ l_n,
+    const double* __restrict__ mu_c, const double* __restrict__ x, const double* __restrict__ grad_x,
+    double* __restrict__ grad_P, double* __restrict__ grad_q, double* __restrict__ grad_l_n,
+    double* __restrict__ grad_mu, double* __restrict__ gamma_out, double* __restrict__ dgamma_out, long B, int n,
+    double dual_eps, int* __restrict__ ir_steps, int* __restrict__ ws, int use_worklist, double* __restrict__ scratch,
+    long scratch_stride)
+{
+    const int t = threadIdx.x;
+    double* scr = scratch + (long)blockIdx.x * scratch_stride;
+    const long count = use_worklist ? (long)ws[kWsCount] : B;
+    for (long w = blockIdx.x; w < count; w += gridDim.x) {
+        const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
+        any_bwd_problem<KIND>(P, q, l_n, mu_c, x, grad_x, grad_P, grad_q, grad_l_n, grad_mu, gamma_out, dgamma_out,
+                              ir_steps, prob, n, dual_eps, scr, t);
+    }
+    if (use_worklist && t == 0) worklist_release(ws, count, (int)gridDim.x);
+}
+
+// persistent grid: two workgroups per CU when the batch is that large
+static unsigned any_grid(long B, bool use_worklist)
+{
+    const long cap = 512;
+    return use_worklist ? (unsigned)cap : (unsigned)(B < cap ? (B > 0 ? B : 1) : cap);
+}
+
+template <int KIND>
+static hipError_t launch_fwd_any_kind(const FwdArgs& a, bool use_worklist, hipStream_t s)
+{
+    const unsigned grid = any_grid(a.B, use_worklist);
+    const long stride = (any_fwd_scratch_doubles(a.N) + 1) & ~1L;
+    double* scratch = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(double) * (size_t)stride * grid, s);
+    if (e != hipSuccess) return e;
+    e = launch(fwd_any_kernel<KIND>, dim3(grid), dim3(kAnyT), 0, s, a.P, a.q, a.l_n, a.mu, a.v, a.x, a.B, a.N, a.eps,
+               a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0, scratch, stride);
+    const hipError_t f = hipFreeAsync(scratch, s);
+    return e != hipSuccess ? e : f;
+}
+
+hipError_t launch_fwd_any(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s)
+{
+    if (a.B == 0) return hipSuccess;
+    switch (kind) {
+    case 0: return launch_fwd_any_kind<0>(a, use_worklist, s);
+    case 1: return launch_fwd_any_kind<1>(a, use_worklist, s);
+    case 2: return launch_fwd_any_kind<2>(a, use_worklist, s);
+    case 3: return launch_fwd_any_kind<3>(a, use_worklist, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int KIND>
+static hipError_t launch_bwd_any_kind(const BwdArgs& a, bool use_worklist, hipStream_t s)
+{
+    const unsigned grid = any_grid(a.B, use_worklist);
+    const long stride = (any_bwd_scratch_doubles(KIND, a.N) + 1) & ~1L;
+    double* scratch = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(double) * (size_t)stride * grid, s);
+    if (e != hipSuccess) return e;
+    e = launch(bwd_any_kernel<KIND>, dim3(grid), dim3(kAnyT), 0, s, a.P, a.q, a.l_n, a.mu, a.x, a.grad_x, a.grad_P,
+               a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.N, a.epsilon, a.ir_steps, a.ws,
+               use_worklist ? 1 : 0, scratch, stride);
+    const hipError_t f = hipFreeAsync(scratch, s);
+    return e != hipSuccess ? e : f;
+}
+
+hipError_t launch_bwd_any(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)
+{
+    if (a.B == 0) return hipSuccess;
+    switch (kind) {
+    case kKindQP: return launch_bwd_any_kind<0>(a, use_worklist, s);
+    case kKindQCQP: return launch_bwd_any_kind<1>(a, use_worklist, s);
+    case kKindBox: return launch_bwd_any_kind<2>(a, use_worklist, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace dqq

@@ -5,6 +5,11 @@
 #include "../../include/diffqcqp_hip.h"
 #include "common.h"
 
+#if defined(__HIPCC__)
+#include <tuple>
+#include <utility>
+#endif
+
 namespace dqq {
 
 // Fallback work-list in the caller's workspace (ints).  [0] number of queued
@@ -12,7 +17,6 @@ namespace dqq {
 // re-zeroes both), entries from [kWsEntries].
 constexpr int kWsCount = 0;
 constexpr int kWsTicket = 1;
-constexpr int kWsHintGen = 2; // generation of the last launch that already reported a non-diagonal tile
 constexpr int kWsEntries = 4;
 
 
@@ -33,6 +37,26 @@ static DQQ_D void worklist_release(int* ws, long count, int participants)
 }
 #endif
 
+#if defined(__HIPCC__)
+// Kernel launch that reports ITS OWN status: hipLaunchKernel's return value, not hipGetLastError() -- the
+// thread's sticky error slot belongs to the caller (a stale error of theirs is neither returned as ours nor
+// cleared).
+template <typename... KArgs, typename... Args, size_t... I>
+static inline hipError_t launch_impl(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t s,
+                                     std::index_sequence<I...>, Args&&... args)
+{
+    std::tuple<KArgs...> params{static_cast<KArgs>(args)...};
+    void* ptrs[] = {static_cast<void*>(&std::get<I>(params))...};
+    return hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, lds, s);
+}
+template <typename... KArgs, typename... Args>
+static inline hipError_t launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t s, Args&&... args)
+{
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel argument count");
+    return launch_impl(kernel, grid, block, lds, s, std::index_sequence_for<KArgs...>{}, std::forward<Args>(args)...);
+}
+#endif
+
 struct FwdArgs {
     const double* P;
     const double* q;
@@ -48,8 +72,6 @@ struct FwdArgs {
     int* ws;
     double* pdiag_out;         // optional (B,N): the diagonal of P, for the backward of the same problems
     unsigned char* flags_out;  // optional (B): 1 = the problem's tile was verified diagonal
-    int* hint;    // host-mapped word: generation of the last launch that met a non-diagonal tile (may be null)
-    int hint_gen; // generation of this launch
 };
 
 struct BwdArgs {
@@ -94,6 +116,12 @@ int fwd_diag_default_lpp(int N, long B);
 // in work-list mode behind this one.
 hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fuse_opt, hipStream_t s,
                            bool* needs_fallback);
+// the launchers' own decision, for the dispatcher: true = non-diagonal tiles are solved inside the fast kernel
+bool fwd_diag_will_fuse(int N, long B, int layout, int fuse_opt);
+bool bwd_diag_will_fuse(int kind, int N, long B, int layout, int fuse_opt);
+// does the general path have a kernel for this size at all
+bool fwd_dense_supported(int kind, int N);
+bool bwd_dense_supported(int kind, int N);
 bool bwd_diag_supported(int N);
 hipError_t launch_bwd_diag(int kind, const BwdArgs& a, int wpb, int fuse_opt, hipStream_t s, bool* needs_fallback);
 
@@ -114,6 +142,9 @@ hipError_t launch_fwd_dense_wave64(int kind, const FwdArgs& a, bool use_worklist
 bool fwd_dense_block_supported(int N);
 hipError_t launch_fwd_dense_block(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s);
 hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);
+// workgroup-per-problem kernels with the matrices in global memory: any N (general_any.hip)
+hipError_t launch_fwd_any(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s);
+hipError_t launch_bwd_any(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);
 // statically sized team backward for even N <= 16, QP / QCQP (bwd_small.hip); launch_bwd_dense routes to it
 bool bwd_small_supported(int kind, int N);
 hipError_t launch_bwd_small(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);

@@ -28,6 +28,21 @@ from . import ops
 torch.set_default_dtype(torch.double)
 
 
+_FAST_N = (2, 4, 8, 16, 32, 64)
+
+
+def _cache_for(ctx, qd, n_inputs):
+    """Buffers for the verified diagonal of P (forward -> backward of the same problems), only when a backward
+    can follow (some input requires grad) and the diagonal fast path exists for this N."""
+    if qd.shape[1] in _FAST_N and any(ctx.needs_input_grad[:n_inputs]):
+        return ops.diag_cache(qd)
+    return None
+
+
+def _saved_cache(saved):
+    return (saved[-2], saved[-1]) if saved[-1].dtype is torch.uint8 else None
+
+
 def _device_for(t):
     if t.is_cuda:
         return t.device
@@ -45,19 +60,20 @@ class QPFn2(Function):
         else:
             dev = _device_for(q)
             Pd, qd = P.detach().to(dev), q.detach().to(dev)
-        cache = ops.diag_cache(qd)  # verified diagonal of P, reused by backward instead of re-reading P
+        cache = _cache_for(ctx, qd, 2)  # verified diagonal of P, reused by backward instead of re-reading P
         l_2 = ops.qp_forward(Pd, qd, eps, max_iter, mu_prox, adaptive_rho=True, cache=cache)
-        ctx.save_for_backward(Pd, qd, l_2, *cache)
+        ctx.save_for_backward(Pd, qd, l_2, *(cache or ()))
         ctx.home = q.device
         return l_2 if q.is_cuda else l_2.to(q.device)
 
     @staticmethod
     def backward(ctx, grad_l):
-        P, q, l, pdiag, flags = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        P, q, l = saved[:3]
         need_P, need_q = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         grad_P, grad_q = None, None
         if need_P or need_q:
-            grad_P, grad_q = ops.qp_backward(P, q, l, grad_l.to(l.device), need_P, need_q, cache=(pdiag, flags))
+            grad_P, grad_q = ops.qp_backward(P, q, l, grad_l.to(l.device), need_P, need_q, cache=_saved_cache(saved))
             if ctx.home != l.device:
                 grad_P = None if grad_P is None else grad_P.to(ctx.home)
                 grad_q = None if grad_q is None else grad_q.to(ctx.home)
@@ -73,19 +89,20 @@ class QCQPFn2(Function):
             dev = _device_for(q)
             Pd, qd = P.detach().to(dev), q.detach().to(dev)
             lnd, mud = l_n.detach().to(dev), mu.detach().to(dev)
-        cache = ops.diag_cache(qd)
+        cache = _cache_for(ctx, qd, 4)
         l_2 = ops.qcqp_forward(Pd, qd, lnd, mud, eps, max_iter, mu_prox, adaptive_rho=True, cache=cache)
-        ctx.save_for_backward(Pd, qd, lnd, mud, l_2, *cache)
+        ctx.save_for_backward(Pd, qd, lnd, mud, l_2, *(cache or ()))
         ctx.home = q.device
         return l_2 if q.is_cuda else l_2.to(q.device)
 
     @staticmethod
     def backward(ctx, grad_l):
-        P, q, l_n, mu, l, pdiag, flags = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        P, q, l_n, mu, l = saved[:5]
         need = tuple(ctx.needs_input_grad[0:4])
         grads = (None, None, None, None)
         if any(need):
-            grads = ops.qcqp_backward(P, q, l_n, mu, l, grad_l.to(l.device), need, cache=(pdiag, flags))
+            grads = ops.qcqp_backward(P, q, l_n, mu, l, grad_l.to(l.device), need, cache=_saved_cache(saved))
             if ctx.home != l.device:
                 grads = tuple(None if g is None else g.to(ctx.home) for g in grads)
         return grads + (None, None, None, None)
@@ -107,19 +124,20 @@ class BoxQPFn2(Function):
         else:
             dev = _device_for(q)
             Pd, qd, lod, hid = (t.detach().to(dev) for t in tensors)
-        cache = ops.diag_cache(qd)
+        cache = _cache_for(ctx, qd, 4)
         l_2 = ops.boxqp_forward(Pd, qd, lod, hid, eps, max_iter, mu_prox=mu_prox, adaptive_rho=True, cache=cache)
-        ctx.save_for_backward(Pd, qd, lod, hid, l_2, *cache)
+        ctx.save_for_backward(Pd, qd, lod, hid, l_2, *(cache or ()))
         ctx.home = q.device
         return l_2 if q.is_cuda else l_2.to(q.device)
 
     @staticmethod
     def backward(ctx, grad_l):
-        P, q, l_min, l_max, l, pdiag, flags = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        P, q, l_min, l_max, l = saved[:5]
         need = tuple(ctx.needs_input_grad[0:4])
         grads = (None, None, None, None)
         if any(need):
-            grads = ops.boxqp_backward(P, q, l_min, l_max, l, grad_l.to(l.device), need, cache=(pdiag, flags))
+            grads = ops.boxqp_backward(P, q, l_min, l_max, l, grad_l.to(l.device), need, cache=_saved_cache(saved))
             if ctx.home != l.device:
                 grads = tuple(None if g is None else g.to(ctx.home) for g in grads)
         return grads + (None, None, None, None)

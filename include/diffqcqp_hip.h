@@ -18,9 +18,11 @@
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL =
  *     the default stream) and the call returns without synchronising;
  *   - return value: 0 on success, <0 for an invalid argument (DQQ_E_*), >0 a
- *     hipError_t from the launch.  Nothing throws; the only process-wide state is
- *     the tuning knobs of dqq_set_option() and one host-mapped counter used as a
- *     performance hint by DQQ_P_AUTO (it never changes a result);
+ *     hipError_t from the launch (the launch's own status: the calling thread's
+ *     sticky HIP error is neither consumed nor cleared).  Nothing throws.  The only
+ *     process-wide state is the tuning knobs of dqq_set_option(); with those fixed,
+ *     the kernels a call launches -- and therefore its results, bit for bit -- are a
+ *     function of its arguments alone (no history, thread-safe, any stream);
  *   - like the reference (Solver.cpp:76, :100), numerical failure is not
  *     signalled: a non-PD P or L=0 yields NaNs in the output;
  *   - `warm_start` does not appear: the reference accepts it and overwrites it
@@ -50,7 +52,7 @@ extern "C" {
 
 #define DQQ_E_NULLPTR (-1)     /* a required pointer is NULL */
 #define DQQ_E_BAD_SIZE (-2)    /* B < 0, N < 1, odd N for QCQP */
-#define DQQ_E_UNSUPPORTED_N (-3) /* N beyond what the kernels hold in LDS (see dqq_max_n) */
+#define DQQ_E_UNSUPPORTED_N (-3) /* DQQ_P_DIAG only: N is not one of the fast-path sizes 2, 4, 8, 16, 32, 64 */
 #define DQQ_E_BAD_LAYOUT (-4)
 #define DQQ_E_WORKSPACE (-5)   /* workspace missing or too small */
 #define DQQ_E_BAD_OPTION (-6)
@@ -62,9 +64,11 @@ extern "C" {
  * streams. */
 size_t dqq_workspace_bytes(int64_t B);
 
-/* Largest N the wave-per-problem general kernels hold: kind 0 = QP forward/backward and the box forwards
- * (64), 1 = QCQP forward (64), 2 = QCQP backward (42), 3 = box QP backward (21).  The workgroup-per-problem
- * backward takes over beyond 2 and 3: QCQP backward accepts every even N <= 64, box QP backward N <= 32. */
+/* There is no size limit (the reference has none, Solver.cpp:61): this returns the largest N the register / LDS
+ * kernels of the general path hold -- kind 0 = QP forward/backward and the box forwards (64), 1 = QCQP forward (64),
+ * 2 = QCQP backward (42), 3 = box QP backward (21).  Beyond it a workgroup-per-problem kernel works out of global
+ * memory, in the reference's operation order, on scratch it takes from the stream-ordered allocator
+ * (hipMallocAsync / hipFreeAsync on `stream`; the only calls that allocate). */
 int dqq_max_n(int kind);
 
 /* Replaces the loop qcqp.py:29-31 (QPFn2.forward -> diffqcqp.solveQP,
@@ -139,7 +143,7 @@ int dqq_signedboxqp_fwd_f64(const double* P, const double* q, const double* l_mi
  * Any output may be NULL.  gamma / dgamma (B,2N: lower multipliers | upper multipliers, may be NULL) are the
  * reference's per-problem return values: gamma, and blgamma[0:2N]; blgamma[2N:3N] = -grad_q.
  * ir_steps (B,2 ints, may be NULL): refinement steps of the dual recovery and of the derivative system.
- * General (non-diagonal) P: N <= 32 (wave kernel up to dqq_max_n(3) = 21, workgroup kernel beyond). */
+ * General (non-diagonal) P: wave kernel up to dqq_max_n(3) = 21, global-memory workgroup kernel beyond. */
 int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, const double* l_max, const double* x,
                       const double* grad_x, double* grad_P, double* grad_q, double* grad_l_min, double* grad_l_max,
                       double* gamma, double* dgamma, int64_t B, int N, double epsilon, int p_layout, int* ir_steps,
@@ -153,9 +157,9 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
  *                    for the dense kernel launched behind it (0), or decide from B (-1, default)
  *   "dense_teams"    general path, backward: pack 64/T problems per wave for small N (1, default) or one
  *                    problem per wave (0)
- *   "block_bwd"      general path, QCQP 22 <= N <= 42 / box QP 11 <= N <= 21 backward: workgroup kernel on the
- *                    matrix cores (1) or the wave kernel in the reference's summation order (0, default).
- *                    Larger systems (QCQP N <= 64, box QP N <= 32) always use the workgroup kernel.
+ *   "block_bwd"      general path, QCQP 22 <= N <= 64 / box QP 11 <= N <= 32 backward: workgroup kernel on the
+ *                    matrix cores (1: several times faster, sums associated differently -- up to 1e-5 relative on
+ *                    ill-conditioned problems) or the kernels in the reference's summation order (0, default)
  *   "small_fwd"      general path, N = 10..16 forward: team-per-problem kernel (1, default) or the
  *                    wave-per-problem kernel (0)
  *   "small_bwd"      general path, even N <= 16 backward (QP, QCQP): statically sized team kernel (1, default) or the

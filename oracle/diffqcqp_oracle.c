@@ -272,6 +272,13 @@ static int admm_solve(int kind, const double *P_in, const double *q, const doubl
 /* Solver::iterative_refinement, qcqplib/Solver.cpp:15-44, with its defaults
  * mu_ir=1e-7, epsilon=1e-10, max_iter=10.  A is n x n.  Returns the number of
  * loop bodies executed.  ws: 3 n^2 + 4 n. */
+/* Test knob (not in the reference): > 0 makes the refinement loop below run exactly that many bodies,
+ * ignoring its exit tests.  The reference's exit (Solver.cpp:32-41) is decided by rounding noise; this lets a test
+ * evaluate the reference formula at the OTHER exit and show that a kernel which left the loop after 3 bodies
+ * where the oracle left after 1 (or vice versa) still returned what the reference computes at that exit. */
+static int g_force_ir_steps = 0;
+ORC_API void orc_set_force_ir_steps(int steps) { g_force_ir_steps = steps; }
+
 static int iterative_refinement_rect(const double *A, const double *b, int rows, int n, double *x, double *ws)
 {
     /* A is rows x n (row-major); the unknown has n = A.cols() entries.  ws: 3 n^2 + 4 n. */
@@ -309,6 +316,7 @@ static int iterative_refinement_rect(const double *A, const double *b, int rows,
             res_pred = res;
             not_improved = 0;
         }
+        if (g_force_ir_steps > 0) { if (steps >= g_force_ir_steps) break; else continue; }
         if (res < epsilon || not_improved == 2) break; /* :39 */
     }
     return steps;

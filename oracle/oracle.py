@@ -143,6 +143,11 @@ def solveDerivativesBoxQP(P, q, l_min, l_max, l, grad_l, epsilon=1e-10, return_s
 
 # ---- batched API: the loops of qcqp.py:24-52, 144-181 ---------------------------
 
+def set_force_ir_steps(steps):
+    """Test knob: > 0 = iterative_refinement runs exactly `steps` loop bodies (0 restores the reference's exits)."""
+    lib().orc_set_force_ir_steps(ctypes.c_int(int(steps)))
+
+
 def max_threads():
     return lib().orc_max_threads()
 

@@ -47,14 +47,14 @@ def test_argument_validation_without_gpu(lib):
     assert f(one, one, one, 4, 8, 1e-7, 1e-7, 10, 1, 7, None, None, None, None, 0, None) == -4
     assert f(None, one, one, 4, 8, 1e-7, 1e-7, 10, 1, 0, None, None, None, None, 0, None) == -1
     assert f(one, one, one, 4, 8, 1e-7, 1e-7, 10, 1, 0, None, None, None, None, 0, None) == -5  # AUTO needs a workspace
-    assert f(one, one, one, 4, 200, 1e-7, 1e-7, 10, 1, 1, None, None, None, None, 0, None) == -3
+    assert f(one, one, one, 4, 200, 1e-7, 1e-7, 10, 1, 2, None, None, None, None, 0, None) == -3  # compact diagonal: fast-path sizes only
     assert f(one, one, one, 0, 8, 1e-7, 1e-7, 10, 1, 0, None, None, None, None, 0, None) == 0   # empty batch: no-op
     g = lib.dqq_qcqp_fwd_f64
     assert g(one, one, one, one, one, 4, 7, 1e-7, 1e-7, 10, 1, 0, None, None, None, None, 0, None) == -2  # odd N
-    assert lib.dqq_qcqp_bwd_f64(one, one, one, one, one, one, None, None, None, None, None, None, 4, 66, 1e-10, 1,
+    assert lib.dqq_qcqp_bwd_f64(one, one, one, one, one, one, None, None, None, None, None, None, 4, 66, 1e-10, 2,
                                 None, None, None, None, 0, None) == -3
-    assert lib.dqq_boxqp_bwd_f64(one, one, one, one, one, one, None, None, None, None, None, None, 4, 34, 1e-10, 1,
-                                 None, None, None, None, 0, None) == -3  # 3N > 96 unknowns
+    assert lib.dqq_qcqp_bwd_f64(one, one, one, one, one, one, None, None, None, None, None, None, 4, 67, 1e-10, 1,
+                                None, None, None, None, 0, None) == -2  # odd N
     assert lib.dqq_set_option(b"no_such_knob", 1) == -6
 
 
@@ -89,3 +89,21 @@ def test_header_is_plain_c(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
                            "-c", str(src), "-o", str(tmp_path / "use_header.o")])
+
+
+def test_reference_import_lines_resolve():
+    """The reference's own import statements work unchanged against this build: `from diffqcqp import ...`
+    (reference qcqp.py:17), `from qcqp import QPFn2, QCQPFn2` (README.md:31), qcqp_no_batch."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    m = importlib.import_module("diffqcqp")
+    for name in ("solveQP", "solveBoxQP", "solveQCQP", "solveDerivativesQP", "solveDerivativesBoxQP",
+                 "solveDerivativesQCQP", "solveSignedBoxQP"):
+        assert callable(getattr(m, name))
+    q = importlib.import_module("qcqp")
+    assert all(hasattr(q, n) for n in ("QPFn2", "QCQPFn2", "BoxQPFn2", "SignedBoxQPFn2"))
+    nb = importlib.import_module("qcqp_no_batch")
+    assert hasattr(nb, "QPFn2") and hasattr(nb, "QCQPFn2")

@@ -340,7 +340,8 @@ def test_small_dense_backward_is_bit_exact_and_matches_the_wave_kernel(oracle, o
                                       ("qcqp", 50, 24), ("qcqp", 44, 24), ("box", 26, 30), ("box", 22, 30)])
 def test_workgroup_backward_for_large_systems(oracle, ops, kind, N, B):
     """Systems of up to 96 unknowns, padded to 48 / 80 / 96 slots: workgroup-per-problem backward on the matrix
-    cores (bwd_block.hip) -- the only kernel for QCQP 42 < N <= 64 / box 21 < N <= 32, opt-in ("block_bwd") below.
+    cores (bwd_block.hip), opt-in ("block_bwd"; the default beyond the wave kernel is the reference-order
+    global-memory kernel, test_no_size_limit / test_reference_order_backward_beyond_the_wave_kernel).
     Its tile products associate sums differently from the oracle's loops; the Tikhonov systems of this
     backward have cond(K) up to ~1e9 (active contacts: K has eigenvalues next to mu = 1e-7), which turns 1e-16
     into up to ~1e-5 relative on a few problems -- the reference itself would show the same against another
@@ -367,6 +368,25 @@ def test_workgroup_backward_for_large_systems(oracle, ops, kind, N, B):
                              tol=1e-4)
     finally:
         _capi.set_option("block_bwd", 0)
+
+
+@pytest.mark.parametrize("kind,N,B", [("qcqp", 64, 40), ("qcqp", 50, 24), ("qcqp", 44, 24), ("box", 32, 48), ("box", 22, 30)])
+def test_reference_order_backward_beyond_the_wave_kernel(oracle, ops, kind, N, B):
+    """QCQP 42 < N <= 64 / box 21 < N <= 32 by default: the global-memory workgroup kernel in the reference's
+    operation order -- same 1e-9 bar (and identical refinement step counts) as the wave kernel below those sizes."""
+    from diffqcqp_amd import _capi
+    d = make_problem(kind, B, N, 730 + N, "dense")
+    g = dev(d)
+    if kind == "qcqp":
+        xo, _ = oracle_fwd(oracle, kind, d)
+        grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
+        check_backward_exact(grads, st, oracle_bwd(oracle, kind, d, xo), exact=False)
+    else:
+        xo = oracle.boxqp_fwd_batch(d["P"].numpy(), d["q"].numpy(), d["l_min"].numpy(), d["l_max"].numpy(), 1e-7, 1000,
+                                    nthreads=8)[0]
+        ref, out, duals = _box_bwd(oracle, ops, d, xo, layout=_capi.P_DENSE)
+        check_backward_exact(list(out[:4]), out[4], ref[:4] + (ref[5],), exact=False)
+        assert np.allclose(npy(duals[0]), ref[4], rtol=1e-9, atol=1e-12)
 
 
 @pytest.mark.parametrize("N", [3, 5, 7])
@@ -565,8 +585,10 @@ def test_box_backward_dense_and_mixed(oracle, ops, N, B, structure):
         assert np.allclose(npy(duals[0]), ref[4], rtol=1e-9, atol=1e-12)
 
 
-def test_box_end_to_end_and_unsupported_n(oracle, ops):
-    """HIP forward -> HIP backward against the oracle chain; general-P box backward is limited to N <= 21."""
+def test_box_end_to_end_and_large_n(oracle, ops):
+    """HIP forward -> HIP backward against the oracle chain; general-P box backward beyond the wave kernel's
+    N <= 21: the global-memory kernel (default, reference order) -- including N = 64 through DQQ_P_AUTO, the
+    BoxQPFn2 default, where the fast path queues its non-diagonal tiles for it."""
     from diffqcqp_amd import _capi
     d = make_problem("box", 1000, 8, 890)
     xo, ito, xh, ith = _box_fwd(oracle, ops, "box", d)
@@ -574,9 +596,37 @@ def test_box_end_to_end_and_unsupported_n(oracle, ops):
     ref, out, _ = _box_bwd(oracle, ops, d, npy(xh))
     check_end_to_end(list(out[:4]), out[4][:, 1], (ref[0], ref[1], ref[2], ref[3], ref[5][:, 1]))
     assert _capi.lib().dqq_max_n(3) == 21
-    big = dev(make_problem("box", 4, 40, 891, "dense"))  # 3N > 96 unknowns: no general box backward
-    with pytest.raises(ValueError, match="UNSUPPORTED_N"):
-        ops.boxqp_backward(big["P"], big["q"], big["l_min"], big["l_max"], big["q"], big["grad_x"], layout=_capi.P_DENSE)
+    for N, B, structure, layout in ((40, 6, "dense", _capi.P_DENSE), (64, 70, "dense", _capi.P_AUTO),
+                                    (64, 70, "mixed", _capi.P_AUTO), (26, 9, "dense", _capi.P_DENSE)):
+        dd = make_problem("box", B, N, 891 + N, structure)
+        xd = oracle.boxqp_fwd_batch(dd["P"].numpy(), dd["q"].numpy(), dd["l_min"].numpy(), dd["l_max"].numpy(), 1e-7,
+                                    1000, nthreads=8)[0]
+        ref, out, duals = _box_bwd(oracle, ops, dd, xd, layout=layout)
+        check_backward_exact(list(out[:4]), out[4], ref[:4] + (ref[5],), exact=False)
+        assert np.allclose(npy(duals[0]), ref[4], rtol=1e-9, atol=1e-12)
+    # the work-list of the stream is empty again after the mixed AUTO calls
+    assert int(ops._workspace(torch.device("cuda", 0), 70)[:2].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("kind,N,B", [("qp", 65, 5), ("qp", 96, 4), ("qcqp", 70, 4), ("qcqp", 128, 3), ("box", 80, 3),
+                                      ("sbox", 72, 3), ("qp", 131, 2)])
+def test_no_size_limit(oracle, ops, kind, N, B):
+    """The reference solves any n (Solver.cpp:61); beyond what the register / LDS kernels hold (dqq_max_n) the
+    global-memory kernels take over: same trajectory, backward in the reference's operation order."""
+    d = make_problem(kind, B, N, 7000 + N, "dense")
+    g = dev(d)
+    if kind in ("qp", "qcqp"):
+        xo, ito = oracle_fwd(oracle, kind, d)
+        xh, ith = hip_fwd(ops, kind, g)
+        check_forward(xh, ith, xo, ito, min_match=0.99)
+        grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda())
+        check_backward_exact(grads, st, oracle_bwd(oracle, kind, d, xo), exact=False)
+    else:
+        xo, ito, xh, ith = _box_fwd(oracle, ops, kind, d)
+        check_forward(xh, ith, xo, ito, min_match=0.99)
+        if kind == "box":
+            ref, out, _ = _box_bwd(oracle, ops, d, xo)
+            check_backward_exact(list(out[:4]), out[4], ref[:4] + (ref[5],), exact=False)
 
 
 def test_box_autograd_functions_and_module_level_api(oracle, ops):
