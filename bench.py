@@ -1,29 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the batched QP/QCQP hot path on MI355X.
+"""bench.py -- benchmark of the batched QP/QCQP hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--graph] [--no-cpu-baseline]
+    python bench.py [--config {2,3,4,5}] [--gpus N] [--steps K] [--warmup W] [--repeats R] [--streams {1,2}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W [--config 4]
 
-Metric (BASELINE.json): QP+QCQP solves/sec (fwd+bwd) per GPU; achieved HBM GB/s
-vs roofline.  One STEP is one pass of the hot path over one batch of synthetic
-input per GPU:
-    QP   forward + backward on B=65536, N=8, diagonal P in the (B,8,8) layout   (configs[1] + its backward)
-    QCQP forward + backward on the same P, q plus l_n, mu                       (configs[2])
-= 2*B forward+backward solves per GPU per step.  Inputs are resident in HBM when
-the timed region starts; outputs are written to preallocated device buffers.  The
-two families are independent problems: by default their launch chains go to two
-HIP streams (QP fwd -> QP bwd | QCQP fwd -> QCQP bwd), so the HBM-bound backward
-of one overlaps the FP64-VALU-bound forward of the other (--streams 1: one stream;
-its rate is reported as `single_stream`).
-N > 1: one process per GPU, every rank solves its own shard of B problems (weak
-scaling, no data-path collective); the single collective is the final RCCL
-all-gather of the last solution x, inside the timed region.
+Metric (BASELINE.json): QP+QCQP solves/sec (fwd+bwd) per GPU; achieved HBM GB/s vs roofline.  A STEP is one
+pass of the hot path over one batch of synthetic input; inputs are resident in HBM when the timed region starts,
+outputs go to preallocated device buffers, every launch goes through the C ABI (include/diffqcqp_hip.h).
 
-Rank 0 prints ONE JSON line.  Besides the contract keys it carries
-  roofline      dominant kernel: algorithmic bytes per launch / its mean duration (HIP events) vs 8 TB/s
-  cpu_baseline  the oracle (our C port of the reference algorithm) on this box's host cores
-  kernels       per-launch breakdown (mean microseconds, algorithmic GB/s) of the four launches of a step
+Workloads (`--config k` = k-th entry of BASELINE.json `configs`, 1-based as in BASELINE.md section 4):
+  default   the headline: per GPU and step, QP forward+backward [configs[1] + its backward] AND QCQP
+            forward+backward [configs[2]] on B=65536, N=8, diagonal P in the (B,8,8) layout = 2*B solves.  The two
+            families are independent problems on DISTINCT inputs; their launch chains go to two HIP streams
+            (--streams 1: one stream).  Weak scaling.
+  2         B=65536 N=8 diagonal-P QP, forward only                                   (one launch per step)
+  3         B=65536 N=8 QCQP forward+backward
+  4         B=262144 N=32 QP forward+backward, the batch SPLIT over the ranks (strong scaling); `value` includes the
+            RCCL all-gather of x after every step, the rate without it is reported alongside
+  5         B=65536 N=64 dense-P QP forward+backward (P = S S^T/64 + 0.1 I), through DQQ_P_AUTO as QPFn2 calls it
+Timing: W warm-up steps, then R regions of EXACTLY K steps, each bracketed by barrier + torch.cuda.synchronize()
+on both sides and reduced with MAX over the ranks; `ms_per_step` / `value` are the MEDIAN region (min / max in
+`repeats`), so a short K is not a single sub-millisecond sample.
+
+Rank 0 prints ONE JSON line.  Besides the contract keys:
+  roofline      the launch with the largest mean duration: algorithmic bytes / its duration from
+                HIP events on the launch stream vs 8 TB/s; `moved` = the bytes that launch really reads + writes
+                (the backward takes the 64-byte verified diagonal from the forward instead of the 512-byte P);
+                for the compute-bound config 5 also the FP64 figure (`fp64`)
+  cpu_baseline  the oracle (C port of the reference algorithm) on this box's host cores, bounded sample
+  kernels       per-launch breakdown;   cold   the same step over rotating input/output sets (> 256 MiB cache)
 """
 import argparse
 import json
@@ -37,156 +43,171 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-B_PER_GPU = 65536
-N = 8
 EPS, MAX_ITER, MU_PROX = 1e-7, 1000, 1e-7
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md chip table (6290 GB/s measured copy)
-# algorithmic bytes per problem, SURVEY.md 8(d), N=8, float64, dense (B,N,N) P layout
-ALGO_BYTES = {"qp_fwd": 640, "qp_bwd": 1280, "qcqp_fwd": 704, "qcqp_bwd": 1408}
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md chip table (6290 GB/s measured copy)
+FP64_PEAK_TFLOPS = 78.6   # MI355X datasheet, vector = matrix FP64 (not in the local guide; the measured issue
+                          # floor, profiles/fp64_issue_ubench.txt, 2.08 ns per wave64 FMA per SIMD, is 63 TFLOP/s)
+F64 = torch.float64
 
 
-def make_inputs(rank, dev):
-    """p~U(0.1,1.1) -> diag_embed, q~U(-1,1), l_n,mu~U(0,1), grad~N(0,1); CPU generator."""
-    g = torch.Generator().manual_seed(1002 + 7919 * rank)
-    f64 = torch.float64
-    p = torch.rand(B_PER_GPU, N, generator=g, dtype=f64) + 0.1
-    t = {
-        "P": torch.diag_embed(p),
-        "q": 2 * torch.rand(B_PER_GPU, N, 1, generator=g, dtype=f64) - 1,
-        "l_n": torch.rand(B_PER_GPU, N // 2, 1, generator=g, dtype=f64),
-        "mu": torch.rand(B_PER_GPU, N // 2, 1, generator=g, dtype=f64),
-        "g_qp": torch.randn(B_PER_GPU, N, 1, generator=g, dtype=f64),
-        "g_qcqp": torch.randn(B_PER_GPU, N, 1, generator=g, dtype=f64),
-    }
-    return t, {k: v.to(dev).contiguous() for k, v in t.items()}
+def algo_bytes(kind, N, pas):
+    """Algorithmic bytes per problem, SURVEY.md 8(d): float64, dense (B,N,N) P layout, warm_start excluded."""
+    w, nc = 8, N // 2
+    if pas == "fwd":
+        return N * N * w + 2 * N * w + (2 * nc * w if kind == "qcqp" else 0)
+    b = 2 * N * N * w + 4 * N * w
+    return b + (4 * nc * w if kind == "qcqp" else 0)
 
 
-class Plan:
-    """The four launches of a step with every pointer resolved once (no allocation in the loop)."""
+def moved_bytes(kind, N, pas, diag_handoff):
+    """Bytes the launch really reads + writes.  With the diagonal hand-off (DQQ_P_AUTO on diagonal tiles) the
+    forward additionally leaves pdiag (8N) + a flag byte, and the backward reads those instead of P."""
+    b = algo_bytes(kind, N, pas)
+    if not diag_handoff:
+        return b
+    return b + 8 * N + 1 if pas == "fwd" else b - 8 * N * N + 8 * N + 1
 
-    def __init__(self, d, dev):
+
+class Chain:
+    """One problem family on one batch: forward [+ backward] launches with every pointer resolved once."""
+
+    def __init__(self, kind, B, N, structure, backward, dev, seed, nsets=1, layout=0):
         from diffqcqp_amd import _capi, ops
-        self.lib = _capi.lib()
-        self.d = d
-        e = lambda *s: torch.empty(s, dtype=torch.float64, device=dev)
-        B = B_PER_GPU
-        self.x_qp, self.x_qcqp = e(B, N, 1), e(B, N, 1)
-        self.gP_qp, self.gq_qp = e(B, N, N), e(B, N, 1)
-        self.gP_qc, self.gq_qc, self.gl_qc, self.gm_qc = e(B, N, N), e(B, N, 1), e(B, N // 2, 1), e(B, N // 2, 1)
-        self.cache_qp, self.cache_qc = ops.diag_cache(d["q"]), ops.diag_cache(d["q"])
-        self.ws = ops._workspace(dev, B)
-        self.wsb = self.ws.numel() * 4
-        self.names = ["qp_fwd", "qp_bwd", "qcqp_fwd", "qcqp_bwd"]
+        self.lib, self.kind, self.B, self.N, self.backward, self.layout = _capi.lib(), kind, B, N, backward, layout
+        self.structure, self.dev = structure, dev
+        self.sets = [self._make_set(seed + 104729 * s) for s in range(nsets)]
+        self.names = [kind + "_fwd"] + ([kind + "_bwd"] if backward else [])
+        self.ws = {}
+        self.ops = ops
+        self.handoff = structure == "diag" and layout == 0
 
-    def launch(self, which, stream):
-        d, L, p = self.d, self.lib, (lambda t: t.data_ptr())
-        B = B_PER_GPU
-        if which == 0:
-            rc = L.dqq_qp_fwd_f64(p(d["P"]), p(d["q"]), p(self.x_qp), B, N, EPS, MU_PROX, MAX_ITER, 1, 0, None,
-                                  p(self.cache_qp[0]), p(self.cache_qp[1]), p(self.ws), self.wsb, stream)
-        elif which == 1:
-            rc = L.dqq_qp_bwd_f64(p(d["P"]), p(d["q"]), p(self.x_qp), p(d["g_qp"]), p(self.gP_qp), p(self.gq_qp), B, N,
-                                  1e-10, 0, None, p(self.cache_qp[0]), p(self.cache_qp[1]), p(self.ws), self.wsb, stream)
-        elif which == 2:
-            rc = L.dqq_qcqp_fwd_f64(p(d["P"]), p(d["q"]), p(d["l_n"]), p(d["mu"]), p(self.x_qcqp), B, N, EPS, MU_PROX,
-                                    MAX_ITER, 1, 0, None, p(self.cache_qc[0]), p(self.cache_qc[1]), p(self.ws), self.wsb,
-                                    stream)
+    def _make_set(self, seed):
+        B, N, dev = self.B, self.N, self.dev
+        g = torch.Generator(device=dev).manual_seed(seed)
+        r = lambda *s: torch.rand(*s, generator=g, dtype=F64, device=dev)
+        e = lambda *s: torch.empty(*s, dtype=F64, device=dev)
+        if self.structure == "diag":      # SURVEY 8(d): p ~ U(0.1, 1.1) -> diag_embed
+            P = torch.diag_embed(r(B, N) + 0.1).contiguous()
+        else:                             # cfg 5: P = S S^T / N + 0.1 I
+            S = r(B, N, N)
+            P = torch.bmm(S, S.transpose(1, 2)) / N
+            del S
+            P.diagonal(dim1=1, dim2=2).add_(0.1)
+        t = {"P": P, "q": 2 * r(B, N, 1) - 1, "x": e(B, N, 1)}
+        if self.kind == "qcqp":
+            t["l_n"], t["mu"] = r(B, N // 2, 1), r(B, N // 2, 1)
+        if self.backward:
+            t["g"] = torch.randn(B, N, 1, generator=g, dtype=F64, device=dev)
+            t["gP"], t["gq"] = e(B, N, N), e(B, N, 1)
+            if self.kind == "qcqp":
+                t["gl"], t["gm"] = e(B, N // 2, 1), e(B, N // 2, 1)
+        t["pdiag"], t["flags"] = e(B, N), torch.empty(B, dtype=torch.uint8, device=dev)
+        return t
+
+    def workspace(self, stream):
+        if stream not in self.ws:
+            self.ws[stream] = self.ops._workspace(self.dev, self.B, stream)
+        return self.ws[stream]
+
+    def launch(self, which, stream, s=0):
+        t, L, p = self.sets[s], self.lib, (lambda a: a.data_ptr())
+        ws = self.workspace(stream)
+        wsb, B, N = ws.numel() * 4, self.B, self.N
+        if which == 0 and self.kind == "qp":
+            rc = L.dqq_qp_fwd_f64(p(t["P"]), p(t["q"]), p(t["x"]), B, N, EPS, MU_PROX, MAX_ITER, 1, self.layout, None,
+                                  p(t["pdiag"]), p(t["flags"]), p(ws), wsb, stream)
+        elif which == 0:
+            rc = L.dqq_qcqp_fwd_f64(p(t["P"]), p(t["q"]), p(t["l_n"]), p(t["mu"]), p(t["x"]), B, N, EPS, MU_PROX, MAX_ITER,
+                                    1, self.layout, None, p(t["pdiag"]), p(t["flags"]), p(ws), wsb, stream)
+        elif self.kind == "qp":
+            rc = L.dqq_qp_bwd_f64(p(t["P"]), p(t["q"]), p(t["x"]), p(t["g"]), p(t["gP"]), p(t["gq"]), B, N, 1e-10,
+                                  self.layout, None, p(t["pdiag"]), p(t["flags"]), p(ws), wsb, stream)
         else:
-            rc = L.dqq_qcqp_bwd_f64(p(d["P"]), p(d["q"]), p(d["l_n"]), p(d["mu"]), p(self.x_qcqp), p(d["g_qcqp"]),
-                                    p(self.gP_qc), p(self.gq_qc), p(self.gl_qc), p(self.gm_qc), None, None, B, N, 1e-10,
-                                    0, None, p(self.cache_qc[0]), p(self.cache_qc[1]), p(self.ws), self.wsb, stream)
+            rc = L.dqq_qcqp_bwd_f64(p(t["P"]), p(t["q"]), p(t["l_n"]), p(t["mu"]), p(t["x"]), p(t["g"]), p(t["gP"]),
+                                    p(t["gq"]), p(t["gl"]), p(t["gm"]), None, None, B, N, 1e-10, self.layout, None,
+                                    p(t["pdiag"]), p(t["flags"]), p(ws), wsb, stream)
         if rc != 0:
             raise RuntimeError("launch %s failed with %d" % (self.names[which], rc))
 
-    def step(self, stream):
-        for w in range(4):
-            self.launch(w, stream)
+    def run(self, stream, s=0):
+        for w in range(len(self.names)):
+            self.launch(w, stream, s)
 
-    def step2(self, stream_a, stream_b):
-        """The QP chain on stream_a and the (independent) QCQP chain on stream_b, each with its own work-list."""
-        ws = self.ws
-        self.launch(0, stream_a)
-        self.ws = self.ws_side
-        self.launch(2, stream_b)
-        self.ws = ws
-        self.launch(1, stream_a)
-        self.ws = self.ws_side
-        self.launch(3, stream_b)
-        self.ws = ws
+    # ---- checks and the CPU arm (rank 0 only; the oracle is the checker / the baseline, never the product)
+    def host_sample(self, n, s=0):
+        t = self.sets[s]
+        keys = [k for k in ("P", "q", "l_n", "mu", "g") if k in t]
+        return {k: t[k][:n].cpu().numpy() for k in keys}
 
+    def check(self, n=1024):
+        from oracle import oracle as O
+        n = min(n, self.B)
+        h, t, nt = self.host_sample(n), self.sets[0], O.max_threads()
+        err = {}
+        if self.kind == "qp":
+            xo, _ = O.qp_fwd_batch(h["P"], h["q"], EPS, MAX_ITER, MU_PROX, nthreads=nt)
+        else:
+            xo, _ = O.qcqp_fwd_batch(h["P"], h["q"], h["l_n"], h["mu"], EPS, MAX_ITER, MU_PROX, nthreads=nt)
+        err["x"] = float(np.abs(t["x"][:n].cpu().numpy() - xo).max())
+        if self.backward and self.kind == "qp":
+            gq = O.qp_bwd_batch(h["P"], h["q"], xo, h["g"], nthreads=nt)[1]
+            err["grad_q"] = float(np.abs(t["gq"][:n].cpu().numpy() - gq).max())
+        elif self.backward:
+            # the reference's refinement exit (1 or 3 bodies) is decided by rounding noise (Solver.cpp:32-41): end to
+            # end the gradients are compared where the exits agree; tests/ show the flipped ones are the reference
+            # formula at the other exit, and that the backward is bit-exact on identical x
+            ref = O.qcqp_bwd_batch(h["P"], h["q"], h["l_n"], h["mu"], xo, h["g"], nthreads=nt)
+            st = self.ops.qcqp_backward(t["P"][:n], t["q"][:n], t["l_n"][:n], t["mu"][:n], t["x"][:n], t["g"][:n],
+                                        need=(False, True, False, False), return_steps=True)[-1].cpu().numpy()
+            same = st == ref[-1]
+            d = np.abs(t["gq"][:n].cpu().numpy() - ref[1]).max(axis=(1, 2)) / np.maximum(1.0, np.abs(ref[1]).max(axis=(1, 2)))
+            err["grad_q_rel_where_refinement_exit_agrees"] = float(d[same].max())
+            err["refinement_exit_flip_rate"] = float(1.0 - same.mean())
+        return err
 
-def check_against_oracle(plan, host, nsample=2048):
-    """Parity spot-check of what was just timed (rank 0): HIP vs oracle on the first nsample problems."""
-    from oracle import oracle as O
-    s = slice(0, nsample)
-    h = {k: v[s].numpy() for k, v in host.items()}
-    xo, _ = O.qp_fwd_batch(h["P"], h["q"], EPS, MAX_ITER, MU_PROX, nthreads=O.max_threads())
-    xq, _ = O.qcqp_fwd_batch(h["P"], h["q"], h["l_n"], h["mu"], EPS, MAX_ITER, MU_PROX, nthreads=O.max_threads())
-    nt = O.max_threads()
-    gq = O.qp_bwd_batch(h["P"], h["q"], xo, h["g_qp"], nthreads=nt)[1]
-    ref = O.qcqp_bwd_batch(h["P"], h["q"], h["l_n"], h["mu"], xq, h["g_qcqp"], nthreads=nt)
-    # QCQP backward: the reference's refinement exit (1 or 3 Tikhonov steps) is decided by rounding noise
-    # (Solver.cpp:32-41), so end to end it is compared where the exits agree; with identical x it is bit-exact.
-    from diffqcqp_amd import ops
-    dv = plan.d
-    st = ops.qcqp_backward(dv["P"][s], dv["q"][s], dv["l_n"][s], dv["mu"][s], plan.x_qcqp[s], dv["g_qcqp"][s],
-                           need=(False, True, False, False), return_steps=True)[-1].cpu().numpy()
-    same = st == ref[-1]
-    same_x = ops.qcqp_backward(dv["P"][s], dv["q"][s], dv["l_n"][s], dv["mu"][s], torch.from_numpy(xq).to(dv["q"].device),
-                               dv["g_qcqp"][s], need=(False, True, False, False))[1].cpu().numpy()
-    gqc = ref[1]
-    dqc = (plan.gq_qc[s].cpu().numpy() - gqc)
-    scale = np.maximum(1.0, np.abs(gqc).max(axis=(1, 2)))
-    err = {
-        "x_qp": float((plan.x_qp[s].cpu() - torch.from_numpy(xo)).abs().max()),
-        "x_qcqp": float((plan.x_qcqp[s].cpu() - torch.from_numpy(xq)).abs().max()),
-        "grad_q_qp": float((plan.gq_qp[s].cpu() - torch.from_numpy(gq)).abs().max()),
-        "grad_q_qcqp_same_x_bit_exact": bool(np.array_equal(same_x, gqc)),
-        "grad_q_qcqp_rel_where_refinement_exit_agrees": float((np.abs(dqc).max(axis=(1, 2)) / scale)[same].max()),
-        "qcqp_refinement_exit_flip_rate": float(1.0 - same.mean()),
-    }
-    return err
-
-
-def cpu_baseline(host):
-    """The oracle timed on the host cores over the SAME workload (one full step = 2*B fwd+bwd solves)."""
-    from oracle import oracle as O
-    h = {k: v.numpy() for k, v in host.items()}
-
-    def one_pass(nt, nb):
-        s = slice(0, nb)
+    def cpu_solves_per_s(self, n, nthreads):
+        from oracle import oracle as O
+        h = self.host_sample(n)
         t0 = time.perf_counter()
-        x, _ = O.qp_fwd_batch(h["P"][s], h["q"][s], EPS, MAX_ITER, MU_PROX, nthreads=nt)
-        O.qp_bwd_batch(h["P"][s], h["q"][s], x, h["g_qp"][s], nthreads=nt)
-        xq, _ = O.qcqp_fwd_batch(h["P"][s], h["q"][s], h["l_n"][s], h["mu"][s], EPS, MAX_ITER, MU_PROX, nthreads=nt)
-        O.qcqp_bwd_batch(h["P"][s], h["q"][s], h["l_n"][s], h["mu"][s], xq, h["g_qcqp"][s], nthreads=nt)
-        return 2 * nb / (time.perf_counter() - t0)
+        if self.kind == "qp":
+            x, _ = O.qp_fwd_batch(h["P"], h["q"], EPS, MAX_ITER, MU_PROX, nthreads=nthreads)
+            if self.backward:
+                O.qp_bwd_batch(h["P"], h["q"], x, h["g"], nthreads=nthreads)
+        else:
+            x, _ = O.qcqp_fwd_batch(h["P"], h["q"], h["l_n"], h["mu"], EPS, MAX_ITER, MU_PROX, nthreads=nthreads)
+            if self.backward:
+                O.qcqp_bwd_batch(h["P"], h["q"], h["l_n"], h["mu"], x, h["g"], nthreads=nthreads)
+        return n / (time.perf_counter() - t0)
 
-    cores = O.max_threads()
-    one_pass(cores, 4096)  # spin up the OpenMP team
-    best_all = max(one_pass(cores, B_PER_GPU) for _ in range(3))
-    one_t = one_pass(1, 16384)
-    return {
-        "value": best_all, "unit": "solves/s", "cores": cores, "kind": "port",
-        "sample": "oracle/diffqcqp_oracle.c (dense C port of the reference algorithm, OpenMP over the batch), "
-                  "best of 3 passes over the full step workload (B=65536 QP + B=65536 QCQP, fwd+bwd)",
-        "single_thread_value": one_t,
-        "single_thread_sample": "same, 1 thread, first 16384 problems of each family",
-    }
+
+WORKLOADS = {
+    # key: (description, [(kind, N, structure, backward)], B_total, scaling, cpu sample per chain)
+    0: ("per GPU and step: B=65536 N=8 diagonal-P (dense (B,8,8) layout) QP forward+backward [BASELINE configs[1] + "
+        "backward] and B=65536 N=8 QCQP forward+backward [configs[2]] on distinct inputs; value counts one "
+        "forward+backward as one solve", [("qp", 8, "diag", True), ("qcqp", 8, "diag", True)], 65536, "weak", 65536),
+    2: ("BASELINE configs[1]: B=65536 N=8 diagonal-P QP, forward only", [("qp", 8, "diag", False)], 65536, "weak", 65536),
+    3: ("BASELINE configs[2]: B=65536 N=8 QCQP (friction cones), forward+backward", [("qcqp", 8, "diag", True)], 65536,
+        "weak", 65536),
+    4: ("BASELINE configs[3]: B=262144 N=32 diagonal-P QP forward+backward, batch split over the ranks, RCCL "
+        "all-gather of x after every step", [("qp", 32, "diag", True)], 262144, "strong", 16384),
+    5: ("BASELINE configs[4]: B=65536 N=64 dense-P QP (P = S S^T/64 + 0.1 I) forward+backward",
+        [("qp", 64, "dense", True)], 65536, "weak", 2048),
+}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=0, choices=(0, 2, 3, 4, 5),
+                    help="BASELINE.json configs entry (1-based); 0 = the headline step (configs 2'+3)")
+    ap.add_argument("--repeats", type=int, default=10, help="timed regions of exactly --steps steps; the median is reported")
     ap.add_argument("--streams", type=int, default=2, choices=(1, 2),
-                    help="2 (default): the QP chain and the QCQP chain of a step -- independent problems -- are enqueued "
-                         "on two HIP streams, so the HBM-bound backward of one overlaps the VALU-bound forward of the "
-                         "other; 1: everything on one stream")
+                    help="headline only: 2 = the QP chain and the QCQP chain on two HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-cold", action="store_true")
     args = ap.parse_args()
 
     # Everything the native libraries print on stdout (RCCL prints its version banner there) goes to
@@ -223,10 +244,41 @@ def main():
         dist.barrier()
     _capi.lib()
 
-    host, d = make_inputs(rank, dev)
-    plan = Plan(d, dev)
-    stream = torch.cuda.current_stream()
-    sh = stream.cuda_stream
+    desc, families, B_total, scaling, cpu_n = WORKLOADS[args.config]
+    if scaling == "strong":
+        lo, hi = parallel.shard_bounds(B_total, rank, world)
+        B_rank = hi - lo
+    else:
+        B_rank = B_total
+    gather = args.config == 4          # the path's one exchange step
+    steps = max(args.steps, 1)
+    if args.config == 5 and args.steps == 100 and args.repeats == 10:
+        steps, args.repeats = 5, 5     # a step is ~7.5 ms of a 4.3 GB working set: bound the default run
+    if args.config == 4 and args.steps == 100:
+        steps = 20
+
+    chains = [Chain(k, B_rank, n, st, bw, dev, 1000 + 17 * args.config + 7919 * rank + 31 * i)
+              for i, (k, n, st, bw) in enumerate(families)]
+    main_stream = torch.cuda.current_stream()
+    sh = main_stream.cuda_stream
+    side = torch.cuda.Stream() if (len(chains) == 2 and args.streams == 2) else None
+    streams = [sh, side.cuda_stream if side is not None else sh]
+    x_all = None
+
+    def step(s=0):
+        """One pass of the hot path over this rank's batch (all chains; set s of each)."""
+        if side is not None:  # interleave so that both streams are fed
+            chains[0].launch(0, streams[0], s)
+            chains[1].launch(0, streams[1], s)
+            chains[0].launch(1, streams[0], s)
+            chains[1].launch(1, streams[1], s)
+        else:
+            for c in chains:
+                c.run(sh, s)
+
+    def drain():
+        if side is not None:
+            side.synchronize()
 
     def barrier():
         torch.cuda.synchronize()
@@ -234,154 +286,198 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def region(fn, k):
+        """Exactly k calls of fn between two barrier+synchronize brackets; MAX over the ranks, seconds."""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        drain()
+        barrier()
+        el = time.perf_counter() - t0
+        if use_dist:
+            tm = torch.tensor([el], dtype=F64, device=dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            el = float(tm.item())
+        return el
+
+    def step_and_gather():
+        nonlocal x_all
+        step()
+        x_all = parallel.gather_batch(chains[0].sets[0]["x"], B_total) if use_dist else chains[0].sets[0]["x"]
+
+    timed = step_and_gather if gather else step
+
     # ---- warm-up (also warms RCCL's all-gather)
     for _ in range(max(args.warmup, 1)):
-        plan.step(sh)
-    if use_dist:
-        parallel.gather_batch(plan.x_qcqp, B_PER_GPU * world)
-    graph = None
-    if args.graph:
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            plan.step(torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
-        for _ in range(3):
-            graph.replay()
+        timed()
+    drain()
+    # ---- timed regions: R times EXACTLY K steps
+    times = sorted(region(timed, steps) for _ in range(max(args.repeats, 1)))
+    elapsed = times[len(times) // 2]
+    if gather and use_dist:
+        assert x_all.shape[0] == B_total
 
-    side = None
-    if args.streams == 2:
-        from diffqcqp_amd import ops as _ops
-        side = torch.cuda.Stream()
-        plan.ws_side = _ops._workspace(dev, B_PER_GPU, side.cuda_stream)  # one work-list per stream
-        for _ in range(3):
-            plan.step2(sh, side.cuda_stream)
-        torch.cuda.synchronize()
+    extra = {}
+    if gather:   # the same regions without the exchange step
+        tn = sorted(region(step, steps) for _ in range(max(args.repeats // 2, 1)))
+        extra["without_gather"] = {"ms_per_step": tn[len(tn) // 2] / steps * 1e3,
+                                   "value": B_total * steps / tn[len(tn) // 2],
+                                   "allgather_bytes_per_rank": B_rank * families[0][1] * 8}
+    if side is not None:   # context: the same steps strictly on one stream
+        save, side = side, None
+        t1 = sorted(region(step, steps) for _ in range(3))
+        side = save
+        extra["single_stream"] = {"ms_per_step": t1[1] / steps * 1e3,
+                                  "value_this_rank": sum(c.B for c in chains) * steps / t1[1],
+                                  "note": "all launches of a step on one stream (what one problem family alone sees)"}
 
-    # ---- timed region: EXACTLY K steps (+ the final gather when sharded)
-    barrier()
-    t0 = time.perf_counter()
-    if graph is not None:
-        for _ in range(args.steps):
-            graph.replay()
-    elif side is not None:
-        for _ in range(args.steps):
-            plan.step2(sh, side.cuda_stream)
-        side.synchronize()
-    else:
-        for _ in range(args.steps):
-            plan.step(sh)
-    gather_ms = None
-    if use_dist:
-        torch.cuda.synchronize()
-        tg = time.perf_counter()
-        x_all = parallel.gather_batch(plan.x_qcqp, B_PER_GPU * world)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - tg) * 1e3
-        assert x_all.shape[0] == B_PER_GPU * world
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    # ---- cold variant: rotate input AND output sets so that a step never finds its data in the 256 MiB Infinity Cache
+    if args.config in (0, 2, 3) and not args.no_cold and world == 1:
+        per_set = sum(sum(v.numel() * v.element_size() for v in c.sets[0].values()) for c in chains)
+        nsets = max(3, int(np.ceil(768 * 2**20 / per_set)))
+        cold = [Chain(c.kind, c.B, c.N, c.structure, c.backward, dev, 5000 + 13 * i, nsets=nsets)
+                for i, c in enumerate(chains)]
+        hot, chains = chains, cold
+        ctr = [0]
 
-    # ---- context (outside the contract's timed region): the same K steps strictly on one stream
-    single_ms = None
-    if side is not None and graph is None:
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            plan.step(sh)
-        barrier()
-        single_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        def cold_step():
+            step(ctr[0] % nsets)
+            ctr[0] += 1
+        for _ in range(nsets):
+            cold_step()
+        drain()
+        tc = sorted(region(cold_step, steps) for _ in range(max(args.repeats // 2, 3)))
+        chains = hot
+        extra["cold"] = {"sets": nsets, "bytes_per_set": per_set, "ms_per_step": tc[len(tc) // 2] / steps * 1e3,
+                         "value": sum(c.B for c in chains) * steps / tc[len(tc) // 2],
+                         "note": "same step, inputs and outputs rotating over `sets` distinct buffers (> 256 MiB in "
+                                 "total): nothing is served from the Infinity Cache"}
+        del cold
+        torch.cuda.empty_cache()
 
-    # ---- roofline pass: HIP events around every launch of the step, on the launch stream.  The dense
-    # fallback launch of the AUTO layout is switched off here so that each bracket holds exactly one kernel
-    # (the inputs are diagonal by construction, so the fallback kernel is an empty launch anyway).
-    _capi.set_option("auto_fallback", 0)
-    nrep = min(max(args.steps, 20), 200)
-    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
+    # ---- roofline pass: HIP events around every launch of the step, on the launch stream.  The work-list launch
+    # behind an all-diagonal DQQ_P_AUTO batch is switched off here so that each bracket holds exactly one kernel.
+    all_diag = all(c.structure == "diag" for c in chains)
+    if all_diag:
+        _capi.set_option("auto_fallback", 0)
+    nrep = 5 if args.config == 5 else (20 if args.config == 4 else 100)
+    launches = [(c, w) for c in chains for w in range(len(c.names))]
+    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in launches]
           for _ in range(nrep)]
     torch.cuda.synchronize()
     for r in range(nrep):
-        for w in range(4):
-            ev[r][w][0].record(stream)
-            plan.launch(w, sh)
-            ev[r][w][1].record(stream)
+        for j, (c, w) in enumerate(launches):
+            ev[r][j][0].record(main_stream)
+            c.launch(w, sh)
+            ev[r][j][1].record(main_stream)
     torch.cuda.synchronize()
     _capi.set_option("auto_fallback", 1)
     kernels = {}
-    for w, name in enumerate(plan.names):
-        ts = sorted(ev[r][w][0].elapsed_time(ev[r][w][1]) for r in range(nrep))
-        mean_ms = sum(ts) / len(ts)
-        kernels[name] = {
-            "mean_us": mean_ms * 1e3, "median_us": ts[len(ts) // 2] * 1e3,
-            "algo_bytes_per_launch": ALGO_BYTES[name] * B_PER_GPU,
-            "algo_GBps": ALGO_BYTES[name] * B_PER_GPU / (mean_ms * 1e-3) / 1e9,
-        }
+    for j, (c, w) in enumerate(launches):
+        ts = sorted(ev[r][j][0].elapsed_time(ev[r][j][1]) for r in range(nrep))
+        mean_ms, pas = sum(ts) / len(ts), ("fwd" if w == 0 else "bwd")
+        ab, mb = algo_bytes(c.kind, c.N, pas) * c.B, moved_bytes(c.kind, c.N, pas, c.handoff) * c.B
+        kernels[c.names[w]] = {"mean_us": mean_ms * 1e3, "median_us": ts[len(ts) // 2] * 1e3,
+                               "min_us": ts[0] * 1e3, "max_us": ts[-1] * 1e3,
+                               "algo_bytes_per_launch": ab, "algo_GBps": ab / (mean_ms * 1e-3) / 1e9,
+                               "moved_bytes_per_launch": mb, "moved_GBps": mb / (mean_ms * 1e-3) / 1e9}
     dom = max(kernels, key=lambda k: kernels[k]["mean_us"])
-    traffic, valu = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc_path):
-        try:
-            pmc = json.load(open(pmc_path)).get(dom, {})
-            traffic = pmc.get("hbm_bytes_per_launch")
-            if "SQ_INSTS_VALU" in pmc:
-                # second ceiling of the same kernel: FP64 VALU issue.  Wave-level VALU instructions of one launch
-                # (SQ_INSTS_VALU, rocprofv3 PMC pass) spread over the chip's 1024 SIMDs, at the measured issue
-                # floor of a wave64 fp64 instruction (tools/ubench/fp64_issue.hip: 2.08 ns; 4 cycles at 2.4 GHz
-                # would be 1.67 ns).  Almost every VALU instruction of this kernel is fp64.
-                floor_us = pmc["SQ_INSTS_VALU"] / 1024.0 * 2.08e-3
-                valu = {"valu_insts_per_launch": pmc["SQ_INSTS_VALU"], "valu_insts_per_wave": pmc.get("valu_insts_per_wave"),
-                        "issue_floor_ns_per_wave_inst": 2.08, "floor_us": floor_us,
-                        "frac": floor_us / kernels[dom]["mean_us"]}
-        except Exception:
-            traffic, valu = None, None
+    step_algo = sum(k["algo_bytes_per_launch"] for k in kernels.values())
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["algo_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": kernels[dom]["algo_GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-        "frac_vs_measured_copy_bw_6290": kernels[dom]["algo_GBps"] / 6290.0,
-        "step_algo_GBps": sum(ALGO_BYTES.values()) * B_PER_GPU / (sum(k["mean_us"] for k in kernels.values()) * 1e-6) / 1e9,
-        "step_algo_GBps_as_timed": sum(ALGO_BYTES.values()) * B_PER_GPU / (elapsed / args.steps) / 1e9,
-        "fp64_valu_issue": valu,
+        "frac": kernels[dom]["algo_GBps"] / HBM_PEAK_GBS, "traffic": None,
+        "moved_GBps": kernels[dom]["moved_GBps"], "frac_vs_measured_copy_bw_6290": kernels[dom]["algo_GBps"] / 6290.0,
+        "step_algo_GBps_kernels_alone": step_algo / (sum(k["mean_us"] for k in kernels.values()) * 1e-6) / 1e9,
+        "step_algo_GBps_as_timed": step_algo / (elapsed / steps) / 1e9,
+        "timing": "HIP events on the launch stream around each launch, mean of %d" % nrep,
     }
+    # HBM traffic and VALU instruction counts are PMC measurements of a separate rocprofv3 run (tools/profile.sh):
+    # quoted from the committed summary of the same workload, with its provenance, never measured by this run
+    tag = {0: "", 2: "_cfg2", 3: "_cfg3", 4: "_cfg4", 5: "_cfg5"}[args.config]
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest%s.json" % tag)
+    if os.path.exists(pmc_path):
+        try:
+            allp = json.load(open(pmc_path))
+            pmc = allp.get(dom, {})
+            roofline["traffic"] = pmc.get("hbm_bytes_per_launch")
+            roofline["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tag %s; not " \
+                                         "measured by this run)" % (os.path.basename(pmc_path), allp.get("_tag", "?"))
+            if "SQ_INSTS_VALU" in pmc:
+                floor_us = pmc["SQ_INSTS_VALU"] / 1024.0 * 2.08e-3
+                roofline["fp64_valu_issue"] = {
+                    "valu_insts_per_launch": pmc["SQ_INSTS_VALU"], "issue_floor_ns_per_wave_inst": 2.08,
+                    "floor_us": floor_us, "frac": floor_us / kernels[dom]["mean_us"],
+                    "source": roofline["traffic_source"]}
+        except Exception:
+            pass
+    if args.config == 5:
+        # compute-bound: FP64 flops with the reference's cost profile (SURVEY.md 8(d)): per problem 2N^2 per mat-vec
+        # (iterations + 11 power-iteration products), 2.33 N^3 per factorisation + explicit inverse (3.5 per solve
+        # on this family), backward A^T A + LLT + inverse 4.33 N^3
+        c = chains[0]
+        it = c.ops.qp_forward(c.sets[0]["P"], c.sets[0]["q"], EPS, MAX_ITER, return_iters=True)[1].double().mean().item()
+        n = c.N
+        f_fwd = (2 * n * n * (it + 11) + 3.5 * 2.33 * n ** 3) * c.B
+        f_bwd = (4.33 * n ** 3 + 2 * n * n * 5) * c.B
+        fl = {"qp_fwd": f_fwd, "qp_bwd": f_bwd}
+        roofline["fp64"] = {
+            "bound": "mfma", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS, "mean_iterations": it,
+            "algo_flops_per_launch": fl,
+            "achieved": {k: fl[k] / (kernels[k]["mean_us"] * 1e-6) / 1e12 for k in fl},
+            "frac": fl[dom] / (kernels[dom]["mean_us"] * 1e-6) / 1e12 / FP64_PEAK_TFLOPS,
+            "note": "this config is FP64-compute-bound (SURVEY.md 8(d)): the HBM fraction above is capped at ~30-55 %",
+        }
 
     if rank != 0:
         dist.barrier()
         dist.destroy_process_group()
         return
 
-    solves = 2 * B_PER_GPU * world * args.steps
+    units_per_step = (B_total if scaling == "strong" else sum(c.B for c in chains) * world)
     out = {
-        "metric": "QP+QCQP solves/sec (fwd+bwd)", "value": solves / elapsed, "unit": "solves/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "metric": "QP+QCQP solves/sec (fwd+bwd)" if args.config != 2 else "QP forward solves/sec",
+        "value": units_per_step * steps / elapsed, "unit": "solves/s",
+        "n_gpus": world, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": "per GPU and step: B=65536 N=8 diagonal-P (dense (B,8,8) layout) QP forward+backward "
-                        "[BASELINE configs[1] + backward] and B=65536 N=8 QCQP forward+backward [configs[2]]; "
-                        "eps=1e-7 max_iter=1000 mu_prox=1e-7; value counts one forward+backward as one solve",
-            "B_per_gpu": B_PER_GPU, "N": N, "p_layout": "auto (off-diagonals verified in-kernel)",
-            "launch": ("hip graph replay" if graph is not None else "eager, 4 C-ABI calls per step")
-                      + (", QP and QCQP chains on two streams" if args.streams == 2 else ""),
-            "sharding": "batch shards, no data-path collective; final all-gather of x" if world > 1 else "single GPU",
+            "workload": desc + "; eps=1e-7 max_iter=1000 mu_prox=1e-7",
+            "baseline_config": args.config if args.config else "2'+3 (headline)",
+            "B_total": B_total if scaling == "strong" else sum(c.B for c in chains) * world,
+            "B_this_rank": [c.B for c in chains], "N": [c.N for c in chains],
+            "p_layout": "auto (off-diagonals verified in-kernel; non-diagonal tiles go to the general kernel)",
+            "launch": "eager, one C-ABI call per pass" + (", the two families on two streams" if side is not None else ""),
+            "sharding": ("batch split over the ranks, no data-path collective; RCCL all-gather of x per step"
+                         if gather else ("batch shards, no collective" if world > 1 else "single GPU")),
         },
+        "repeats": {"R": len(times), "ms_per_step_median": elapsed / steps * 1e3, "ms_per_step_min": times[0] / steps * 1e3,
+                    "ms_per_step_max": times[-1] / steps * 1e3,
+                    "note": "R regions of exactly `steps` steps, barrier + synchronize on both sides, MAX over ranks; "
+                            "value / ms_per_step are the median region"},
         "roofline": roofline,
         "kernels": kernels,
-        "per_gpu_value": solves / elapsed / world,
+        "per_gpu_value": units_per_step * steps / elapsed / world,
     }
-    if gather_ms is not None:
-        out["final_allgather_ms"] = gather_ms
-    if single_ms is not None:
-        out["single_stream"] = {"ms_per_step": single_ms, "value_this_rank": 2 * B_PER_GPU / (single_ms * 1e-3),
-                                "note": "same K steps with all four launches on one stream (what one problem family "
-                                        "alone sees); not the headline"}
+    out.update(extra)
     if not args.no_check:
-        out["parity_max_abs_err_vs_oracle_first_2048"] = check_against_oracle(plan, host)
+        out["parity_max_abs_err_vs_oracle_sample"] = {c.names[0][:-4]: c.check(256 if c.N >= 32 else 2048) for c in chains}
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(host)
-        out["gpu_over_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["value"]
+        from oracle import oracle as O
+        cores = O.max_threads()
+        n = min(cpu_n, chains[0].B)
+        for c in chains:
+            c.cpu_solves_per_s(min(n, 512), cores)   # spin up the OpenMP team
+        rates = [max(c.cpu_solves_per_s(n, cores) for _ in range(2)) for c in chains]
+        tot = sum(n for _ in chains) / sum(n / r for r in rates)
+        n1 = max(n // 64, 64)
+        one = sum(n1 for _ in chains) / sum(n1 / c.cpu_solves_per_s(n1, 1) for c in chains)
+        out["cpu_baseline"] = {
+            "value": tot, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": "oracle/diffqcqp_oracle.c (dense C port of the reference algorithm, OpenMP over the batch), best of "
+                      "2 passes over the first %d problems of each family of this workload" % n,
+            "single_thread_value": one, "single_thread_sample": "same, 1 thread, first %d problems" % n1}
+        out["gpu_over_cpu_all_cores"] = out["value"] / tot
     os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()

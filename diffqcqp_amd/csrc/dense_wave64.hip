@@ -85,7 +85,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     constexpr bool QP_LIKE = (KIND != 1);
     const long count = use_worklist ? (long)ws[kWsCount] : B;
 
-    for (long w = blockIdx.x; w < count; w += gridDim.x) {
+    for (long w = blockIdx.x;; w += gridDim.x) {
+        // work-list mode: entries are claimed one at a time (iteration counts differ by 2x between problems; a fixed
+        // stride would leave the grid waiting for its unluckiest wave)
+        if (use_worklist) { // (an empty list is left untouched: nobody would reset the counter)
+            if (count == 0) break;
+            w = __builtin_amdgcn_readfirstlane(threadIdx.x == 0 ? atomicAdd(&ws[kWsNext], 1) : 0);
+        }
+        if (w >= count) break;
         // everything derived from the lane index is recomputed per problem: hoisted out of this loop (which runs
         // once per wave outside the work-list mode) those dozens of masks and offsets only occupy registers
         int lane = threadIdx.x;
@@ -299,7 +306,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     constexpr int N = 64;
     const long count = use_worklist ? (long)ws[kWsCount] : B;
 
-    for (long w = blockIdx.x; w < count; w += gridDim.x) {
+    for (long w = blockIdx.x;; w += gridDim.x) {
+        if (use_worklist) { // (an empty list is left untouched: nobody would reset the counter)
+            if (count == 0) break;
+            w = __builtin_amdgcn_readfirstlane(threadIdx.x == 0 ? atomicAdd(&ws[kWsNext], 1) : 0);
+        }
+        if (w >= count) break;
         int lane = threadIdx.x;
         asm volatile("" : "+v"(lane)); // see the forward kernel: nothing lane-derived is hoisted out of the loop
         const int g = lane >> 4, n = lane & 15;

@@ -17,6 +17,7 @@ namespace dqq {
 // re-zeroes both), entries from [kWsEntries].
 constexpr int kWsCount = 0;
 constexpr int kWsTicket = 1;
+constexpr int kWsNext = 2; // work-list mode with dynamic pick-up: next unclaimed entry
 constexpr int kWsEntries = 4;
 
 
@@ -32,6 +33,7 @@ static DQQ_D void worklist_release(int* ws, long count, int participants)
         if (tk == participants - 1) {
             ws[kWsCount] = 0;
             ws[kWsTicket] = 0;
+            ws[kWsNext] = 0;
         }
     }
 }

@@ -9,6 +9,8 @@ namespace dqq {
 // Streams NCH chunks of 128 doubles (16 B per lane, 1 KiB per wave instruction) of a tile of P,
 // writes the diagonal entries to sd[problem*N + row] and returns a non-zero word if any
 // off-diagonal entry is not +-0.  GUARD: the tile is ragged (last tile of the batch).
+// Large tiles (N >= 32: 64+ KiB) stop streaming at the first group of chunks that shows a non-zero off-diagonal
+// -- the tile is not going to take the fast path, and a dense batch would otherwise be read twice in full.
 template <int N, int NCH, bool GUARD>
 static DQQ_D unsigned stream_tile_diag(const double* __restrict__ Pw, int limit, double* sd, int lane)
 {
@@ -32,6 +34,7 @@ static DQQ_D unsigned stream_tile_diag(const double* __restrict__ Pw, int limit,
             else if (c + 1 == r) { sd[row] = v[j].y; nz |= b0; }
             else nz |= b0 | b1;
         }
+        if (NCH > 32 && __any(nz != 0)) break; // wave-uniform
     }
     return nz;
 }

@@ -41,6 +41,53 @@ def _worker(rank, world, port, B, q_out):
     dist.destroy_process_group()
 
 
+def _worker_n32(rank, world, port, B, q_out):
+    """BASELINE configs[3] shapes (N=32 diagonal-P QP, forward + backward): x and grad_q are gathered, grad_P stays
+    sharded with P."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import make_problem
+    from diffqcqp_amd import parallel
+    from oracle import oracle as O
+    d = make_problem("qp", B, 32, 1004)
+    lo, hi = parallel.shard_bounds(B, rank, world)
+    P, q, g = (parallel.shard(d[k]) for k in ("P", "q", "grad_x"))
+    x, _ = O.qp_fwd_batch(P.numpy(), q.numpy(), 1e-7, 1000)
+    gP, gq, _ = O.qp_bwd_batch(P.numpy(), q.numpy(), x, g.numpy())
+    x_full = parallel.gather_batch(torch.from_numpy(x), B)
+    gq_full, work = parallel.gather_batch(torch.from_numpy(gq), B, async_op=True)
+    if work is not None:
+        work.wait()
+    assert gP.shape == (hi - lo, 32, 32)                       # grad_P: this rank's slice only
+    assert torch.equal(x_full[lo:hi], torch.from_numpy(x))
+    q_out.put((rank, x_full.numpy() if rank == 0 else None, gq_full.numpy() if rank == 0 else None, gP))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,B", [(2, 40), (2, 33)])
+def test_config4_shapes_forward_backward_sharded(oracle, world, B):
+    from conftest import make_problem
+    ctx = mp.get_context("spawn")
+    q_out = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world * 11 + B
+    procs = [ctx.Process(target=_worker_n32, args=(r, world, port, B, q_out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q_out.get(timeout=180) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    d = make_problem("qp", B, 32, 1004)
+    x, _ = oracle.qp_fwd_batch(d["P"].numpy(), d["q"].numpy(), 1e-7, 1000)
+    gP, gq, _ = oracle.qp_bwd_batch(d["P"].numpy(), d["q"].numpy(), x, d["grad_x"].numpy())
+    assert np.array_equal(got[0][1], x) and np.array_equal(got[0][2], gq)
+    assert np.array_equal(np.concatenate([t[3] for t in got], axis=0), gP)
+
+
 @pytest.mark.parametrize("world,B", [(2, 64), (2, 37), (3, 10)])
 def test_shard_solve_gather_matches_single_process(oracle, world, B):
     from conftest import make_problem
