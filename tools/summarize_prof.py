@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Condenses rocprofv3 output databases (rocpd sqlite) into the small summaries kept under profiles/.
 
-    python tools/summarize_prof.py <kernel_trace.db> <sq_pmc.db> <fetch_pmc.db> <write_pmc.db> <outdir> <tag>
+    python tools/summarize_prof.py <kernel_trace.db> <sq_pmc.db> <fetch_pmc.db> <write_pmc.db> <outdir> <tag> [suffix]
 
 Writes  <outdir>/<tag>_kernel_stats.csv   per-kernel calls / mean / min / max duration (ns) and share
         <outdir>/<tag>_pmc.json           per-kernel mean counter values per launch + derived HBM bytes
-        <outdir>/pmc_latest.json          the same HBM traffic keyed by bench.py's launch names
+        <outdir>/pmc_latest<suffix>.json  the same HBM traffic keyed by bench.py's launch names (a launch = every
+                                          kernel of that pass: DQQ_P_AUTO on dense P is the verifying fast-path
+                                          kernel + the general kernel behind it), "_tag" = <tag>
 HBM traffic per launch = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024: FETCH_SIZE/WRITE_SIZE are in KiB and,
 on gfx950 with this rocprofv3, FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane)
 coalesced streaming read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE matched the known store
@@ -27,15 +29,19 @@ def short(name):
 
 
 def bench_key(s):
-    for pat, key in (("fwd_diag_kernel<0", "qp_fwd"), ("fwd_diag_kernel<1", "qcqp_fwd"),
-                     ("bwd_diag_kernel<0", "qp_bwd"), ("bwd_diag_kernel<1", "qcqp_bwd")):
-        if s.startswith(pat):
-            return key
-    return None
+    """bench.py launch name of a kernel: <family>_<pass>; the family is the KIND template argument (0 qp, 1 qcqp)."""
+    if not s.startswith(("fwd_", "bwd_")):
+        return None
+    m = re.search(r"<(\d)", s)
+    fam = {"0": "qp", "1": "qcqp"}.get(m.group(1) if m else "0")
+    if "_qp_kernel" in s:
+        fam = "qp"
+    return None if fam is None else "%s_%s" % (fam, s[:3])
 
 
 def main():
     kt, sq, fe, wr, outdir, tag = sys.argv[1:7]
+    suffix = sys.argv[7] if len(sys.argv) > 7 else ""
     os.makedirs(outdir, exist_ok=True)
     c = sqlite3.connect(kt)
     rows = c.execute("select name, count(*), avg(end-start), min(end-start), max(end-start), sum(end-start) "
@@ -64,12 +70,18 @@ def main():
             v["valu_insts_per_wave"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"]
         key = bench_key(k)
         if key and "hbm_bytes_per_launch" in v:
-            latest[key] = {"kernel": k, "hbm_bytes_per_launch": v["hbm_bytes_per_launch"]}
-            for extra in ("SQ_INSTS_VALU", "SQ_WAVES", "valu_insts_per_wave"):
+            e = latest.setdefault(key, {"kernels": [], "hbm_bytes_per_launch": 0.0})
+            e["kernels"].append(k)
+            e["hbm_bytes_per_launch"] += v["hbm_bytes_per_launch"]
+            for extra in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES"):
                 if extra in v:
-                    latest[key][extra] = v[extra]
+                    e[extra] = e.get(extra, 0.0) + v[extra]
+    for e in latest.values():
+        if e.get("SQ_WAVES"):
+            e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
+    latest["_tag"] = tag
     json.dump(pmc, open(os.path.join(outdir, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
-    json.dump(latest, open(os.path.join(outdir, "pmc_latest.json"), "w"), indent=1, sort_keys=True)
+    json.dump(latest, open(os.path.join(outdir, "pmc_latest%s.json" % suffix), "w"), indent=1, sort_keys=True)
     for r in rows[:10]:
         print("%-46s calls %5d mean %9.2f us  %5.1f%%" % (short(r[0]), r[1], r[2] / 1e3, 100.0 * r[5] / tot))
 
