@@ -220,87 +220,58 @@ hipError_t launch_fwd_dense_wave64(int kind, const FwdArgs& a, bool use_worklist
 // (A~[a][k] = P[a][k] if a and k are inactive, l_a if a = k is active, 0 otherwise -- a symmetric permutation of the
 // reference's blkdiag(diag(l_A), P_II), see dense_block.hip).
 //
-// P is streamed from L2 one tile-row at a time (32 registers) instead of being held: the registers belong to
-// K = A~ A~^T + mu I (accumulated on the matrix cores as sum_k T_k^T T_k while the tile-rows go by) and then to
-// -K^-1 (block sweep, in place).  The refinement residual K x - A^T b (:30), which needs K after it has been
-// overwritten by its inverse, is evaluated as A~ (A~^T x) + mu x from two more streams of P with the masks applied
-// to the vectors (x is exactly zero on the active set): same quantity, rounded differently (~1e-16 |K| |x|, against
-// exit thresholds of 1e-10).
-
-// tile-row TK of the tile layout of A^T:  T[ta][r] of lane (g,n) = A[16ta+n][16TK+4r+g]    (mat-vec: A x)
+// P is read ONCE (64 loads in flight, tile layout of P^T in registers): gamma = -(P l + q), then the masks are
+// applied in place and A^T b follows from the same registers.  K = A~ A~^T + mu I is accumulated on the matrix
+// cores in two halves of eight tiles (A~ 128 registers + a half of K 64) and parked, in tile order (every store and
+// load a fully coalesced 512 bytes), in the 32 KiB of grad_P that belong to this problem -- that slot is written
+// with the actual gradient only at the very end.  K comes back for the block sweep (-K^-1 in place), and the
+// refinement residual K x - A^T b (:30) streams it once more from the same slot (L2-hot) instead of keeping a second
+// 128-register matrix alive.  grad_P == NULL (no scratch): the caller routes to the workgroup kernel.
 template <int TK>
-static DQQ_D void load_tile_row_transposed(v4d (&T)[4], const double* __restrict__ A, int lane)
+static DQQ_D void load_tile_row_tileorder(v4d (&T)[4], const double* __restrict__ Ks, int lane)
 {
-    const unsigned lo = (lane & 15) * 64 + (lane >> 4);
-#pragma unroll
-    for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) T[ta][r] = (A + ((16 * ta) * 64 + 16 * TK + 4 * r))[lo];
-}
-
-// tile-row TK of the tile layout of A:  T[tj][r] of lane (g,n) = A[16TK+4r+g][16tj+n]      (mat-vec: A^T x)
-template <int TK>
-static DQQ_D void load_tile_row_plain(v4d (&T)[4], const double* __restrict__ A, int lane)
-{
-    const unsigned lo = (lane >> 4) * 64 + (lane & 15);
 #pragma unroll
     for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) T[tj][r] = (A + ((16 * TK + 4 * r) * 64 + 16 * tj))[lo];
+        for (int r = 0; r < 4; ++r) T[tj][r] = (Ks + ((TK * 4 + tj) * 4 + r) * 64)[lane];
 }
 
 template <int TK>
-static DQQ_D void bwd_qp_accumulate_row(v4d (&K)[4][4], MatvecStream& mv, const double* __restrict__ Pg,
-                                        unsigned long long am, double xi_act, int lane)
+static DQQ_D void stream_tileorder_row(MatvecStream& mv, const double* __restrict__ Ks, int lane)
+{
+    v4d T[4];
+    load_tile_row_tileorder<TK>(T, Ks, lane);
+    mv.add_row<TK>(T);
+}
+
+template <int HALF>
+static DQQ_D void bwd_qp_gram_half(const v4d (&A)[4][4], double* __restrict__ Ks, int lane)
 {
     const int g = lane >> 4, n = lane & 15;
-    v4d T[4];
-    load_tile_row_transposed<TK>(T, Pg, lane);
-    // A~: zero where the row a = 16ta+n or the column k = 16TK+4r+g is active; l_a on the diagonal of an active a
-    const double dk = lane_gather(xi_act, 16 * TK + n); // l_a where a = 16TK+n is active, else its P entry is kept
+    const bool on_diag = (n & 3) == g;
+    const v4d zero = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int ta = 0; ta < 4; ++ta)
+    for (int h = 0; h < 2; ++h) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int ta = 2 * HALF + h;
+        v4d Kt[4] = {zero, zero, zero, zero};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool row_act = (am >> (16 * ta + n)) & 1ull, col_act = (am >> (16 * TK + 4 * r + g)) & 1ull;
-            double t = (row_act || col_act) ? 0.0 : T[ta][r];
-            if (ta == TK) t = (row_act && 4 * r + g == n) ? dk : t;
-            T[ta][r] = t;
-        }
-    mv.add_row<TK>(T);
+        for (int tk = 0; tk < 4; ++tk)
 #pragma unroll
-    for (int ta = 0; ta < 4; ++ta)
+            for (int tb = 0; tb < 4; ++tb) Kt[tb] = tile_xty(Kt[tb], A[tk][ta], A[tk][tb]); // sum_k A~[a][k] A~[b][k]
 #pragma unroll
-        for (int tb = 0; tb < 4; ++tb) K[ta][tb] = tile_xty(K[ta][tb], T[ta], T[tb]); // += sum_k A~[a][k] A~[b][k]
-    __builtin_amdgcn_sched_barrier(0); // keep the next tile-row's 32 loads behind this row's products (registers)
-}
-
-template <int TK, bool TRANSPOSED>
-static DQQ_D void stream_matvec_row(MatvecStream& mv, const double* __restrict__ Pg, int lane)
-{
-    v4d T[4];
-    if (TRANSPOSED) load_tile_row_transposed<TK>(T, Pg, lane);
-    else load_tile_row_plain<TK>(T, Pg, lane);
-    mv.add_row<TK>(T);
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// P x (TRANSPOSED_LAYOUT = true) or P^T x, P streamed from memory
-template <bool TRANSPOSED_LAYOUT>
-static DQQ_D double stream_matvec(const double* __restrict__ Pg, double x, int xsrc, int lane)
-{
-    MatvecStream mv;
-    mv.begin(x, xsrc);
-    stream_matvec_row<0, TRANSPOSED_LAYOUT>(mv, Pg, lane);
-    stream_matvec_row<1, TRANSPOSED_LAYOUT>(mv, Pg, lane);
-    stream_matvec_row<2, TRANSPOSED_LAYOUT>(mv, Pg, lane);
-    stream_matvec_row<3, TRANSPOSED_LAYOUT>(mv, Pg, lane);
-    return mv.finish();
+        for (int r = 0; r < 4; ++r) Kt[ta][r] += (on_diag && (n >> 2) == r) ? kMuIr : 0.0;   // + mu_ir I, :21
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) (Ks + ((ta * 4 + tb) * 4 + r) * 64)[lane] = Kt[tb][r];
+    }
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_dense_wave64_qp_kernel(
     const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ x,
-    const double* __restrict__ grad_x, double* __restrict__ grad_P, double* __restrict__ grad_q, long B, double dual_eps,
+    const double* __restrict__ grad_x, double* grad_P, double* __restrict__ grad_q, long B, double dual_eps,
     int* __restrict__ ir_steps, int* __restrict__ ws, int use_worklist)
 {
     constexpr int N = 64;
@@ -319,34 +290,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // wave-uniform by construction; readfirstlane tells the compiler so (P's addressing then uses an SGPR base)
         const long prob = __builtin_amdgcn_readfirstlane(use_worklist ? ws[kWsEntries + w] : (int)w);
         const double* Pg = P + prob * (long)(N * N);
+        double* Ks = grad_P + prob * (long)(N * N);   // scratch for K until the gradient is written
         const double xi = x[prob * N + lane], gi = grad_x[prob * N + lane], qi = q[prob * N + lane];
+        WaveTile64 W;
+        load_tiles_transposed(W.G, Pg, lane);         // W.G[tk][ta][r] of lane (g,n) = P[16ta+n][16tk+4r+g]
         // dualFromPrimalQP, Solver.cpp:125-134, and the active set of solveDerivativesQP, :139-147
-        double gamma = -(stream_matvec<true>(Pg, xi, xsrc, lane) + qi);
+        double gamma = -(W.matvec(xi, xsrc) + qi);
         if (xi > dual_eps) gamma = 0;
         const bool is_act = gamma < -kActiveEps;
         const unsigned long long am = __ballot(is_act);
-        // A^T b (:19) with b = [0; grad_I], and K = A~ A~^T + mu_ir I (:20-21), in one stream of P
-        WaveTile64 W;
-        const v4d zero = {0.0, 0.0, 0.0, 0.0};
+        // A~ in place: zero where the row a = 16ta+n or the column k = 16tk+4r+g is active, l_a on the diagonal of
+        // an active a (:148-158)
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int tk = 0; tk < 4; ++tk) {
+            const double dk = lane_gather(xi, 16 * tk + n);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) W.G[a][b] = zero;
-        MatvecStream mv;
-        mv.begin(is_act ? 0.0 : gi, xsrc);
-        bwd_qp_accumulate_row<0>(W.G, mv, Pg, am, xi, lane);
-        bwd_qp_accumulate_row<1>(W.G, mv, Pg, am, xi, lane);
-        bwd_qp_accumulate_row<2>(W.G, mv, Pg, am, xi, lane);
-        bwd_qp_accumulate_row<3>(W.G, mv, Pg, am, xi, lane);
-        double Ab = mv.finish();
-        if (is_act) Ab = 0.0;
-        {
-            const bool on_diag = (n & 3) == g;
+            for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) W.G[t][t][r] += (on_diag && (n >> 2) == r) ? kMuIr : 0.0;
+                for (int r = 0; r < 4; ++r) {
+                    const bool row_act = (am >> (16 * ta + n)) & 1ull, col_act = (am >> (16 * tk + 4 * r + g)) & 1ull;
+                    double t = (row_act || col_act) ? 0.0 : W.G[tk][ta][r];
+                    if (ta == tk) t = (row_act && 4 * r + g == n) ? dk : t;
+                    W.G[tk][ta][r] = t;
+                }
         }
+        double Ab = W.matvec(is_act ? 0.0 : gi, xsrc);                        // A^T b (:19), b = [0; grad_I]
+        if (is_act) Ab = 0.0;
+        bwd_qp_gram_half<0>(W.G, Ks, lane);                                   // K = A~ A~^T + mu_ir I (:20-21)
+        bwd_qp_gram_half<1>(W.G, Ks, lane);
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) W.G[ti][tj][r] = (Ks + ((ti * 4 + tj) * 4 + r) * 64)[lane];
         bool bad = false;
         block_sweep_inverse(W.G, lane, bad);                                  // :22-23; W.G = -K^-1
         const double KinvAb = -W.matvec(Ab, xsrc);                            // :27
@@ -357,22 +334,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         for (int it = 0; it < kIrMaxIter; ++it) {
             steps = it + 1;
             xs = KinvAb - kMuIr * W.matvec(xs, xsrc);                         // :29
-            // K xs - A^T b (:30) = A~ (A~^T xs) + mu xs - Ab; xs is exactly zero on the active set
-            double wv = stream_matvec<false>(Pg, is_act ? 0.0 : xs, xsrc, lane);
-            wv = is_act ? 0.0 : wv;
-            double y = stream_matvec<true>(Pg, wv, xsrc, lane);
-            y = is_act ? (xi * xi) * xs : y;
-            const double d = (y + kMuIr * xs) - Ab;
+            MatvecStream mv;                                                  // K xs, K streamed from its slot
+            mv.begin(xs, xsrc);
+            stream_tileorder_row<0>(mv, Ks, lane);
+            stream_tileorder_row<1>(mv, Ks, lane);
+            stream_tileorder_row<2>(mv, Ks, lane);
+            stream_tileorder_row<3>(mv, Ks, lane);
+            const double d = mv.finish() - Ab;                                // :30
             const double res = sqrt(wave_sum64(d * d));                       // :31
             if (ctl.update(res)) break;                                       // :32-41
         }
         const double dl = bad ? NAN : (is_act ? 0.0 : xs);                    // :187-191
         if (grad_q != nullptr) grad_q[prob * N + lane] = -dl;                // qcqp.py:49
-        if (grad_P != nullptr) {                                              // qcqp.py:48: -(dl l^T)
-            double* Gp = grad_P + prob * (long)(N * N);
 #pragma unroll 8
-            for (int k = 0; k < N; ++k) __builtin_nontemporal_store(-(lane_bcast(dl, k) * xi), Gp + k * N + lane);
-        }
+        for (int k = 0; k < N; ++k)                                           // qcqp.py:48: -(dl l^T)
+            __builtin_nontemporal_store(-(lane_bcast(dl, k) * xi), Ks + k * N + lane);
         if (ir_steps != nullptr && lane == 0) ir_steps[prob] = steps;
     }
     if (use_worklist && threadIdx.x == 0) worklist_release(ws, count, (int)gridDim.x);
@@ -383,7 +359,7 @@ bool bwd_dense_wave64_supported(int kind, int N) { return kind == 0 && N == 64; 
 hipError_t launch_bwd_dense_wave64(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
-    if (kind != 0 || a.N != 64) return hipErrorInvalidValue;
+    if (kind != 0 || a.N != 64 || a.grad_P == nullptr) return hipErrorInvalidValue;
     const long cap = 1L << 22;
     const unsigned grid = use_worklist ? 2048u : (unsigned)(a.B < cap ? a.B : cap);
     return launch(bwd_dense_wave64_qp_kernel, dim3(grid), dim3(64), 0, s, a.P, a.q, a.x, a.grad_x, a.grad_P, a.grad_q,
