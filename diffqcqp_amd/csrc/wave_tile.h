@@ -22,8 +22,7 @@ namespace dqq {
 
 // acc += (lane BC of this lane's 16-lane row of x) * m      (v_fmac_f64 with a DPP row_newbcast source)
 #define DQQ_FMAC_BCAST_ROW(TI, R)                                                                              \
-    asm("s_nop 1\n\t"                                                                                           \
-        "v_fmac_f64_dpp %0, %4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                              \
+    asm("v_fmac_f64_dpp %0, %4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                              \
         "v_fmac_f64_dpp %1, %4, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                              \
         "v_fmac_f64_dpp %2, %4, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                              \
         "v_fmac_f64_dpp %3, %4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"                                  \
@@ -32,8 +31,7 @@ namespace dqq {
 
 // the same for one tile-row T[0..3] streamed from memory: acc[tj] += T[tj][R] * (lane BC of the row of x0)
 #define DQQ_FMAC_BCAST_TROW(T, R, BC)                                                                          \
-    asm("s_nop 1\n\t"                                                                                           \
-        "v_fmac_f64_dpp %0, %4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                              \
+    asm("v_fmac_f64_dpp %0, %4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                              \
         "v_fmac_f64_dpp %1, %4, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                              \
         "v_fmac_f64_dpp %2, %4, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                              \
         "v_fmac_f64_dpp %3, %4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"                                  \
@@ -56,6 +54,15 @@ DQQ_D void swap16(double a, double b, double& even_rows, double& odd_rows)
     const auto h = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
     even_rows = __hiloint2double(h[0], l[0]);
     odd_rows = __hiloint2double(h[1], l[1]);
+}
+
+// A DPP source written by a VALU instruction needs two wait states before the DPP read.  The mat-vec's source
+// comes from ds_bpermute (no hazard), but the compiler may copy it with a v_mov right before the first
+// v_fmac_f64_dpp of an asm block it cannot see into: this pins the value and pays the two states once.
+DQQ_D double dpp_source(double v)
+{
+    asm volatile("s_nop 1" : "+v"(v));
+    return v;
 }
 
 // value of v held by lane `src_lane` (per-lane index), through the LDS crossbar (no LDS memory)
@@ -89,7 +96,7 @@ struct WaveTile64 {
     // element per lane.  xsrc = 4 (lane & 15) + (lane >> 4).
     DQQ_D double matvec(double x, int xsrc) const
     {
-        const double x0 = lane_gather(x, xsrc); // lane (g, n') <- x[4 n' + g]
+        const double x0 = dpp_source(lane_gather(x, xsrc)); // lane (g, n') <- x[4 n' + g]
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         DQQ_FMAC_BCAST_ROW(0, 0); DQQ_FMAC_BCAST_ROW(0, 1); DQQ_FMAC_BCAST_ROW(0, 2); DQQ_FMAC_BCAST_ROW(0, 3);
         DQQ_FMAC_BCAST_ROW(1, 0); DQQ_FMAC_BCAST_ROW(1, 1); DQQ_FMAC_BCAST_ROW(1, 2); DQQ_FMAC_BCAST_ROW(1, 3);
@@ -113,7 +120,7 @@ struct MatvecStream {
     double x0, a0, a1, a2, a3;
     DQQ_D void begin(double x, int xsrc)
     {
-        x0 = lane_gather(x, xsrc);
+        x0 = dpp_source(lane_gather(x, xsrc));
         a0 = a1 = a2 = a3 = 0.0;
     }
     template <int TK>
@@ -142,8 +149,8 @@ struct MatvecStream {
 // Each 16-lane row of the wave works on the same block redundantly: lane (.,i) holds row i of the block in
 // 16 registers, a pivot column is handed to the other rows of the block as a DPP row_newbcast operand.
 // Sweep k on the stored rows a_i (true row = s_i * stored row, s_i = 1 until row i has been the pivot):
-//     d = a_kk, t_i = a_ik / d, b_i = s_i t_i (= true a_ik / d = true a_ki / d by symmetry)
-//     rows i != k:  a_ij -= a_ik b_j  (j != k),  a_ik = t_i
+//     d = a_kk, t_i = a_ik / d, b_i = -s_i t_i (= minus the true a_ik / d = a_ki / d by symmetry)
+//     rows i != k:  a_ij += a_ik b_j  (j != k),  a_ik = t_i
 //     row k: unchanged except a_kk = -1, s_k = 1/d      (deferring the scaling of the pivot row keeps the
 //     update of all rows the same instruction; scaling it in place would cost a second pass per sweep)
 // After 16 sweeps s_i * a_i = -B^-1.   bad: a pivot was not positive.
@@ -164,18 +171,21 @@ struct MatvecStream {
     } while (0)
 
 template <int K>
-DQQ_D void sweep16_step(double (&a)[16], double& s, int n, bool& bad)
+DQQ_D void sweep16_step(double (&a)[16], double& ns, int n, bool& bad)
 {
+    // ns = MINUS the row scale s: b carries the sign, so the update below is a plain a_ij += b_j * a_ik
     const double d = __builtin_amdgcn_update_dpp(0.0, a[K], 0x150 + K, 0xf, 0xf, true); // a_kk of this 16-lane row
-    bad = bad || __ballot(!(d > 0.0)) != 0; // decided here (scalar), or all 64 pivots stay alive for a late test
+    bad = bad | (__ballot(!(d > 0.0)) != 0); // decided here (scalar, no branch), or all 64 pivots stay alive for a late test
     const double rd = fast_rcp(d);
     const double c = a[K];
     const double t = c * rd;
-    const double b = t * s;
-    const bool piv = (n == K);
-    const double nc = piv ? 0.0 : -c;
-    a[K] = piv ? -1.0 : t;
-    s = piv ? rd : s;
+    const double b = t * ns;                 // - true a_ik / d
+    double nc = c;
+    if (n == K) {                            // the pivot row (an exec-mask region, no per-lane selects): keeps its
+        nc = 0.0;                            // entries, a_kk = -1, and from now on carries the scale 1/d
+        ns = -rd;
+    }
+    a[K] = (n == K) ? -1.0 : t;
     // the 15 columns j != K, the next pivot's column first
     if constexpr (K == 0) DQQ_SWEEP15(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
     if constexpr (K == 1) DQQ_SWEEP15(1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0);
@@ -207,7 +217,7 @@ DQQ_D v4d diag16_inverse(const v4d& T, int lane, bool& bad)
         swap16(h0, h0, a[4 * r + 0], a[4 * r + 1]);
         swap16(h1, h1, a[4 * r + 2], a[4 * r + 3]);
     }
-    double s = 1.0;
+    double s = -1.0; // minus the row scale
     sweep16_step<0>(a, s, n, bad);  sweep16_step<1>(a, s, n, bad);  sweep16_step<2>(a, s, n, bad);
     sweep16_step<3>(a, s, n, bad);  sweep16_step<4>(a, s, n, bad);  sweep16_step<5>(a, s, n, bad);
     sweep16_step<6>(a, s, n, bad);  sweep16_step<7>(a, s, n, bad);  sweep16_step<8>(a, s, n, bad);
@@ -219,7 +229,7 @@ DQQ_D v4d diag16_inverse(const v4d& T, int lane, bool& bad)
     // `g & 1 ? a[i+1] : a[i]` is turned into a dynamically indexed load by the compiler, which sends the whole
     // array to scratch)
     v4d D;
-    const double ns = -s;
+    const double ns = s; // already minus the scale
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         double lo, hi, pick, unused;
