@@ -86,24 +86,34 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
     }
 
     // ---- Solver.cpp:72-77 / 531-536
-    double rho = sqrt(mu * L) * pow(L / mu, .4);
-    double tau_inc = pow(L / mu, .15), tau_dec = tau_inc;
+    double p40, p15;
+    G::pow_pair(L / mu, p40, p15);
+    double rho = sqrt(mu * L) * p40;
+    double tau_inc = p15, tau_dec = tau_inc;
     double inv_rho = fast_rcp(rho);
     bool bad = !(rho > 0.0) || !(rho < 1.79e308);
+    // Every M[e] receives the same sequence of additions and rounding is monotone, so the smallest M[e] is always
+    // the one of the smallest p[e]: positivity of the shifted diagonal after a rho update is ONE comparison.
+    double Mmin = p[0];
+#pragma unroll
+    for (int e = 1; e < E; ++e) Mmin = fmin(Mmin, p[e]);
+    Mmin = Mmin + (rho + mu);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         M[e] = p[e] + (rho + mu);
-        bad = bad || !(M[e] > 0.0);
+        bad = bad || !(M[e] > 0.0);   // (also catches a NaN entry, which fmin above would drop)
         Minv[e] = fast_rcp(M[e]);
         qp[e] = q[e];
         l2[e] = 0.0;
         u[e] = 0.0;
     }
 
+    // A per-lane loop: a lane leaves it when its problem stops (all lanes of a problem decide alike: the group
+    // reductions are symmetric) and keeps its state in place under the execution mask -- as a wave-uniform loop
+    // around a `done` flag the same code carried a dozen register copies per iteration.
     int rho_up = 0, cpt = 0, iters = 0;
-    bool done = !valid;
-    for (int it = 0; it < max_iter; ++it) {
-        if (!done) {
+    if (valid) {
+        for (int it = 0; it < max_iter; ++it) {
             double rd = 0.0, rp = 0.0, nl = 0.0;
             double w[E], z[E];
 #pragma unroll
@@ -144,12 +154,20 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
                     }
                 }
             }
+            double dw[E], dz[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                u[e] += rho * (w[e] - z[e]);                                  // :83 / :543
-                rd = fmax(rd, fabs(z[e] - l2[e]));                            // :84-85 / :544-545
-                rp = fmax(rp, fabs(z[e] - w[e]));                             // :86 / :546
+                dw[e] = w[e] - z[e];
+                dz[e] = z[e] - l2[e];
+                u[e] += rho * dw[e];                                          // :83 / :543
                 l2[e] = z[e];                                                 // :87 / :547
+            }
+            rd = max_abs2(dz[0], dz[1]);                                      // :84-85 / :544-545
+            rp = max_abs2(dw[0], dw[1]);                                      // :86 / :546
+#pragma unroll
+            for (int e = 2; e < E; ++e) {
+                rd = max_abs1(rd, dz[e]);
+                rp = max_abs1(rp, dw[e]);
             }
             rd = G::max(rd);
             rp = G::max(rp);
@@ -160,8 +178,8 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
             if (KIND == 1) {
                 if (stop) stop = res_prim < eps + kEpsRel * sqrt(G::sum(nl)); // :548
             }
-            done = stop;
-            if (!stop && adaptive) {
+            if (stop) break;
+            if (adaptive) {
                 // rho adaptation, Solver.cpp:90-120 / 550-580: increase when the primal residual dominates,
                 // decrease when the dual one does, at most once every 5 imbalanced iterations.  Same state
                 // machine as common.h RhoSchedule (used by the general kernels), kept inline here: through the
@@ -184,16 +202,16 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
                     rho_up = inc ? 1 : -1;
                     inv_rho = fast_rcp(rho);
                     // llt() + solveInPlace(Identity) of the shifted matrix, diagonal case (:100-101)
+                    Mmin += delta;
+                    bad = bad || !(Mmin > 0.0);
 #pragma unroll
                     for (int e = 0; e < E; ++e) {
                         M[e] += delta;
-                        bad = bad || !(M[e] > 0.0);
                         Minv[e] = fast_rcp(M[e]);
                     }
                 }
             }
         }
-        if (G::wave_all(done)) break;
     }
     bad = G::max(bad ? 1.0 : 0.0) > 0.0;
 #pragma unroll

@@ -116,11 +116,49 @@ struct RhoSchedule {
     }
 };
 
+// max(a, b) as ONE v_max_f64: fmax() makes the compiler quiet both operands first (a v_max_f64 x, x, x each)
+// whenever it cannot prove them canonical, e.g. after a DPP move.  Same result for every non-signalling input.
+DQQ_HD double max_raw(double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return fmax(a, b);
+#endif
+}
+
+// max(|a|, |b|) and max(a, |b|), one instruction each (source modifiers)
+DQQ_HD double max_abs2(double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return fmax(fabs(a), fabs(b));
+#endif
+}
+DQQ_HD double max_abs1(double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return fmax(a, fabs(b));
+#endif
+}
+
 // One lane owns the whole problem: reductions are the identity.
 struct HostGroup {
+    static constexpr int kLanes = 1;
     static DQQ_HD double sum(double v) { return v; }
     static DQQ_HD double max(double v) { return v; }
     static DQQ_HD bool wave_all(bool b) { return b; }
+    // x^0.4 and x^0.15 (rho and tau of Solver.cpp:72-73)
+    static DQQ_HD void pow_pair(double x, double& p40, double& p15) { p40 = pow(x, .4); p15 = pow(x, .15); }
 };
 
 #if defined(__HIPCC__)
@@ -160,6 +198,23 @@ DQQ_D double partner(double v)
 // LPP adjacent lanes (LPP a power of two, aligned) share one problem.
 template <int LPP>
 struct LaneGroup {
+    static constexpr int kLanes = LPP;
+    // x^0.4 and x^0.15: with two or more lanes per problem the even lane evaluates one power and the odd lane
+    // the other (one pow() per lane, a per-lane exponent), then they swap -- all lanes of the problem end up with
+    // the same two bit patterns
+    static DQQ_D void pow_pair(double x, double& p40, double& p15)
+    {
+        if constexpr (LPP >= 2) {
+            const bool odd = (threadIdx.x & 1) != 0;
+            const double mine = pow(x, odd ? .15 : .4);
+            const double other = partner<1>(mine);
+            p40 = odd ? other : mine;
+            p15 = odd ? mine : other;
+        } else {
+            p40 = pow(x, .4);
+            p15 = pow(x, .15);
+        }
+    }
     static DQQ_D double sum(double v)
     {
         if constexpr (LPP >= 2) v = v + partner<1>(v);
@@ -172,12 +227,12 @@ struct LaneGroup {
     }
     static DQQ_D double max(double v)
     {
-        if constexpr (LPP >= 2) v = fmax(v, partner<1>(v));
-        if constexpr (LPP >= 4) v = fmax(v, partner<2>(v));
-        if constexpr (LPP >= 8) v = fmax(v, partner<4>(v));
-        if constexpr (LPP >= 16) v = fmax(v, partner<8>(v));
-        if constexpr (LPP >= 32) v = fmax(v, partner<16>(v));
-        if constexpr (LPP >= 64) v = fmax(v, partner<32>(v));
+        if constexpr (LPP >= 2) v = max_raw(v, partner<1>(v));
+        if constexpr (LPP >= 4) v = max_raw(v, partner<2>(v));
+        if constexpr (LPP >= 8) v = max_raw(v, partner<4>(v));
+        if constexpr (LPP >= 16) v = max_raw(v, partner<8>(v));
+        if constexpr (LPP >= 32) v = max_raw(v, partner<16>(v));
+        if constexpr (LPP >= 64) v = max_raw(v, partner<32>(v));
         return v;
     }
     static DQQ_D bool wave_all(bool b) { return __all(b); }
