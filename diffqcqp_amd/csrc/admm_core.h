@@ -147,11 +147,9 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
                     const double n2 = a * a + b * b;
                     const double rn = fast_rsqrt(n2);      // n2 == 0: inf -> nrm NaN -> no scaling
                     const double nrm = n2 * rn;
-                    if (nrm > rad[c]) {
-                        const double sc = rad[c] * rn;
-                        z[2 * c] = a * sc;
-                        z[2 * c + 1] = b * sc;
-                    }
+                    const double sc = (nrm > rad[c]) ? rad[c] * rn : 1.0; // one select; * 1.0 is exact
+                    z[2 * c] = a * sc;
+                    z[2 * c + 1] = b * sc;
                 }
             }
             double dw[E], dz[E];

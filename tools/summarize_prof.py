@@ -25,7 +25,10 @@ def short(name):
     m = re.search(r"dqq::(\w+)<([^>]*)>", name)
     if m:
         return "%s<%s>" % (m.group(1), m.group(2).replace(" ", ""))
-    return name.split("(")[0][:80]
+    name = name.split("(")[0]
+    if name.startswith("dqq::"):
+        name = name[5:]
+    return name[:80]
 
 
 def bench_key(s):
@@ -73,9 +76,13 @@ def main():
             e = latest.setdefault(key, {"kernels": [], "hbm_bytes_per_launch": 0.0})
             e["kernels"].append(k)
             e["hbm_bytes_per_launch"] += v["hbm_bytes_per_launch"]
-            for extra in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES"):
-                if extra in v:
-                    e[extra] = e.get(extra, 0.0) + v[extra]
+            # instruction counters: those of the kernel that does the work (the largest), not of the empty
+            # work-list launch next to it
+            if v.get("SQ_INSTS_VALU", 0.0) >= e.get("SQ_INSTS_VALU", -1.0):
+                e["main_kernel"] = k
+                for extra in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES"):
+                    if extra in v:
+                        e[extra] = v[extra]
     for e in latest.values():
         if e.get("SQ_WAVES"):
             e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
