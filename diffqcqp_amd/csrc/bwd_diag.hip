@@ -64,29 +64,35 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : (KIND == 1 ? 4 :
     bool have_diag = false;
     if (pdiag != nullptr && flags != nullptr && layout == DQQ_P_AUTO)
         have_diag = __all(!valid || flags[first + pl] != 0);
+    constexpr bool AGG = !FUSE && N >= 32 && WPB > 1; // queue non-diagonal tiles with one atomic per workgroup
+    __shared__ int s_cnt[2];
     if (layout == DQQ_P_DIAG) {
         pv = valid ? *reinterpret_cast<const double2*>(P + first * N + 2 * lane) : make_double2(1.0, 1.0);
-    } else if (have_diag) {
-        pv = valid ? *reinterpret_cast<const double2*>(pdiag + first * N + 2 * lane) : make_double2(1.0, 1.0);
     } else {
-        const double* Pw = P + first * (long)(N * N);
-        const unsigned nz = (nvalid == T) ? stream_tile_diag<N, N, false>(Pw, limit, pd, lane)
-                                          : stream_tile_diag<N, N, true>(Pw, limit, pd, lane);
-        if (__any(nz != 0)) { // wave-uniform
-            if constexpr (FUSE) {
+        bool tile_dense = false;
+        if (have_diag) {
+            pv = valid ? *reinterpret_cast<const double2*>(pdiag + first * N + 2 * lane) : make_double2(1.0, 1.0);
+        } else {
+            const double* Pw = P + first * (long)(N * N);
+            const unsigned nz = (nvalid == T) ? stream_tile_diag<N, N, false>(Pw, limit, pd, lane)
+                                              : stream_tile_diag<N, N, true>(Pw, limit, pd, lane);
+            tile_dense = __any(nz != 0); // wave-uniform
+        }
+        if constexpr (FUSE) {
+            if (tile_dense) {
                 for (int jj = 0; jj < nvalid; ++jj)
                     dense_bwd_problem<KIND>(P, q, l_n, mu_c, x, grad_x, grad_P, grad_q, grad_l_n, grad_mu, gamma_out,
                                             dgamma_out, ir_steps, first + jj, N, dual_eps, s_dense[wave], lane);
                 return;
             }
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&ws[kWsCount], nvalid);
-            base = __shfl(base, 0, 64);
-            if (lane < nvalid) ws[kWsEntries + base + lane] = (int)(first + lane);
-            return;
+        } else if (layout == DQQ_P_AUTO) {
+            worklist_push<AGG>(ws, first, tile_dense ? nvalid : 0, lane, s_cnt);
+            if (tile_dense) return;
         }
-        wave_lds_fence();
-        pv = valid ? *reinterpret_cast<const double2*>(pd + 2 * lane) : make_double2(1.0, 1.0);
+        if (!have_diag) {
+            wave_lds_fence();
+            pv = valid ? *reinterpret_cast<const double2*>(pd + 2 * lane) : make_double2(1.0, 1.0);
+        }
     }
 
     // ---------------- phase B: per-lane KKT blocks + iterative refinement

@@ -45,6 +45,8 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
     // the dense kernel launched behind this one.
     constexpr int SMEM = (FUSE && dense_fwd_lds_doubles(N) > 64 * E) ? dense_fwd_lds_doubles(N) : 64 * E;
     __shared__ __attribute__((aligned(16))) double s_diag[WPB][SMEM];
+    constexpr bool AGG = !FUSE && N >= 32 && WPB > 1; // queue non-diagonal tiles with one atomic per workgroup
+    __shared__ int s_cnt[2];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long tile = (long)blockIdx.x * WPB + wave;
@@ -71,19 +73,18 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
         double* sd = s_diag[wave];
         const unsigned nz = (nvalid == PPW) ? stream_tile_diag<N, NCH, false>(Pw, limit, sd, lane)
                                             : stream_tile_diag<N, NCH, true>(Pw, limit, sd, lane);
-        if (__any(nz != 0)) { // wave-uniform
-            if (flags_out != nullptr && valid && (lane % LPP) == 0) flags_out[first + pl] = 0;
-            if constexpr (FUSE) {
+        const bool tile_dense = __any(nz != 0); // wave-uniform
+        if (tile_dense && flags_out != nullptr && valid && (lane % LPP) == 0) flags_out[first + pl] = 0;
+        if constexpr (FUSE) {
+            if (tile_dense) {
                 for (int j = 0; j < nvalid; ++j)
                     dense_fwd_problem<KIND>(P, q, l_n, mu_c, v_sign, x, iters, first + j, N, eps, mu_prox, max_iter,
                                             adaptive, sd, lane);
                 return;
             }
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&ws[kWsCount], nvalid);
-            base = __shfl(base, 0, 64);
-            if (lane < nvalid) ws[kWsEntries + base + lane] = (int)(first + lane);
-            return;
+        } else {
+            worklist_push<AGG>(ws, first, tile_dense ? nvalid : 0, lane, s_cnt);
+            if (tile_dense) return;
         }
         wave_lds_fence();
 #pragma unroll

@@ -59,6 +59,38 @@ static inline hipError_t launch(void (*kernel)(KArgs...), dim3 grid, dim3 block,
 }
 #endif
 
+#if defined(__HIPCC__)
+// Queue the n problems [first, first + n) of the calling wave (n = 0: none) for the general kernel.
+// AGG: ONE global atomic per workgroup instead of one per wave -- with N >= 32 a wave tile is 2 to 16 problems, and
+// a dense batch through DQQ_P_AUTO otherwise serialises tens of thousands of same-address atomics (0.38 ms at
+// B=65536, N=64).  Every wave of the workgroup that has not returned yet must make the call (three workgroup
+// barriers; waves that already ended are not waited for).  s_cnt: two ints of LDS.
+template <bool AGG>
+static DQQ_D void worklist_push(int* __restrict__ ws, long first, int n, int lane, int* s_cnt)
+{
+    if constexpr (!AGG) {
+        if (n > 0) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&ws[kWsCount], n);
+            base = __shfl(base, 0, 64);
+            if (lane < n) ws[kWsEntries + base + lane] = (int)(first + lane);
+        }
+    } else {
+        if (threadIdx.x == 0) s_cnt[0] = 0;
+        __syncthreads();
+        int local = 0;
+        if (lane == 0 && n > 0) local = atomicAdd(&s_cnt[0], n);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_cnt[0] > 0) s_cnt[1] = atomicAdd(&ws[kWsCount], s_cnt[0]);
+        __syncthreads();
+        if (n > 0) {
+            const int base = s_cnt[1] + __shfl(local, 0, 64);
+            if (lane < n) ws[kWsEntries + base + lane] = (int)(first + lane);
+        }
+    }
+}
+#endif
+
 struct FwdArgs {
     const double* P;
     const double* q;
