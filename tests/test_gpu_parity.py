@@ -845,6 +845,45 @@ def test_full_size_config4_per_gpu_shard(oracle, ops):
     check_backward_exact(gs, sts, oracle_bwd(oracle, "qp", ds, xo))
 
 
+def test_full_size_config4_whole_batch(oracle, ops):
+    """configs[3] at its FULL size on one GPU: B=262144, N=32, diagonal P in the (B,32,32) layout (2.1 GB of P,
+    generated on the device), QP forward + backward.  Size-independent properties over the whole batch: closed form
+    x* = max(-q/p, 0) within the solver's accuracy, feasibility, iteration counts inside the family's range, the
+    backward identity dl_i = p_i g_i / (p_i^2 + 1e-7) on the inactive set, grad_P = grad_q (x) x bit for bit,
+    equivariance under a permutation of the batch; plus the oracle on a sample spread over the batch."""
+    B, N = 262144, 32
+    gen = torch.Generator(device="cuda").manual_seed(1004)
+    p = torch.rand(B, N, generator=gen, dtype=torch.float64, device="cuda") + 0.1
+    P = torch.diag_embed(p).contiguous()
+    q = 2 * torch.rand(B, N, 1, generator=gen, dtype=torch.float64, device="cuda") - 1
+    gx = torch.randn(B, N, 1, generator=gen, dtype=torch.float64, device="cuda")
+    cache = ops.diag_cache(q)
+    x, it = ops.qp_forward(P, q, 1e-7, 1000, return_iters=True, cache=cache)
+    assert bool(cache[1].all())                                    # every tile verified diagonal
+    assert bool((x >= 0).all()) and 10 <= int(it.min()) and int(it.max()) < 60
+    cf = torch.clamp(-q[:, :, 0] / p, min=0)
+    err = (x[:, :, 0] - cf).abs().amax(1)
+    assert float(err.median()) < 1e-6 and float(err.max()) < 1e-3   # the reference's own accuracy (SURVEY 0.4)
+    gP, gq, st = ops.qp_backward(P, q, x, gx, return_steps=True, cache=cache)
+    assert int(st.max()) == 1 and int(st.min()) == 1
+    assert torch.equal(gP, gq * x.transpose(1, 2))                  # qcqp.py:48-51
+    inactive = (x[:, :, 0] > 1e-10) | (-(p * x[:, :, 0] + q[:, :, 0]) >= -1e-10)
+    dl = torch.where(inactive, p * gx[:, :, 0] / (p * p + 1e-7), torch.zeros_like(p))
+    assert float((gq[:, :, 0] + dl).abs().max()) < 1e-9
+    # permutation equivariance on a slice (problems are independent: no cross-problem term anywhere)
+    perm = torch.randperm(4096, generator=torch.Generator().manual_seed(3)).cuda()
+    sl = slice(100000, 104096)
+    xp, itp = ops.qp_forward(P[sl][perm].contiguous(), q[sl][perm].contiguous(), 1e-7, 1000, return_iters=True)
+    # (the smaller batch runs with fewer lanes per problem: same trajectory, tree sums associated differently)
+    assert torch.equal(itp, it[sl][perm]) and float((xp - x[sl][perm]).abs().max()) < 1e-12
+    idx = torch.arange(0, B, 1024, device="cuda")
+    d = {"P": P[idx].cpu(), "q": q[idx].cpu(), "grad_x": gx[idx].cpu()}
+    xo, ito = oracle_fwd(oracle, "qp", d)
+    check_forward(x[idx], it[idx], xo, ito)
+    gs, sts = hip_bwd(ops, "qp", dev(d), torch.from_numpy(xo).cuda())
+    check_backward_exact(gs, sts, oracle_bwd(oracle, "qp", d, xo))
+
+
 def test_full_size_config5_dense_n64(oracle, ops):
     """configs[4] at its full size: B=65536, N=64, dense P = S S^T/64 + 0.1 I (generated on the device), QP
     forward + backward.  Size-independent properties: feasibility, the natural KKT residual |min(x, Px+q)|,
