@@ -21,7 +21,8 @@
 // u*(1/rho) instead of u/rho;
 // compiler FMA contraction; group (tree) sums when LPP > 1; 1-ulp reciprocal /
 // reciprocal-square-root (common.h fast_rcp / fast_rsqrt) in place of IEEE divide
-// and sqrt in the power iteration, the disk projection and the rho updates.
+// and sqrt in the power iteration, the disk projection and the rho updates; the QCQP's
+// primal stop test compared in squared form (no square root).
 // Failure signalling: the reference's LLT of a non-positive shifted diagonal
 // yields NaNs (Solver.cpp:76, never checked); here a non-positive M or a
 // non-finite rho poisons the output with NaN explicitly.
@@ -114,15 +115,15 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
     int rho_up = 0, cpt = 0, iters = 0;
     if (valid) {
         for (int it = 0; it < max_iter; ++it) {
-            double rd = 0.0, rp = 0.0, nl = 0.0;
-            double w[E], z[E];
+            double rd = 0.0, rp = 0.0;
+            double w[E], z[E], lv[(KIND == 1) ? E : 1];
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const double l = Minv[e] * (rho * l2[e] - u[e] - qp[e]);      // :80 / :539
                 qp[e] = q[e] - mu * l;                                        // :81 / :540
                 w[e] = kAlpha * l + (1 - kAlpha) * l2[e];                     // alpha*l + (1-alpha)*l2_pred
                 z[e] = w[e] + u[e] * inv_rho;                                 // :82 / :541
-                if (KIND == 1) nl += l * l;
+                if (KIND == 1) lv[e] = l;
             }
             if (KIND == 0) {
 #pragma unroll
@@ -174,7 +175,16 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
             iters = it + 1;
             bool stop = res_dual < eps;                                       // :88
             if (KIND == 1) {
-                if (stop) stop = res_prim < eps + kEpsRel * sqrt(G::sum(nl)); // :548
+                if (stop) {
+                    // res_prim < eps + 1e-4 |l|_2 (:548), only evaluated once the dual test passes, and without
+                    // the square root: t = res_prim - eps < 0, or t^2 < 1e-8 |l|^2
+                    double nl = 0.0;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) nl += lv[e] * lv[e];
+                    nl = G::sum(nl);
+                    const double t = res_prim - eps;
+                    stop = t < 0.0 || t * t < (kEpsRel * kEpsRel) * nl;
+                }
             }
             if (stop) break;
             if (adaptive) {

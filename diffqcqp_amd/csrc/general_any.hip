@@ -47,18 +47,21 @@ __global__ __launch_bounds__(kAnyT) void bwd_any_kernel(
     if (use_worklist && t == 0) worklist_release(ws, count, (int)gridDim.x);
 }
 
-// persistent grid: two workgroups per CU when the batch is that large
-static unsigned any_grid(long B, bool use_worklist)
+// persistent grid: two workgroups per CU when the batch is that large -- fewer when their scratch slices
+// (stride doubles each) would not fit a 4 GiB budget (N in the thousands)
+static unsigned any_grid(long B, bool use_worklist, long stride)
 {
-    const long cap = 512;
+    long cap = 512;
+    const long budget = (4L << 30) / (8 * (stride > 0 ? stride : 1));
+    if (cap > budget) cap = budget > 0 ? budget : 1;
     return use_worklist ? (unsigned)cap : (unsigned)(B < cap ? (B > 0 ? B : 1) : cap);
 }
 
 template <int KIND>
 static hipError_t launch_fwd_any_kind(const FwdArgs& a, bool use_worklist, hipStream_t s)
 {
-    const unsigned grid = any_grid(a.B, use_worklist);
     const long stride = (any_fwd_scratch_doubles(a.N) + 1) & ~1L;
+    const unsigned grid = any_grid(a.B, use_worklist, stride);
     double* scratch = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(double) * (size_t)stride * grid, s);
     if (e != hipSuccess) return e;
@@ -83,8 +86,8 @@ hipError_t launch_fwd_any(int kind, const FwdArgs& a, bool use_worklist, hipStre
 template <int KIND>
 static hipError_t launch_bwd_any_kind(const BwdArgs& a, bool use_worklist, hipStream_t s)
 {
-    const unsigned grid = any_grid(a.B, use_worklist);
     const long stride = (any_bwd_scratch_doubles(KIND, a.N) + 1) & ~1L;
+    const unsigned grid = any_grid(a.B, use_worklist, stride);
     double* scratch = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(double) * (size_t)stride * grid, s);
     if (e != hipSuccess) return e;
