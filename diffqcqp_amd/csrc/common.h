@@ -174,9 +174,11 @@ constexpr int kDppRor8 = 0x128;       // row_ror:8: lane i <-> i^8 within 16
 template <int CTRL>
 DQQ_D double dpp_f64(double v)
 {
+    // every control used here reads a valid lane for every lane, so the "old" operand never shows: leaving it
+    // unbound (0 + bound_ctrl) spares the v_mov that would otherwise seed the destination of each half
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 

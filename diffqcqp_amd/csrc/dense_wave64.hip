@@ -161,11 +161,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
             l2 = z;
             u += rho * (kAlpha * l + (1 - kAlpha) * l2p - l2);           // :83 / :543
-            const double rd_i = QP_LIKE ? fabs(rho * (l2 - l2p)) : fabs(l2 - l2p);
-            const double rp_i = fabs(l2 - (kAlpha * l + (1 - kAlpha) * l2p));
+            const double rd_i = QP_LIKE ? rho * (l2 - l2p) : l2 - l2p;         // signed: the maxima take |.|
+            const double rp_i = l2 - (kAlpha * l + (1 - kAlpha) * l2p);
             l2p = l2;
             double rdm, res_prim;
-            wave_max2(rd_i, rp_i, rdm, res_prim);
+            wave_max2_abs(rd_i, rp_i, rdm, res_prim);
             const double res_dual = QP_LIKE ? rdm : rho * rdm;
             bool stop = res_dual < eps;                                  // :88
             if (KIND == 1) stop = (res_prim < eps + kEpsRel * sqrt(wave_sum64(l * l))) && stop; // :548

@@ -79,14 +79,14 @@ DQQ_D double wave_sum64(double v)
     return (lane_bcast(m, 0) + lane_bcast(m, 16)) + (lane_bcast(m, 32) + lane_bcast(m, 48));
 }
 
-// max over the wave of a and of b (both >= 0): one butterfly for both
-DQQ_D void wave_max2(double a, double b, double& ma, double& mb)
+// max over the wave of |a| and of |b|: one butterfly for both
+DQQ_D void wave_max2_abs(double a, double b, double& ma, double& mb)
 {
     double lo, hi;
     swap32(a, b, lo, hi); // lo = {a[0..31] | b[0..31]}, hi = {a[32..63] | b[32..63]}
-    const double m = LaneGroup<16>::max(fmax(lo, hi));
-    ma = fmax(lane_bcast(m, 0), lane_bcast(m, 16));
-    mb = fmax(lane_bcast(m, 32), lane_bcast(m, 48));
+    const double m = LaneGroup<16>::max(max_abs2(lo, hi));
+    ma = max_raw(lane_bcast(m, 0), lane_bcast(m, 16));
+    mb = max_raw(lane_bcast(m, 32), lane_bcast(m, 48));
 }
 
 struct WaveTile64 {
