@@ -180,19 +180,21 @@ static const int* lpp_choices(int N, int& count)
     }
 }
 
-// Built-in choice.  Fewer lanes per problem = fewer VALU instructions per problem (the scalar
+// Built-in choice.  N <= 16: fewer lanes per problem = fewer VALU instructions per problem (the scalar
 // rho/tau/stop logic and the pow() prologue are replicated on every lane of a problem), but the
 // kernel is latency-bound with a single wave per SIMD, so take the smallest LPP that still puts
-// about two waves on each of the chip's 1024 SIMDs -- four for N >= 32, where a wave first streams
-// 32+ KiB of P and more resident waves overlap that stream with other waves' arithmetic
-// (B=32768, N=32: 73 us at LPP 4, 66 us at LPP 8).  Measurements: DESIGN.md.
+// about two waves on each of the chip's 1024 SIMDs.  N >= 32: a wave first streams 32+ KiB of P per
+// problem, and the smaller its tile, the finer that stream interleaves with other waves' arithmetic
+// -- the most lanes per problem win at every batch size measured (N=32 QP forward, LPP 4 / 8 / 16:
+// B=32768 73 / 68 / 63 us, B=262144 478 / 458 / 442 us; QCQP B=32768 84 / 78 / 69 us; N=64 alike).
 int fwd_diag_default_lpp(int N, long B)
 {
     int count = 0;
     const int* c = lpp_choices(N, count);
     if (count == 0) return 0;
+    if (N >= 32) return c[count - 1];
     for (int i = 0; i < count; ++i)
-        if (B * c[i] / 64 >= (N >= 32 ? 4096 : 2048)) return c[i];
+        if (B * c[i] / 64 >= 2048) return c[i];
     return c[count - 1];
 }
 
