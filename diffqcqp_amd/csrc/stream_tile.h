@@ -15,7 +15,7 @@ template <int N, int NCH, bool GUARD>
 static DQQ_D unsigned stream_tile_diag(const double* __restrict__ Pw, int limit, double* sd, int lane)
 {
     unsigned nz = 0;
-    constexpr int U = NCH < 8 ? NCH : 8;
+    constexpr int U = NCH < 16 ? (NCH < 8 ? NCH : 8) : 16;
     for (int k0 = 0; k0 < NCH; k0 += U) {
         double2 v[U];
 #pragma unroll
