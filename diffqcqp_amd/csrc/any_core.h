@@ -52,9 +52,10 @@ static DQQ_D void chol_inverse_wg(double* A, double* Ainv, int n, int ld, int t)
         DQQ_WG_SYNC();
     }
     for (int c = t; c < n; c += kAnyT) { // thread = column of the inverse: L y = e_c, then L^T x = y
-        for (int i = 0; i < n; ++i) {
+        for (int i = 0; i < c; ++i) Ainv[i * ld + c] = 0.0; // L^-1 is lower triangular: exact zeros (0 - sum of 0 products)
+        for (int i = c; i < n; ++i) {
             double v = (i == c) ? 1.0 : 0.0;
-            for (int j = 0; j < i; ++j) v -= A[i * ld + j] * Ainv[j * ld + c];
+            for (int j = c; j < i; ++j) v -= A[i * ld + j] * Ainv[j * ld + c];
             Ainv[i * ld + c] = v / A[i * ld + i];
         }
         for (int i = n - 1; i >= 0; --i) {
@@ -252,12 +253,14 @@ static DQQ_D void any_ir(double* At, double* K, double* Kinv, const double* dd, 
         double Ab = 0.0;
         for (int k = 0; k < rows; ++k) Ab += At[k * ld + i] * dd[k];           // A^T b, :19
         vAb[i] = Ab;
-        for (int j = 0; j < m; ++j) {                                           // A^T A, :20
-            double s = 0.0;
-            for (int k = 0; k < rows; ++k) s += At[k * ld + i] * At[k * ld + j];
-            K[i * ld + j] = s;
-        }
-        K[i * ld + i] += kMuIr;                                                 // :21
+    }
+    // A^T A + mu I (:20-21): one entry per thread and trip (m^2 entries over 256 threads; a row per thread would
+    // leave all but m of them idle), each entry summed over k in index order as before
+    for (long idx = t; idx < (long)m * m; idx += kAnyT) {
+        const int i = (int)(idx / m), j = (int)(idx % m);
+        double s = 0.0;
+        for (int k = 0; k < rows; ++k) s += At[k * ld + i] * At[k * ld + j];
+        K[i * ld + j] = (i == j) ? s + kMuIr : s;
     }
     DQQ_WG_SYNC();
     for (long idx = t; idx < (long)m * m; idx += kAnyT) At[(idx / m) * ld + idx % m] = K[(idx / m) * ld + idx % m];
