@@ -40,10 +40,12 @@ static DQQ_D void chol_inverse_wg(double* A, double* Ainv, int n, int ld, int t)
 #pragma clang fp contract(off)
     for (int k = 0; k < n; ++k) {
         double s = 0.0;
+#pragma unroll 8
         for (int j = 0; j < k; ++j) { const double v = A[k * ld + j]; s += v * v; }
         const double xk = sqrt(A[k * ld + k] - s);
         for (int i = k + 1 + t; i < n; i += kAnyT) {
             double v = 0.0;
+#pragma unroll 8
             for (int j = 0; j < k; ++j) v += A[i * ld + j] * A[k * ld + j];
             A[i * ld + k] = (A[i * ld + k] - v) / xk;
         }
@@ -55,11 +57,13 @@ static DQQ_D void chol_inverse_wg(double* A, double* Ainv, int n, int ld, int t)
         for (int i = 0; i < c; ++i) Ainv[i * ld + c] = 0.0; // L^-1 is lower triangular: exact zeros (0 - sum of 0 products)
         for (int i = c; i < n; ++i) {
             double v = (i == c) ? 1.0 : 0.0;
+#pragma unroll 8 // loads ahead of the (sequential, reference-order) chain of subtractions
             for (int j = c; j < i; ++j) v -= A[i * ld + j] * Ainv[j * ld + c];
             Ainv[i * ld + c] = v / A[i * ld + i];
         }
         for (int i = n - 1; i >= 0; --i) {
             double v = Ainv[i * ld + c];
+#pragma unroll 8
             for (int j = i + 1; j < n; ++j) v -= A[j * ld + i] * Ainv[j * ld + c];
             Ainv[i * ld + c] = v / A[i * ld + i];
         }
@@ -71,6 +75,7 @@ static DQQ_D double any_row_dot(const double* Mat, int ld, int row, const double
 {
 #pragma clang fp contract(off)
     double s = 0.0;
+#pragma unroll 8
     for (int j = 0; j < n; ++j) s += Mat[row * ld + j] * vec[j];
     return s;
 }
@@ -88,28 +93,29 @@ static DQQ_D void any_load_matrix(double* dst, int ld, const double* __restrict_
     for (long idx = t; idx < (long)n * n; idx += kAnyT) dst[(idx / n) * ld + idx % n] = src[idx];
 }
 
-static DQQ_HD long any_fwd_scratch_doubles(int n) { return 2L * n * (n | 1) + 8L * n + 8; }
+// Scratch of one workgroup, in doubles: `mat` matrices of rows x (rows|1) + a vector block.  The two matrices every
+// O(n^3) loop runs on (forward: A, Ainv; backward: A^T, K^-1) go to LDS when they fit (kAnyLdsBytes); the rest
+// (backward: K; all vectors) is always a slice of global memory.
+constexpr size_t kAnyLdsBytes = 152 * 1024;
 static DQQ_HD int any_bwd_rows(int kind, int n) { return kind == 0 ? n : (kind == 2 ? 3 * n : n + n / 2); }
-static DQQ_HD long any_bwd_scratch_doubles(int kind, int n)
-{
-    const long m = any_bwd_rows(kind, n);
-    return 3L * m * (m | 1) + 16L * m + 8L * n + 16;
-}
+static DQQ_HD long any_mat_doubles(int rows) { return (long)rows * (rows | 1); }
+static DQQ_HD long any_fwd_vec_doubles(int n) { return 8L * n + 8; }
+static DQQ_HD long any_bwd_vec_doubles(int kind, int n) { return 16L * any_bwd_rows(kind, n) + 8L * n + 16; }
 
-// One problem, forward, by one workgroup.  scr: any_fwd_scratch_doubles(n) doubles of global memory; red: LDS.
+// One problem, forward, by one workgroup.  red: kAnyT doubles of LDS.
 template <int KIND>
 static DQQ_D void any_fwd_problem(const double* __restrict__ P, const double* __restrict__ q,
                                   const double* __restrict__ l_n, const double* __restrict__ mu_c,
                                   const double* __restrict__ v_sign, double* __restrict__ x, int* __restrict__ iters,
-                                  long prob, int n, double eps, double mu, int max_iter, int adaptive, double* scr,
-                                  double* red, int t)
+                                  long prob, int n, double eps, double mu, int max_iter, int adaptive, double* A,
+                                  double* Ainv, double* vec, double* red, int t)
 {
+    // A: P + shift (lower) -> its Cholesky factor, Ainv: the explicit inverse (n x (n|1) doubles each: LDS when they
+    // fit, global memory otherwise); vec: 8n doubles of global memory
 #pragma clang fp contract(off)
     constexpr bool QP_LIKE = (KIND != 1);
     const int ld = n | 1;
-    double* A = scr;                // P + shift (lower) -> its Cholesky factor
-    double* Ainv = A + (long)n * ld;
-    double* va = Ainv + (long)n * ld; // broadcast buffers
+    double* va = vec;               // broadcast buffers
     double* vb = va + n;
     double* vqp = vb + n;           // ADMM state, one entry per coordinate
     double* vl2 = vqp + n;
@@ -259,6 +265,7 @@ static DQQ_D void any_ir(double* At, double* K, double* Kinv, const double* dd, 
     for (long idx = t; idx < (long)m * m; idx += kAnyT) {
         const int i = (int)(idx / m), j = (int)(idx % m);
         double s = 0.0;
+#pragma unroll 8
         for (int k = 0; k < rows; ++k) s += At[k * ld + i] * At[k * ld + j];
         K[i * ld + j] = (i == j) ? s + kMuIr : s;
     }
@@ -289,7 +296,7 @@ static DQQ_D void any_ir(double* At, double* K, double* Kinv, const double* dd, 
 }
 
 // One problem, backward, by one workgroup: QP (KIND 0), QCQP (1), box QP (2; l_n = l_min, mu_c = l_max,
-// grad_l_n = grad_l_min, grad_mu = grad_l_max).  scr: any_bwd_scratch_doubles(KIND, n).
+// grad_l_n = grad_l_min, grad_mu = grad_l_max).
 template <int KIND>
 static DQQ_D void any_bwd_problem(const double* __restrict__ P, const double* __restrict__ q,
                                   const double* __restrict__ l_n, const double* __restrict__ mu_c,
@@ -297,16 +304,15 @@ static DQQ_D void any_bwd_problem(const double* __restrict__ P, const double* __
                                   double* __restrict__ grad_P, double* __restrict__ grad_q, double* __restrict__ grad_l_n,
                                   double* __restrict__ grad_mu, double* __restrict__ gamma_out,
                                   double* __restrict__ dgamma_out, int* __restrict__ ir_steps, long prob, int n,
-                                  double dual_eps, double* scr, int t)
+                                  double dual_eps, double* At, double* K, double* Kinv, double* vec, int t)
 {
+    // At, Kinv: LDS when they fit, else global; K (holds P, row stride ld, while a system is assembled) and vec
+    // (any_bwd_vec_doubles) in global memory
 #pragma clang fp contract(off)
     const int nc = n / 2;
     const int mmax = any_bwd_rows(KIND, n);
     const int ld = mmax | 1;
-    double* At = scr;
-    double* K = At + (long)mmax * ld;      // holds P (row stride ld) while a system is assembled
-    double* Kinv = K + (long)mmax * ld;
-    double* vdd = Kinv + (long)mmax * ld;  // mmax: right-hand side
+    double* vdd = vec;                     // mmax: right-hand side
     double* vAb = vdd + mmax;
     double* vKAb = vAb + mmax;
     double* xs = vKAb + mmax;

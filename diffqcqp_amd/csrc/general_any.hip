@@ -1,14 +1,17 @@
 // general_any.hip -- the general (dense P) kernels without a size limit: one 256-thread workgroup per problem,
 // matrices in a per-workgroup slice of global memory (any_core.h).  Takes every N the register / LDS kernels do
 // not hold (forward and QP backward N > 64, QCQP backward N > 42, box QP backward N > 21) in the reference's
-// operation order.  The scratch slices come from the stream-ordered allocator (hipMallocAsync / hipFreeAsync on
+// operation order.  The two matrices of the O(n^3) loops are staged in LDS while they fit (forward N <= 98, systems
+// of up to 98 unknowns in the backward: QCQP N <= 64, box N <= 32).  The scratch slices come from the stream-ordered allocator (hipMallocAsync / hipFreeAsync on
 // the caller's stream: no synchronisation, and the only entry points that allocate).
 #include "any_core.h"
 #include "launch.h"
 
 namespace dqq {
 
-template <int KIND>
+// LDS = true: the two matrices of the O(n^3) loops live in dynamic LDS (one workgroup's worth: up to 152 KiB, one
+// workgroup per CU at the largest sizes), everything else in the global slice.
+template <int KIND, bool LDS>
 __global__ __launch_bounds__(kAnyT) void fwd_any_kernel(const double* __restrict__ P, const double* __restrict__ q,
                                                         const double* __restrict__ l_n, const double* __restrict__ mu_c,
                                                         const double* __restrict__ v_sign, double* __restrict__ x, long B,
@@ -16,18 +19,24 @@ __global__ __launch_bounds__(kAnyT) void fwd_any_kernel(const double* __restrict
                                                         int* __restrict__ iters, int* __restrict__ ws, int use_worklist,
                                                         double* __restrict__ scratch, long scratch_stride)
 {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double red[kAnyT];
     const int t = threadIdx.x;
     double* scr = scratch + (long)blockIdx.x * scratch_stride;
+    const long mat = any_mat_doubles(n);
+    double* A = LDS ? smem : scr;
+    double* Ainv = LDS ? smem + mat : scr + mat;
+    double* vec = LDS ? scr : scr + 2 * mat;
     const long count = use_worklist ? (long)ws[kWsCount] : B;
     for (long w = blockIdx.x; w < count; w += gridDim.x) {
         const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
-        any_fwd_problem<KIND>(P, q, l_n, mu_c, v_sign, x, iters, prob, n, eps, mu, max_iter, adaptive, scr, red, t);
+        any_fwd_problem<KIND>(P, q, l_n, mu_c, v_sign, x, iters, prob, n, eps, mu, max_iter, adaptive, A, Ainv, vec, red,
+                              t);
     }
     if (use_worklist && t == 0) worklist_release(ws, count, (int)gridDim.x);
 }
 
-template <int KIND>
+template <int KIND, bool LDS>
 __global__ __launch_bounds__(kAnyT) void bwd_any_kernel(
     const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ l_n,
     const double* __restrict__ mu_c, const double* __restrict__ x, const double* __restrict__ grad_x,
@@ -36,13 +45,19 @@ __global__ __launch_bounds__(kAnyT) void bwd_any_kernel(
     double dual_eps, int* __restrict__ ir_steps, int* __restrict__ ws, int use_worklist, double* __restrict__ scratch,
     long scratch_stride)
 {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
     const int t = threadIdx.x;
     double* scr = scratch + (long)blockIdx.x * scratch_stride;
+    const long mat = any_mat_doubles(any_bwd_rows(KIND, n));
+    double* K = scr;
+    double* At = LDS ? smem : scr + mat;
+    double* Kinv = LDS ? smem + mat : scr + 2 * mat;
+    double* vec = LDS ? scr + mat : scr + 3 * mat;
     const long count = use_worklist ? (long)ws[kWsCount] : B;
     for (long w = blockIdx.x; w < count; w += gridDim.x) {
         const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
         any_bwd_problem<KIND>(P, q, l_n, mu_c, x, grad_x, grad_P, grad_q, grad_l_n, grad_mu, gamma_out, dgamma_out,
-                              ir_steps, prob, n, dual_eps, scr, t);
+                              ir_steps, prob, n, dual_eps, At, K, Kinv, vec, t);
     }
     if (use_worklist && t == 0) worklist_release(ws, count, (int)gridDim.x);
 }
@@ -57,18 +72,35 @@ static unsigned any_grid(long B, bool use_worklist, long stride)
     return use_worklist ? (unsigned)cap : (unsigned)(B < cap ? (B > 0 ? B : 1) : cap);
 }
 
-template <int KIND>
-static hipError_t launch_fwd_any_kind(const FwdArgs& a, bool use_worklist, hipStream_t s)
+template <typename Kern, typename... Args>
+static hipError_t launch_any(Kern kernel, size_t lds_bytes, long stride, long B, bool use_worklist, hipStream_t s,
+                             Args... args)
 {
-    const long stride = (any_fwd_scratch_doubles(a.N) + 1) & ~1L;
-    const unsigned grid = any_grid(a.B, use_worklist, stride);
+    const unsigned grid = any_grid(B, use_worklist, stride);
+    if (lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
     double* scratch = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(double) * (size_t)stride * grid, s);
     if (e != hipSuccess) return e;
-    e = launch(fwd_any_kernel<KIND>, dim3(grid), dim3(kAnyT), 0, s, a.P, a.q, a.l_n, a.mu, a.v, a.x, a.B, a.N, a.eps,
-               a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0, scratch, stride);
+    e = launch(kernel, dim3(grid), dim3(kAnyT), lds_bytes, s, args..., scratch, stride);
     const hipError_t f = hipFreeAsync(scratch, s);
     return e != hipSuccess ? e : f;
+}
+
+template <int KIND>
+static hipError_t launch_fwd_any_kind(const FwdArgs& a, bool use_worklist, hipStream_t s)
+{
+    const long mat = any_mat_doubles(a.N), vec = any_fwd_vec_doubles(a.N);
+    const size_t lds = sizeof(double) * 2 * (size_t)mat;
+    const int wl = use_worklist ? 1 : 0;
+    if (lds <= kAnyLdsBytes)
+        return launch_any(fwd_any_kernel<KIND, true>, lds, (vec + 1) & ~1L, a.B, use_worklist, s, a.P, a.q, a.l_n, a.mu,
+                          a.v, a.x, a.B, a.N, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, wl);
+    return launch_any(fwd_any_kernel<KIND, false>, 0, (2 * mat + vec + 1) & ~1L, a.B, use_worklist, s, a.P, a.q, a.l_n,
+                      a.mu, a.v, a.x, a.B, a.N, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, wl);
 }
 
 hipError_t launch_fwd_any(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s)
@@ -86,16 +118,16 @@ hipError_t launch_fwd_any(int kind, const FwdArgs& a, bool use_worklist, hipStre
 template <int KIND>
 static hipError_t launch_bwd_any_kind(const BwdArgs& a, bool use_worklist, hipStream_t s)
 {
-    const long stride = (any_bwd_scratch_doubles(KIND, a.N) + 1) & ~1L;
-    const unsigned grid = any_grid(a.B, use_worklist, stride);
-    double* scratch = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(double) * (size_t)stride * grid, s);
-    if (e != hipSuccess) return e;
-    e = launch(bwd_any_kernel<KIND>, dim3(grid), dim3(kAnyT), 0, s, a.P, a.q, a.l_n, a.mu, a.x, a.grad_x, a.grad_P,
-               a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.N, a.epsilon, a.ir_steps, a.ws,
-               use_worklist ? 1 : 0, scratch, stride);
-    const hipError_t f = hipFreeAsync(scratch, s);
-    return e != hipSuccess ? e : f;
+    const long mat = any_mat_doubles(any_bwd_rows(KIND, a.N)), vec = any_bwd_vec_doubles(KIND, a.N);
+    const size_t lds = sizeof(double) * 2 * (size_t)mat;
+    const int wl = use_worklist ? 1 : 0;
+    if (lds <= kAnyLdsBytes)
+        return launch_any(bwd_any_kernel<KIND, true>, lds, (mat + vec + 1) & ~1L, a.B, use_worklist, s, a.P, a.q, a.l_n,
+                          a.mu, a.x, a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.N,
+                          a.epsilon, a.ir_steps, a.ws, wl);
+    return launch_any(bwd_any_kernel<KIND, false>, 0, (3 * mat + vec + 1) & ~1L, a.B, use_worklist, s, a.P, a.q, a.l_n,
+                      a.mu, a.x, a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.N,
+                      a.epsilon, a.ir_steps, a.ws, wl);
 }
 
 hipError_t launch_bwd_any(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)
