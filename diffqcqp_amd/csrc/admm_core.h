@@ -21,7 +21,9 @@
 // u*(1/rho) instead of u/rho;
 // compiler FMA contraction; group (tree) sums when LPP > 1; 1-ulp reciprocal /
 // reciprocal-square-root (common.h fast_rcp / fast_rsqrt) in place of IEEE divide
-// and sqrt in the power iteration, the disk projection and the rho updates; the QCQP's
+// and sqrt in the power iteration, the disk projection and the rho updates (the E
+// reciprocals of a rho update from one reciprocal of their product, 1/rho and
+// 1/tau carried along by products: ~3 roundings instead of 1); the QCQP's
 // primal stop test compared in squared form (no square root).
 // Failure signalling: the reference's LLT of a non-positive shifted diagonal
 // yields NaNs (Solver.cpp:76, never checked); here a non-positive M or a
@@ -40,6 +42,30 @@ namespace dqq {
 // signs (KIND 2, 3; may be null otherwise).
 // valid = false: the lane only keeps the wave's control flow company.
 // Returns the number of ADMM iterations executed (Solver.cpp:79 / :538 loop).
+// Reciprocals of E positive numbers from ONE reciprocal (of their product) and 3(E-1) multiplications: 14 instead
+// of 20 instructions at E = 4.  Each result carries ~3 roundings instead of 1.  A product that leaves the double
+// range (entries beyond ~1e75) or a non-positive factor falls back to one reciprocal per entry.
+template <int E>
+DQQ_HD void rcp_all(const double (&m)[E], double (&inv)[E])
+{
+    double pre[E];
+    pre[0] = m[0];
+#pragma unroll
+    for (int e = 1; e < E; ++e) pre[e] = pre[e - 1] * m[e];
+    if (pre[E - 1] > 1e-280 && pre[E - 1] < 1e280) {
+        double r = fast_rcp(pre[E - 1]);
+#pragma unroll
+        for (int e = E - 1; e > 0; --e) {
+            inv[e] = r * pre[e - 1];
+            r = r * m[e];
+        }
+        inv[0] = r;
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) inv[e] = fast_rcp(m[e]);
+    }
+}
+
 template <int KIND, int E, class G>
 DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const double* rad, int n, double eps,
                          double mu, int max_iter, int adaptive, bool valid, double (&x)[E],
@@ -103,11 +129,11 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
     for (int e = 0; e < E; ++e) {
         M[e] = p[e] + (rho + mu);
         bad = bad || !(M[e] > 0.0);   // (also catches a NaN entry, which fmin above would drop)
-        Minv[e] = fast_rcp(M[e]);
         qp[e] = q[e];
         l2[e] = 0.0;
         u[e] = 0.0;
     }
+    rcp_all<E>(M, Minv);
 
     // A per-lane loop: a lane leaves it when its problem stops (all lanes of a problem decide alike: the group
     // reductions are symmetric) and keeps its state in place under the execution mask -- as a wave-uniform loop
@@ -204,19 +230,19 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
                         else if (inc) tau_inc = ti;                           // :554-556
                         else tau_dec = td;                                    // :568-570
                     }
-                    const double f = inc ? tau_inc : fast_rcp(tau_dec);       // rho *= tau_inc | rho /= tau_dec
+                    // one reciprocal per update, of the factor in use: rho and 1/rho move by reciprocal factors
+                    const double tau = inc ? tau_inc : tau_dec, inv_tau = fast_rcp(tau);
+                    const double f = inc ? tau : inv_tau;                     // rho *= tau_inc | rho /= tau_dec
                     const double delta = rho * (f - 1);                       // :98 / :112
                     rho = rho * f;                                            // :99 / :113
                     rho_up = inc ? 1 : -1;
-                    inv_rho = fast_rcp(rho);
+                    inv_rho = inv_rho * (inc ? inv_tau : tau);
                     // llt() + solveInPlace(Identity) of the shifted matrix, diagonal case (:100-101)
                     Mmin += delta;
                     bad = bad || !(Mmin > 0.0);
 #pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        M[e] += delta;
-                        Minv[e] = fast_rcp(M[e]);
-                    }
+                    for (int e = 0; e < E; ++e) M[e] += delta;
+                    rcp_all<E>(M, Minv);
                 }
             }
         }
