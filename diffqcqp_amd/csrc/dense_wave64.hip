@@ -24,64 +24,79 @@
 
 namespace dqq {
 
-// G <- tile layout of A^T for the row-major 64 x 64 matrix A: G[ti][tj][r] of lane (g,n) = A[16tj+n][16ti+4r+g],
-// so that WaveTile64::matvec returns A x (no symmetry assumed).
-static DQQ_D void load_tiles_transposed(v4d (&G)[4][4], const double* __restrict__ A, int lane)
+// The forward kernel takes any N <= 64: the matrix is embedded in (16 NT) x (16 NT), NT = ceil(N / 16), padded with
+// the identity (PAD): the padded coordinates decouple (their rows of the inverse are unit vectors), their vector
+// entries are zero from start to end, and sums / maxima over the wave are unaffected.
+
+// G <- tile layout of A^T for the row-major n x n matrix A: G[ti][tj][r] of lane (g,l) = A[16tj+l][16ti+4r+g],
+// so that WaveTile::matvec returns A x (no symmetry assumed).
+template <int NT, bool PAD>
+static DQQ_D void load_tiles_transposed(v4d (&G)[NT][NT], const double* __restrict__ A, int n, int lane)
 {
-    // addressing: uniform base (SGPRs, advanced per tile) + one 32-bit per-lane offset for all 64 loads -- as a
+    // addressing: uniform base (SGPRs, advanced per tile) + one 32-bit per-lane offset for all loads -- as a
     // per-lane 64-bit pointer plus constants the compiler keeps dozens of address pairs alive and spills them
-    const unsigned lo = (lane & 15) * 64 + (lane >> 4);
+    const int g = lane >> 4, l = lane & 15;
+    const unsigned lo = l * n + g;
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
+    for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
+        for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) G[ti][tj][r] = (A + ((16 * tj) * 64 + 16 * ti + 4 * r))[lo];
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * tj + l, col = 16 * ti + 4 * r + g;
+                if (!PAD || (row < n && col < n)) G[ti][tj][r] = (A + ((16 * tj) * n + 16 * ti + 4 * r))[lo];
+                else G[ti][tj][r] = (row == col) ? 1.0 : 0.0;
+            }
 }
 
 // G <- tile layout of the symmetric matrix whose lower triangle is A's (what LLT reads, Solver.cpp:76):
 // S[a][b] = A[max(a,b)][min(a,b)].  Off-diagonal tiles are statically one side or the other; inside the diagonal
 // tiles the side depends on the lane.
-static DQQ_D void load_tiles_lower_symmetric(v4d (&G)[4][4], const double* __restrict__ A, int lane)
+template <int NT, bool PAD>
+static DQQ_D void load_tiles_lower_symmetric(v4d (&G)[NT][NT], const double* __restrict__ A, int n, int lane)
 {
-    const int g = lane >> 4, n = lane & 15;
-    const unsigned rowmajor = g * 64 + n;   // + (16ti + 4r) * 64 + 16tj : A[16ti+4r+g][16tj+n]
-    const unsigned colmajor = n * 64 + g;   // + (16tj) * 64 + 16ti + 4r : A[16tj+n][16ti+4r+g]
+    const int g = lane >> 4, l = lane & 15;
+    const unsigned rowmajor = g * n + l;   // + (16ti + 4r) * n + 16tj : A[16ti+4r+g][16tj+l]
+    const unsigned colmajor = l * n + g;   // + (16tj) * n + 16ti + 4r : A[16tj+l][16ti+4r+g]
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
+    for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
+        for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int o_row = (16 * ti + 4 * r) * 64 + 16 * tj, o_col = (16 * tj) * 64 + 16 * ti + 4 * r;
-                if (ti > tj) G[ti][tj][r] = (A + o_row)[rowmajor];
-                else if (ti < tj) G[ti][tj][r] = (A + o_col)[colmajor];
-                else G[ti][tj][r] = (A + o_row)[(4 * r + g >= n) ? rowmajor : colmajor + (unsigned)(o_col - o_row)];
+                const int a = 16 * ti + 4 * r + g, b = 16 * tj + l;
+                const int o_row = (16 * ti + 4 * r) * n + 16 * tj, o_col = (16 * tj) * n + 16 * ti + 4 * r;
+                double v;
+                if (PAD && !(a < n && b < n)) v = (a == b) ? 1.0 : 0.0;
+                else if (ti > tj) v = (A + o_row)[rowmajor];
+                else if (ti < tj) v = (A + o_col)[colmajor];
+                else v = (A + o_row)[(4 * r + g >= l) ? rowmajor : colmajor + (unsigned)(o_col - o_row)];
+                G[ti][tj][r] = v;
             }
 }
 
-// Diagonal of the matrix <- d (one element per lane: lane l = entry l).  In tile (t,t) lane (g,n) holds the diagonal
-// entry 16t+n in register n >> 2 iff (n & 3) == g.
-static DQQ_D void set_tile_diagonal(v4d (&G)[4][4], double d, int lane)
+// Diagonal of the matrix <- d (one element per lane: lane l = entry l).  In tile (t,t) lane (g,l) holds the diagonal
+// entry 16t+l in register l >> 2 iff (l & 3) == g.
+template <int NT>
+static DQQ_D void set_tile_diagonal(v4d (&G)[NT][NT], double d, int lane)
 {
-    const int g = lane >> 4, n = lane & 15;
-    const bool on_diag = (n & 3) == g;
+    const int g = lane >> 4, l = lane & 15;
+    const bool on_diag = (l & 3) == g;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const double dt = lane_gather(d, 16 * t + n);
+    for (int t = 0; t < NT; ++t) {
+        const double dt = lane_gather(d, 16 * t + l);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) G[t][t][r] = (on_diag && (n >> 2) == r) ? dt : G[t][t][r];
+        for (int r = 0; r < 4; ++r) G[t][t][r] = (on_diag && (l >> 2) == r) ? dt : G[t][t][r];
     }
 }
 
-template <int KIND>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void fwd_dense_wave64_kernel(
+template <int KIND, int NT, bool PAD>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT == 4 ? 2 : (NT == 3 ? 3 : 4)))) void fwd_dense_wave64_kernel(
     const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ l_n,
-    const double* __restrict__ mu_c, const double* __restrict__ v_sign, double* __restrict__ x, long B, double eps,
+    const double* __restrict__ mu_c, const double* __restrict__ v_sign, double* __restrict__ x, long B, int N, double eps,
     double mu, int max_iter, int adaptive, int* __restrict__ iters, int* __restrict__ ws, int use_worklist)
 {
-    // KIND 2 / 3 (box / signed box QP): l_n = l_min, mu_c = l_max per coordinate
-    constexpr int N = 64;
+    // KIND 2 / 3 (box / signed box QP): l_n = l_min, mu_c = l_max per coordinate.  PAD: N < 16 NT.
     constexpr bool QP_LIKE = (KIND != 1);
     const long count = use_worklist ? (long)ws[kWsCount] : B;
 
@@ -101,10 +116,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // wave-uniform by construction; readfirstlane tells the compiler so (P's addressing then uses an SGPR base)
         const long prob = __builtin_amdgcn_readfirstlane(use_worklist ? ws[kWsEntries + w] : (int)w);
         const double* Pg = P + prob * (long)(N * N);
-        WaveTile64 W;
+        // lanes >= N hold no coordinate (NT < 4) or a padded one (PAD): all their vector entries stay zero
+        const bool live = (NT == 4 && !PAD) || lane < N;
+        WaveTile<NT> W;
         // ---- power_iteration, Solver.cpp:46-59 (the normalisation by a 1-ulp reciprocal square root)
-        load_tiles_transposed(W.G, Pg, lane);
-        double v = 0.125; // 1/sqrt(64); already of unit norm
+        load_tiles_transposed<NT, PAD>(W.G, Pg, N, lane);
+        double v = live ? 1.0 / sqrt((double)N) : 0.0; // of unit norm up to rounding
+        {
+            const double s = wave_sum64(v * v);
+            v = s > 0 ? v * fast_rsqrt(s) : v;
+        }
         const int pi_steps = QP_LIKE ? 10 : 100;
         for (int k = 0; k < pi_steps; ++k) {
             const double Av = W.matvec(v, xsrc);
@@ -115,14 +136,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         RhoSchedule sched;
         sched.init(Lmax, mu);                                    // :72-73 / :531-532
         double rho = sched.rho;
-        double mdiag = Pg[lane * (N + 1)] + (rho + mu);          // accumulated shifted diagonal, :75
+        double mdiag = live ? Pg[lane * (N + 1)] + (rho + mu) : 1.0; // accumulated shifted diagonal, :75
         bool bad = false;
 
-        const double qi = q[prob * N + lane];
+        const double qi = live ? q[prob * N + lane] : 0.0;
         double rad = 0.0;
-        if (KIND == 1) rad = l_n[prob * (N / 2) + lane / 2] * mu_c[prob * (N / 2) + lane / 2];
+        if (KIND == 1) rad = live ? l_n[prob * (N / 2) + lane / 2] * mu_c[prob * (N / 2) + lane / 2] : 0.0;
         double blo = 0.0, bhi = 0.0, bsg = 0.0;
-        if (KIND >= 2) {
+        if (KIND >= 2 && live) {
             blo = l_n[prob * N + lane];
             bhi = mu_c[prob * N + lane];
             if (KIND == 3) { const double vv = v_sign[prob * N + lane]; bsg = (double)((vv > 0) - (vv < 0)); } // :395
@@ -133,9 +154,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         double inv_rho = 1.0 / rho;
         for (int it = 0; it < max_iter; ++it) {
             if (need_refactor) { // llt() + solveInPlace(Identity) of P + shift, Solver.cpp:76-77: W.G <- -(P + shift)^-1
-                load_tiles_lower_symmetric(W.G, Pg, lane);
-                set_tile_diagonal(W.G, mdiag, lane);
-                block_sweep_inverse(W.G, lane, bad);
+                load_tiles_lower_symmetric<NT, PAD>(W.G, Pg, N, lane);
+                set_tile_diagonal<NT>(W.G, mdiag, lane);
+                block_sweep_inverse<NT>(W.G, lane, bad);
                 need_refactor = false;
                 inv_rho = 1.0 / rho;
             }
@@ -173,42 +194,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (adaptive) {
                 double delta = 0.0;
                 if (sched.template update<QP_LIKE, false>(res_prim, res_dual, delta)) { // :90-120 / :550-580
-                    mdiag += delta;
+                    mdiag += live ? delta : 0.0;
                     rho = sched.rho;
                     need_refactor = true;
                 }
             }
         }
         const bool failed = bad || !(rho > 0.0) || !(rho < 1.79e308);
-        x[prob * N + lane] = failed ? NAN : l2;
+        if (live) x[prob * N + lane] = failed ? NAN : l2;
         if (iters != nullptr && lane == 0) iters[prob] = it_done;
     }
     // last wave out re-zeroes the work-list header (nothing to do when the list was empty)
     if (use_worklist && threadIdx.x == 0) worklist_release(ws, count, (int)gridDim.x);
 }
 
-template <int KIND>
+template <int KIND, int NT, bool PAD>
 static hipError_t launch_wave64(const FwdArgs& a, bool use_worklist, hipStream_t s)
 {
     // one wave per problem, dispatched by the hardware as waves retire (iteration counts differ per problem);
-    // work-list mode: a fixed grid of 8 waves per CU strides over the list
+    // work-list mode: a fixed grid of 8 waves per CU claims the entries one at a time
     const long cap = 1L << 22;
     const unsigned grid = use_worklist ? 2048u : (unsigned)(a.B < cap ? a.B : cap);
-    return launch(fwd_dense_wave64_kernel<KIND>, dim3(grid), dim3(64), 0, s, a.P, a.q, a.l_n, a.mu, a.v, a.x, a.B,
-                       a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0);
+    return launch(fwd_dense_wave64_kernel<KIND, NT, PAD>, dim3(grid), dim3(64), 0, s, a.P, a.q, a.l_n, a.mu, a.v, a.x, a.B,
+                  a.N, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0);
 }
 
-bool fwd_dense_wave64_supported(int N) { return N == 64; }
+template <int KIND>
+static hipError_t launch_wave64_kind(const FwdArgs& a, bool use_worklist, hipStream_t s)
+{
+    if (a.N == 64) return launch_wave64<KIND, 4, false>(a, use_worklist, s);
+    if (a.N > 48) return launch_wave64<KIND, 4, true>(a, use_worklist, s);
+    if (a.N == 48) return launch_wave64<KIND, 3, false>(a, use_worklist, s);
+    if (a.N > 32) return launch_wave64<KIND, 3, true>(a, use_worklist, s);
+    if (a.N == 32) return launch_wave64<KIND, 2, false>(a, use_worklist, s);
+    return launch_wave64<KIND, 2, true>(a, use_worklist, s);
+}
+
+// every 16 < N <= 64 (N <= 16: the lane / team kernels hold the whole problem per lane or per 16 lanes)
+bool fwd_dense_wave64_supported(int N) { return N > 16 && N <= 64; }
 
 hipError_t launch_fwd_dense_wave64(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
-    if (a.N != 64) return hipErrorInvalidValue;
+    if (!fwd_dense_wave64_supported(a.N)) return hipErrorInvalidValue;
     switch (kind) {
-    case 0: return launch_wave64<0>(a, use_worklist, s);
-    case 1: return launch_wave64<1>(a, use_worklist, s);
-    case 2: return launch_wave64<2>(a, use_worklist, s);
-    case 3: return launch_wave64<3>(a, use_worklist, s);
+    case 0: return launch_wave64_kind<0>(a, use_worklist, s);
+    case 1: return launch_wave64_kind<1>(a, use_worklist, s);
+    case 2: return launch_wave64_kind<2>(a, use_worklist, s);
+    case 3: return launch_wave64_kind<3>(a, use_worklist, s);
     default: return hipErrorInvalidValue;
     }
 }
@@ -293,7 +326,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         double* Ks = grad_P + prob * (long)(N * N);   // scratch for K until the gradient is written
         const double xi = x[prob * N + lane], gi = grad_x[prob * N + lane], qi = q[prob * N + lane];
         WaveTile64 W;
-        load_tiles_transposed(W.G, Pg, lane);         // W.G[tk][ta][r] of lane (g,n) = P[16ta+n][16tk+4r+g]
+        load_tiles_transposed<4, false>(W.G, Pg, 64, lane); // W.G[tk][ta][r] of lane (g,n) = P[16ta+n][16tk+4r+g]
         // dualFromPrimalQP, Solver.cpp:125-134, and the active set of solveDerivativesQP, :139-147
         double gamma = -(W.matvec(xi, xsrc) + qi);
         if (xi > dual_eps) gamma = 0;
@@ -325,7 +358,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
                 for (int r = 0; r < 4; ++r) W.G[ti][tj][r] = (Ks + ((ti * 4 + tj) * 4 + r) * 64)[lane];
         bool bad = false;
-        block_sweep_inverse(W.G, lane, bad);                                  // :22-23; W.G = -K^-1
+        block_sweep_inverse<4>(W.G, lane, bad);                               // :22-23; W.G = -K^-1
         const double KinvAb = -W.matvec(Ab, xsrc);                            // :27
         double xs = 0.0;
         IrControl ctl;

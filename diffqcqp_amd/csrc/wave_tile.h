@@ -1,4 +1,4 @@
-// wave_tile.h -- one wave64 owns one 64 x 64 symmetric matrix entirely in registers (gfx950).
+// wave_tile.h -- one wave64 owns one symmetric matrix of up to 64 x 64 entirely in registers (gfx950).
 //
 // Storage ("tile layout"): the matrix is cut into 4 x 4 tiles of 16 x 16; tile (ti,tj) is a v4d per lane in
 // the accumulator layout of v_mfma_f64_16x16x4_f64:
@@ -20,16 +20,7 @@
 
 namespace dqq {
 
-// acc += (lane BC of this lane's 16-lane row of x) * m      (v_fmac_f64 with a DPP row_newbcast source)
-#define DQQ_FMAC_BCAST_ROW(TI, R)                                                                              \
-    asm("v_fmac_f64_dpp %0, %4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                              \
-        "v_fmac_f64_dpp %1, %4, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                              \
-        "v_fmac_f64_dpp %2, %4, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                              \
-        "v_fmac_f64_dpp %3, %4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"                                  \
-        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)                                                                \
-        : "v"(x0), "v"(G[TI][0][R]), "v"(G[TI][1][R]), "v"(G[TI][2][R]), "v"(G[TI][3][R]), "n"(4 * TI + R))
-
-// the same for one tile-row T[0..3] streamed from memory: acc[tj] += T[tj][R] * (lane BC of the row of x0)
+// one tile-row T[0..3] streamed from memory: acc[tj] += T[tj][R] * (lane BC of the 16-lane row of x0)
 #define DQQ_FMAC_BCAST_TROW(T, R, BC)                                                                          \
     asm("v_fmac_f64_dpp %0, %4, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                              \
         "v_fmac_f64_dpp %1, %4, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"                              \
@@ -89,30 +80,48 @@ DQQ_D void wave_max2_abs(double a, double b, double& ma, double& mb)
     mb = max_raw(lane_bcast(m, 32), lane_bcast(m, 48));
 }
 
-struct WaveTile64 {
-    v4d G[4][4];
+// acc += (lane BC of this lane's 16-lane row of x0) * m
+template <int BC>
+DQQ_D void fmac_bcast(double& acc, double x0, double m)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x0), "v"(m), "n"(BC));
+}
+
+template <int NT, int I>
+struct MatvecRows { // rows I, I+1, ... of the 4 NT broadcast steps (BC = I = 4 ti + r), unrolled at compile time
+    static DQQ_D void run(const v4d (&G)[NT][NT], double x0, double (&acc)[4])
+    {
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) fmac_bcast<I>(acc[tj], x0, G[I / 4][tj][I % 4]);
+        if constexpr (I + 1 < 4 * NT) MatvecRows<NT, I + 1>::run(G, x0, acc);
+    }
+};
+
+// The matrix of one problem: (16 NT) x (16 NT), NT x NT tiles.  NT = 4 is the 64 x 64 case; smaller NT leave the
+// lanes >= 16 NT of every vector idle (they hold zeros).
+template <int NT>
+struct WaveTile {
+    v4d G[NT][NT];
 
     // y = S x for the symmetric S held in G (or y = A x when G holds the tile layout of A^T); x, y one
     // element per lane.  xsrc = 4 (lane & 15) + (lane >> 4).
     DQQ_D double matvec(double x, int xsrc) const
     {
         const double x0 = dpp_source(lane_gather(x, xsrc)); // lane (g, n') <- x[4 n' + g]
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        DQQ_FMAC_BCAST_ROW(0, 0); DQQ_FMAC_BCAST_ROW(0, 1); DQQ_FMAC_BCAST_ROW(0, 2); DQQ_FMAC_BCAST_ROW(0, 3);
-        DQQ_FMAC_BCAST_ROW(1, 0); DQQ_FMAC_BCAST_ROW(1, 1); DQQ_FMAC_BCAST_ROW(1, 2); DQQ_FMAC_BCAST_ROW(1, 3);
-        DQQ_FMAC_BCAST_ROW(2, 0); DQQ_FMAC_BCAST_ROW(2, 1); DQQ_FMAC_BCAST_ROW(2, 2); DQQ_FMAC_BCAST_ROW(2, 3);
-        DQQ_FMAC_BCAST_ROW(3, 0); DQQ_FMAC_BCAST_ROW(3, 1); DQQ_FMAC_BCAST_ROW(3, 2); DQQ_FMAC_BCAST_ROW(3, 3);
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        MatvecRows<NT, 0>::run(G, x0, a);
         // a[tj] of lane (g,n) = partial sum of y[16 tj + n] over the columns = g (mod 4): reduce over g,
-        // scattering tj = g
+        // scattering tj = g (accumulators beyond NT are zero)
         double p, q2, s02, s13, e, o;
-        swap32(a0, a2, p, q2);
+        swap32(a[0], a[2], p, q2);
         s02 = p + q2; // rows 0,1: a0 summed over {g, g+2}; rows 2,3: a2
-        swap32(a1, a3, p, q2);
+        swap32(a[1], a[3], p, q2);
         s13 = p + q2;
         swap16(s02, s13, e, o);
         return e + o;
     }
 };
+using WaveTile64 = WaveTile<4>;
 
 // The same mat-vec with the matrix streamed one tile-row at a time (T[tj] = tiles (TK, tj) of the layout):
 //     MatvecStream mv; mv.begin(x, xsrc); for TK: mv.add_row<TK>(T); y = mv.finish();
@@ -252,38 +261,39 @@ DQQ_D v4d tile_xty(v4d acc, const v4d& X, const v4d& Y)
 // In place: G (symmetric positive definite, tile layout) -> -G^-1, by four block sweeps:
 //   D = G_KK^-1;  B_J = D G_KJ;  G_IJ -= G_KI^T B_J (I, J != K);  G_JK = G_KJ^T D;  G_KJ = B_J;  G_KK = -D
 // Every product is an X^T Y (the matrix stays symmetric), 60 tile products = 240 MFMAs in all.
-template <int K>
-DQQ_D void block_sweep_step(v4d (&G)[4][4], int lane, bool& bad)
+template <int NT, int K>
+DQQ_D void block_sweep_step(v4d (&G)[NT][NT], int lane, bool& bad)
 {
     const v4d zero = {0.0, 0.0, 0.0, 0.0};
     const v4d D = diag16_inverse(G[K][K], lane, bad);
-    v4d Bt[4];
+    v4d Bt[NT];
 #pragma unroll
-    for (int J = 0; J < 4; ++J)
+    for (int J = 0; J < NT; ++J)
         if (J != K) Bt[J] = tile_xty(zero, D, G[K][J]);
 #pragma unroll
-    for (int I = 0; I < 4; ++I) {
+    for (int I = 0; I < NT; ++I) {
         if (I == K) continue;
         const v4d nX = -G[K][I];
 #pragma unroll
-        for (int J = 0; J < 4; ++J)
+        for (int J = 0; J < NT; ++J)
             if (J != K) G[I][J] = tile_xty(G[I][J], nX, Bt[J]);
     }
 #pragma unroll
-    for (int J = 0; J < 4; ++J)
+    for (int J = 0; J < NT; ++J)
         if (J != K) G[J][K] = tile_xty(zero, G[K][J], D);
 #pragma unroll
-    for (int J = 0; J < 4; ++J)
+    for (int J = 0; J < NT; ++J)
         if (J != K) G[K][J] = Bt[J];
     G[K][K] = -D;
 }
 
-DQQ_D void block_sweep_inverse(v4d (&G)[4][4], int lane, bool& bad)
+template <int NT>
+DQQ_D void block_sweep_inverse(v4d (&G)[NT][NT], int lane, bool& bad)
 {
-    block_sweep_step<0>(G, lane, bad);
-    block_sweep_step<1>(G, lane, bad);
-    block_sweep_step<2>(G, lane, bad);
-    block_sweep_step<3>(G, lane, bad);
+    block_sweep_step<NT, 0>(G, lane, bad);
+    if constexpr (NT > 1) block_sweep_step<NT, 1>(G, lane, bad);
+    if constexpr (NT > 2) block_sweep_step<NT, 2>(G, lane, bad);
+    if constexpr (NT > 3) block_sweep_step<NT, 3>(G, lane, bad);
 }
 
 } // namespace dqq

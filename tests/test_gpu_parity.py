@@ -389,6 +389,36 @@ def test_reference_order_backward_beyond_the_wave_kernel(oracle, ops, kind, N, B
         assert np.allclose(npy(duals[0]), ref[4], rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("kind", ["qp", "qcqp", "box", "sbox"])
+@pytest.mark.parametrize("N,B", [(18, 70), (20, 90), (24, 64), (31, 40), (32, 130), (34, 40), (40, 50), (47, 30), (48, 60),
+                                 (50, 30), (56, 40), (63, 20)])
+def test_wave_per_problem_forward_every_size(oracle, ops, kind, N, B):
+    """16 < N <= 64, dense P: one wave per problem with the matrix in registers (dense_wave64.hip), N padded with the
+    identity to the next multiple of 16.  Same trajectory as the oracle; also against the LDS wave kernel."""
+    from diffqcqp_amd import _capi
+    if kind == "qcqp" and N % 2:
+        pytest.skip("QCQP needs an even N")
+    d = make_problem(kind, B, N, 5100 + N, "dense")
+    g = dev(d)
+    if kind in ("qp", "qcqp"):
+        xo, ito = oracle_fwd(oracle, kind, d)
+        xh, ith = hip_fwd(ops, kind, g, layout=_capi.P_DENSE)
+    else:
+        xo, ito, xh, ith = _box_fwd(oracle, ops, kind, d, layout=_capi.P_DENSE)
+    check_forward(xh, ith, xo, ito, min_match=0.97)
+    _capi.set_option("dense_wave64", 0)
+    _capi.set_option("dense_block", 0)
+    try:
+        if kind in ("qp", "qcqp"):
+            xw, itw = hip_fwd(ops, kind, g, layout=_capi.P_DENSE)
+        else:
+            _, _, xw, itw = _box_fwd(oracle, ops, kind, d, layout=_capi.P_DENSE)
+    finally:
+        _capi.set_option("dense_wave64", 1)
+        _capi.set_option("dense_block", 1)
+    assert (xw - xh).abs().max() < 1e-8 and (itw == ith).float().mean() >= 0.97
+
+
 @pytest.mark.parametrize("N", [3, 5, 7])
 def test_dense_kernel_odd_n_qp(oracle, ops, N):
     d = make_problem("qp", 60, N, 600 + N, "dense")
