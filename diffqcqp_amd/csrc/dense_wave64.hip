@@ -387,12 +387,121 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (use_worklist && threadIdx.x == 0) worklist_release(ws, count, (int)gridDim.x);
 }
 
-bool bwd_dense_wave64_supported(int kind, int N) { return kind == 0 && N == 64; }
+// ---------------------------------------------------------------- backward (QP), 16 < N <= 48
+// The same composition as above for 2 x 2 and 3 x 3 tiles: here A~ (NT^2 tiles), K = A~ A~^T + mu I and a copy of K
+// for the refinement residual all fit the registers of a wave (NT = 3: 18 tiles = 144 VGPRs while K is accumulated,
+// then K^-1 + K), so nothing is parked in memory.  N is padded with the identity to 16 NT (PAD): a padded coordinate
+// is inactive with x = g = 0, its block of K is 1 + mu and its solution entry stays zero.
+template <int NT, bool PAD>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT == 3 ? 2 : 3))) void bwd_dense_wave_qp_kernel(
+    const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ x,
+    const double* __restrict__ grad_x, double* __restrict__ grad_P, double* __restrict__ grad_q, long B, int N,
+    double dual_eps, int* __restrict__ ir_steps, int* __restrict__ ws, int use_worklist)
+{
+    const long count = use_worklist ? (long)ws[kWsCount] : B;
+    for (long w = blockIdx.x;; w += gridDim.x) {
+        if (use_worklist) {
+            if (count == 0) break;
+            w = __builtin_amdgcn_readfirstlane(threadIdx.x == 0 ? atomicAdd(&ws[kWsNext], 1) : 0);
+        }
+        if (w >= count) break;
+        int lane = threadIdx.x;
+        asm volatile("" : "+v"(lane));
+        const int g = lane >> 4, n = lane & 15;
+        const int xsrc = 4 * n + g;
+        const long prob = __builtin_amdgcn_readfirstlane(use_worklist ? ws[kWsEntries + w] : (int)w);
+        const double* Pg = P + prob * (long)(N * N);
+        const bool live = lane < N;
+        const double xi = live ? x[prob * N + lane] : 0.0, gi = live ? grad_x[prob * N + lane] : 0.0;
+        const double qi = live ? q[prob * N + lane] : 0.0;
+        WaveTile<NT> A;
+        load_tiles_transposed<NT, PAD>(A.G, Pg, N, lane);                     // A.G[tk][ta][r] = P[16ta+n][16tk+4r+g]
+        // dualFromPrimalQP, Solver.cpp:125-134, and the active set of solveDerivativesQP, :139-147
+        double gamma = -(A.matvec(xi, xsrc) + qi);
+        if (xi > dual_eps) gamma = 0;
+        const bool is_act = live && gamma < -kActiveEps;
+        const unsigned long long am = __ballot(is_act);
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk) {                                     // A~ in place, :148-158
+            const double dk = lane_gather(xi, 16 * tk + n);
+#pragma unroll
+            for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool row_act = (am >> (16 * ta + n)) & 1ull, col_act = (am >> (16 * tk + 4 * r + g)) & 1ull;
+                    double t = (row_act || col_act) ? 0.0 : A.G[tk][ta][r];
+                    if (ta == tk) t = (row_act && 4 * r + g == n) ? dk : t;
+                    A.G[tk][ta][r] = t;
+                }
+        }
+        double Ab = A.matvec(is_act ? 0.0 : gi, xsrc);                        // A^T b (:19), b = [0; grad_I]
+        if (is_act) Ab = 0.0;
+        WaveTile<NT> K, Kc;                                                   // K = A~ A~^T + mu_ir I (:20-21)
+        const v4d zero = {0.0, 0.0, 0.0, 0.0};
+        const bool on_diag = (n & 3) == g;
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < NT; ++tb) {
+                v4d acc = zero;
+#pragma unroll
+                for (int tk = 0; tk < NT; ++tk) acc = tile_xty(acc, A.G[tk][ta], A.G[tk][tb]);
+                if (ta == tb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] += (on_diag && (n >> 2) == r) ? kMuIr : 0.0;
+                }
+                K.G[ta][tb] = acc;
+                Kc.G[ta][tb] = acc;
+            }
+        bool bad = false;
+        block_sweep_inverse<NT>(K.G, lane, bad);                              // :22-23; K.G = -K^-1
+        const double KinvAb = -K.matvec(Ab, xsrc);                            // :27
+        double xs = 0.0;
+        IrControl ctl;
+        ctl.init();
+        int steps = 0;
+        for (int it = 0; it < kIrMaxIter; ++it) {
+            steps = it + 1;
+            xs = KinvAb - kMuIr * K.matvec(xs, xsrc);                         // :29
+            const double d = Kc.matvec(xs, xsrc) - Ab;                        // :30
+            const double res = sqrt(wave_sum64(d * d));                       // :31
+            if (ctl.update(res)) break;                                       // :32-41
+        }
+        const double dl = bad ? NAN : (is_act ? 0.0 : xs);                    // :187-191
+        if (live && grad_q != nullptr) grad_q[prob * N + lane] = -dl;        // qcqp.py:49
+        if (grad_P != nullptr) {                                              // qcqp.py:48: -(dl l^T)
+            double* Gp = grad_P + prob * (long)(N * N);
+            for (int k = 0; k < N; ++k) {
+                const double v = -(lane_bcast(dl, k) * xi);
+                if (live) __builtin_nontemporal_store(v, Gp + k * N + lane);
+            }
+        }
+        if (ir_steps != nullptr && lane == 0) ir_steps[prob] = steps;
+    }
+    if (use_worklist && threadIdx.x == 0) worklist_release(ws, count, (int)gridDim.x);
+}
+
+template <int NT, bool PAD>
+static hipError_t launch_bwd_wave_small(const BwdArgs& a, bool use_worklist, hipStream_t s)
+{
+    const long cap = 1L << 22;
+    const unsigned grid = use_worklist ? 2048u : (unsigned)(a.B < cap ? a.B : cap);
+    return launch(bwd_dense_wave_qp_kernel<NT, PAD>, dim3(grid), dim3(64), 0, s, a.P, a.q, a.x, a.grad_x, a.grad_P, a.grad_q,
+                  a.B, a.N, a.epsilon, a.ir_steps, a.ws, use_worklist ? 1 : 0);
+}
+
+// QP backward: N = 64 (K parked in the grad_P slot: needs grad_P) and every 16 < N <= 48 (all in registers)
+bool bwd_dense_wave64_supported(int kind, int N) { return kind == 0 && (N == 64 || (N > 16 && N <= 48)); }
 
 hipError_t launch_bwd_dense_wave64(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
-    if (kind != 0 || a.N != 64 || a.grad_P == nullptr) return hipErrorInvalidValue;
+    if (!bwd_dense_wave64_supported(kind, a.N)) return hipErrorInvalidValue;
+    if (a.N == 48) return launch_bwd_wave_small<3, false>(a, use_worklist, s);
+    if (a.N > 32 && a.N < 48) return launch_bwd_wave_small<3, true>(a, use_worklist, s);
+    if (a.N == 32) return launch_bwd_wave_small<2, false>(a, use_worklist, s);
+    if (a.N < 32) return launch_bwd_wave_small<2, true>(a, use_worklist, s);
+    if (a.grad_P == nullptr) return hipErrorInvalidValue;
     const long cap = 1L << 22;
     const unsigned grid = use_worklist ? 2048u : (unsigned)(a.B < cap ? a.B : cap);
     return launch(bwd_dense_wave64_qp_kernel, dim3(grid), dim3(64), 0, s, a.P, a.q, a.x, a.grad_x, a.grad_P, a.grad_q,

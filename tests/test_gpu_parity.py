@@ -417,6 +417,14 @@ def test_wave_per_problem_forward_every_size(oracle, ops, kind, N, B):
         _capi.set_option("dense_wave64", 1)
         _capi.set_option("dense_block", 1)
     assert (xw - xh).abs().max() < 1e-8 and (itw == ith).float().mean() >= 0.97
+    if kind == "qp":
+        # QP backward: 16 < N <= 48 and N = 64 run on the same register-resident design (K on the matrix cores);
+        # same 1e-9 / identical-refinement-steps bar as the reference-order wave kernel
+        grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
+        check_backward_exact(grads, st, oracle_bwd(oracle, kind, d, xo), exact=False)
+        gq_only = ops.qp_backward(g["P"], g["q"], torch.from_numpy(xo).cuda(), g["grad_x"], need_P=False,
+                                  layout=_capi.P_DENSE)
+        assert gq_only[0] is None and torch.equal(gq_only[1], grads[1])
 
 
 @pytest.mark.parametrize("N", [3, 5, 7])

@@ -25,4 +25,10 @@ for kind, N, B in (("qp", 20, 16384), ("qp", 24, 16384), ("qp", 32, 8192), ("qcq
             f = lambda: ops.boxqp_forward(d["P"], d["q"], d["l_min"], d["l_max"], 1e-7, 1000, layout=1)
         row["fwd_ms_wave" if opt else "fwd_ms_old"] = round(timeit(f), 3)
     _capi.set_option("dense_wave64", 1)
+    if kind == "qp":
+        x = ops.qp_forward(d["P"], d["q"], 1e-7, 1000, layout=1)
+        row["bwd_ms"] = round(timeit(lambda: ops.qp_backward(d["P"], d["q"], x, d["grad_x"], layout=1)), 3)
+    elif kind == "qcqp":
+        x = ops.qcqp_forward(d["P"], d["q"], d["l_n"], d["mu"], 1e-7, 1000, layout=1)
+        row["bwd_ms"] = round(timeit(lambda: ops.qcqp_backward(d["P"], d["q"], d["l_n"], d["mu"], x, d["grad_x"], layout=1)), 3)
     print(json.dumps(row), flush=True)
