@@ -302,12 +302,14 @@ static DQQ_D void bwd_qp_gram_half(const v4d (&A)[4][4], double* __restrict__ Ks
     }
 }
 
+// PAD (48 < N < 64, padded with the identity to 64): the problem's grad_P slot is smaller than K, so K is parked in
+// a per-wave slice of `scratch` (stream-ordered allocation, persistent grid) instead.
+template <bool PAD>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_dense_wave64_qp_kernel(
     const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ x,
-    const double* __restrict__ grad_x, double* grad_P, double* __restrict__ grad_q, long B, double dual_eps,
-    int* __restrict__ ir_steps, int* __restrict__ ws, int use_worklist)
+    const double* __restrict__ grad_x, double* grad_P, double* __restrict__ grad_q, long B, int N, double dual_eps,
+    int* __restrict__ ir_steps, int* __restrict__ ws, int use_worklist, double* scratch)
 {
-    constexpr int N = 64;
     const long count = use_worklist ? (long)ws[kWsCount] : B;
 
     for (long w = blockIdx.x;; w += gridDim.x) {
@@ -323,14 +325,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // wave-uniform by construction; readfirstlane tells the compiler so (P's addressing then uses an SGPR base)
         const long prob = __builtin_amdgcn_readfirstlane(use_worklist ? ws[kWsEntries + w] : (int)w);
         const double* Pg = P + prob * (long)(N * N);
-        double* Ks = grad_P + prob * (long)(N * N);   // scratch for K until the gradient is written
-        const double xi = x[prob * N + lane], gi = grad_x[prob * N + lane], qi = q[prob * N + lane];
+        double* Gp = grad_P != nullptr ? grad_P + prob * (long)(N * N) : nullptr;
+        double* Ks = PAD ? scratch + (long)blockIdx.x * 4096 : Gp;   // K's 4096 doubles until the gradient is written
+        const bool live = !PAD || lane < N;
+        const double xi = live ? x[prob * N + lane] : 0.0, gi = live ? grad_x[prob * N + lane] : 0.0;
+        const double qi = live ? q[prob * N + lane] : 0.0;
         WaveTile64 W;
-        load_tiles_transposed<4, false>(W.G, Pg, 64, lane); // W.G[tk][ta][r] of lane (g,n) = P[16ta+n][16tk+4r+g]
+        load_tiles_transposed<4, PAD>(W.G, Pg, N, lane); // W.G[tk][ta][r] of lane (g,n) = P[16ta+n][16tk+4r+g]
         // dualFromPrimalQP, Solver.cpp:125-134, and the active set of solveDerivativesQP, :139-147
         double gamma = -(W.matvec(xi, xsrc) + qi);
         if (xi > dual_eps) gamma = 0;
-        const bool is_act = gamma < -kActiveEps;
+        const bool is_act = live && gamma < -kActiveEps;
         const unsigned long long am = __ballot(is_act);
         // A~ in place: zero where the row a = 16ta+n or the column k = 16tk+4r+g is active, l_a on the diagonal of
         // an active a (:148-158)
@@ -378,10 +383,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (ctl.update(res)) break;                                       // :32-41
         }
         const double dl = bad ? NAN : (is_act ? 0.0 : xs);                    // :187-191
-        if (grad_q != nullptr) grad_q[prob * N + lane] = -dl;                // qcqp.py:49
-#pragma unroll 8
-        for (int k = 0; k < N; ++k)                                           // qcqp.py:48: -(dl l^T)
-            __builtin_nontemporal_store(-(lane_bcast(dl, k) * xi), Ks + k * N + lane);
+        if (live && grad_q != nullptr) grad_q[prob * N + lane] = -dl;        // qcqp.py:49
+        if (Gp != nullptr) {
+            for (int k = 0; k < N; ++k) {                                     // qcqp.py:48: -(dl l^T)
+                const double v = -(lane_bcast(dl, k) * xi);
+                if (live) __builtin_nontemporal_store(v, Gp + k * N + lane);
+            }
+        }
         if (ir_steps != nullptr && lane == 0) ir_steps[prob] = steps;
     }
     if (use_worklist && threadIdx.x == 0) worklist_release(ws, count, (int)gridDim.x);
@@ -490,8 +498,9 @@ static hipError_t launch_bwd_wave_small(const BwdArgs& a, bool use_worklist, hip
                   a.B, a.N, a.epsilon, a.ir_steps, a.ws, use_worklist ? 1 : 0);
 }
 
-// QP backward: N = 64 (K parked in the grad_P slot: needs grad_P) and every 16 < N <= 48 (all in registers)
-bool bwd_dense_wave64_supported(int kind, int N) { return kind == 0 && (N == 64 || (N > 16 && N <= 48)); }
+// QP backward: every 16 < N <= 64 (N <= 48 all in registers; N = 64 parks K in the grad_P slot and needs grad_P;
+// 48 < N < 64 parks it in scratch)
+bool bwd_dense_wave64_supported(int kind, int N) { return kind == 0 && N > 16 && N <= 64; }
 
 hipError_t launch_bwd_dense_wave64(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)
 {
@@ -501,11 +510,21 @@ hipError_t launch_bwd_dense_wave64(int kind, const BwdArgs& a, bool use_worklist
     if (a.N > 32 && a.N < 48) return launch_bwd_wave_small<3, true>(a, use_worklist, s);
     if (a.N == 32) return launch_bwd_wave_small<2, false>(a, use_worklist, s);
     if (a.N < 32) return launch_bwd_wave_small<2, true>(a, use_worklist, s);
+    if (a.N < 64) { // padded 4 x 4 tiles: K in a scratch slice per wave of a persistent grid
+        const unsigned grid = use_worklist ? 2048u : (unsigned)(a.B < 2048 ? a.B : 2048);
+        double* scratch = nullptr;
+        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(double) * 4096 * (size_t)grid, s);
+        if (e != hipSuccess) return e;
+        e = launch(bwd_dense_wave64_qp_kernel<true>, dim3(grid), dim3(64), 0, s, a.P, a.q, a.x, a.grad_x, a.grad_P,
+                   a.grad_q, a.B, a.N, a.epsilon, a.ir_steps, a.ws, use_worklist ? 1 : 0, scratch);
+        const hipError_t f = hipFreeAsync(scratch, s);
+        return e != hipSuccess ? e : f;
+    }
     if (a.grad_P == nullptr) return hipErrorInvalidValue;
     const long cap = 1L << 22;
     const unsigned grid = use_worklist ? 2048u : (unsigned)(a.B < cap ? a.B : cap);
-    return launch(bwd_dense_wave64_qp_kernel, dim3(grid), dim3(64), 0, s, a.P, a.q, a.x, a.grad_x, a.grad_P, a.grad_q,
-                       a.B, a.epsilon, a.ir_steps, a.ws, use_worklist ? 1 : 0);
+    return launch(bwd_dense_wave64_qp_kernel<false>, dim3(grid), dim3(64), 0, s, a.P, a.q, a.x, a.grad_x, a.grad_P,
+                  a.grad_q, a.B, a.N, a.epsilon, a.ir_steps, a.ws, use_worklist ? 1 : 0, nullptr);
 }
 
 } // namespace dqq

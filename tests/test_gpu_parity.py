@@ -418,7 +418,7 @@ def test_wave_per_problem_forward_every_size(oracle, ops, kind, N, B):
         _capi.set_option("dense_block", 1)
     assert (xw - xh).abs().max() < 1e-8 and (itw == ith).float().mean() >= 0.97
     if kind == "qp":
-        # QP backward: 16 < N <= 48 and N = 64 run on the same register-resident design (K on the matrix cores);
+        # QP backward: every 16 < N <= 64 runs on the same register-resident design (K on the matrix cores);
         # same 1e-9 / identical-refinement-steps bar as the reference-order wave kernel
         grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
         check_backward_exact(grads, st, oracle_bwd(oracle, kind, d, xo), exact=False)
