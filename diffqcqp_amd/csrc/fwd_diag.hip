@@ -17,6 +17,10 @@
 // footprint would cost the fast path its occupancy) the problem indices are
 // appended to the fallback work-list that the general dense kernel (dense.hip)
 // drains right after this launch.
+#include <atomic>
+#include <type_traits>
+
+#include "admm_compact.h"
 #include "admm_core.h"
 #include "dense_core.h"
 #include "launch.h"
@@ -24,7 +28,9 @@
 
 namespace dqq {
 
-template <int KIND, int N, int LPP, int WPB, bool FUSE>
+// CMP: the tiles of a workgroup are repacked as their problems stop (admm_compact.h); a workgroup that meets a
+// non-diagonal tile runs the plain per-wave solve instead.
+template <int KIND, int N, int LPP, int WPB, bool FUSE, bool CMP = false>
 __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __restrict__ P,
                                                             const double* __restrict__ q,
                                                             const double* __restrict__ l_n,
@@ -47,11 +53,15 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
     __shared__ __attribute__((aligned(16))) double s_diag[WPB][SMEM];
     constexpr bool AGG = !FUSE && N >= 32 && WPB > 1; // queue non-diagonal tiles with one atomic per workgroup
     __shared__ int s_cnt[2];
+    static_assert(!CMP || (WPB > 1 && KIND < 2), "compaction: QP / QCQP, several waves per workgroup");
+    [[maybe_unused]] __shared__ typename std::conditional<CMP, CompactLds<(KIND == 1) ? 1 : 0, N / LPP>, int>::type s_cmp;
+    [[maybe_unused]] bool wg_dense = false; // CMP: some tile of this workgroup is not diagonal
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long tile = (long)blockIdx.x * WPB + wave;
     const long first = tile * PPW;
-    if (first >= B) return; // whole wave leaves; no workgroup barrier is used below
+    if (first >= B) return; // whole wave leaves before any workgroup barrier
+    DQQ_TL(0);
     const int nvalid = (B - first) < PPW ? (int)(B - first) : PPW;
     const int pl = lane / LPP;
     const bool valid = pl < nvalid;
@@ -74,6 +84,7 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
         const unsigned nz = (nvalid == PPW) ? stream_tile_diag<N, NCH, false>(Pw, limit, sd, lane)
                                             : stream_tile_diag<N, NCH, true>(Pw, limit, sd, lane);
         const bool tile_dense = __any(nz != 0); // wave-uniform
+        if constexpr (CMP) wg_dense = __syncthreads_or(tile_dense) != 0;
         if (tile_dense && flags_out != nullptr && valid && (lane % LPP) == 0) flags_out[first + pl] = 0;
         if constexpr (FUSE) {
             if (tile_dense) {
@@ -91,6 +102,7 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
         for (int e = 0; e < E; ++e) p[e] = valid ? sd[lane * E + e] : 1.0;
     }
 
+    DQQ_TL(1);
     {
         const double* qq = q + first * N + lane * E;
 #pragma unroll
@@ -124,8 +136,37 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
         }
     }
 
+    DQQ_TL(2);
+    if constexpr (CMP) {
+        if (!wg_dense) {
+            if (valid) { // hand the verified diagonal to the backward first: p does not travel with a problem
+                if (flags_out != nullptr && (lane % LPP) == 0) flags_out[first + pl] = 1;
+                if (pdiag_out != nullptr) {
+                    double* pp = pdiag_out + first * N + lane * E;
+#pragma unroll
+                    for (int e = 0; e < E; e += 2) *reinterpret_cast<double2*>(pp + e) = make_double2(p[e], p[e + 1]);
+                }
+            }
+            unsigned live = 0;
+#pragma unroll
+            for (int w = 0; w < WPB; ++w)
+                if (((long)blockIdx.x * WPB + w) * PPW < B) live |= 1u << w;
+            admm_fwd_diag_compact<KIND, E, LPP, WPB>(p, qv, rad, N, eps, mu_prox, max_iter, adaptive, valid, first + pl,
+                                                     x, iters, s_cmp, wave, live);
+            DQQ_TL(5);
+            return;
+        }
+    }
     const int it = admm_fwd_diag<KIND, E, LaneGroup<LPP>>(p, qv, rad, N, eps, mu_prox, max_iter, adaptive, valid, xv,
                                                           lo, hi, sg);
+#ifdef DQQ_TIMELINE
+    {
+        int m = valid ? it : 0, s = valid ? it : 0;
+        for (int o = 32; o; o >>= 1) { m = max(m, __shfl_xor(m, o)); s += __shfl_xor(s, o); }
+        DQQ_TL_VAL(6, (unsigned long long)m);
+        DQQ_TL_VAL(7, (unsigned long long)s);
+    }
+#endif
 
     if (valid) {
         double* xx = x + first * N + lane * E;
@@ -140,24 +181,36 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
             for (int e = 0; e < E; e += 2) *reinterpret_cast<double2*>(pp + e) = make_double2(p[e], p[e + 1]);
         }
     }
+    DQQ_TL(5);
 }
 
-template <int KIND, int N, int LPP, int WPB, bool FUSE>
+template <int KIND, int N, int LPP, int WPB, bool FUSE, bool CMP = false>
 static hipError_t launch_one(const FwdArgs& a, hipStream_t s)
 {
     constexpr int PPW = 64 / LPP;
     const long ntiles = (a.B + PPW - 1) / PPW;
     const long nblocks = (ntiles + WPB - 1) / WPB;
     if (nblocks == 0) return hipSuccess;
-    return launch((fwd_diag_kernel<KIND, N, LPP, WPB, FUSE>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q,
+    return launch((fwd_diag_kernel<KIND, N, LPP, WPB, FUSE, CMP>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q,
                        a.l_n, a.mu, a.v, a.x, a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.layout, a.iters, a.ws,
                        a.pdiag_out, a.flags_out);
 }
+
+// Option "fwd_compact": 1 = repack the tiles of a workgroup as their problems stop (admm_compact.h).  OFF by
+// default: at the bench shape (B = 65536, iteration counts 8..38) a tile needs 20 % fewer wave-iterations, but
+// every checkpoint costs the workgroup a barrier's worth of imbalance (0.5-1 us) and the launch is bound by its
+// longest problem anyway: QCQP forward 29.4 -> 36.1 us.  It pays for heavy-tailed iteration counts (QP,
+// P = diag(exp(U(-10,10))): 690 -> 480 us).  Instantiated for N = 8, two lanes per problem.
+std::atomic<int> g_fwd_compact{0};
+constexpr bool fwd_diag_compacts(int kind, int n, int lpp) { return kind < 2 && n == 8 && lpp == 2; }
 
 template <int KIND, int N, int LPP>
 static hipError_t launch_wpb(const FwdArgs& a, int wpb, bool fuse, hipStream_t s)
 {
     if constexpr (fwd_diag_fuses(N)) {
+        if constexpr (fwd_diag_compacts(KIND, N, LPP)) {
+            if (fuse && wpb != 1 && g_fwd_compact.load() > 0) return launch_one<KIND, N, LPP, 4, true, true>(a, s);
+        }
         if (fuse) return wpb == 1 ? launch_one<KIND, N, LPP, 1, true>(a, s) : launch_one<KIND, N, LPP, 4, true>(a, s);
     }
     return wpb == 1 ? launch_one<KIND, N, LPP, 1, false>(a, s) : launch_one<KIND, N, LPP, 4, false>(a, s);
@@ -251,3 +304,11 @@ hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fus
 }
 
 } // namespace dqq
+
+#ifdef DQQ_TIMELINE
+// debug library only (tools/ubench/build_timeline.sh): where the waves of fwd_diag_kernel drop their clocks
+extern "C" __attribute__((visibility("default"))) int dqq_debug_set_timeline(void* buf)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(dqq_timeline_buf), &buf, sizeof(buf));
+}
+#endif

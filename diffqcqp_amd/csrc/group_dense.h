@@ -1,0 +1,284 @@
+// group_dense.h -- general (dense P) ADMM forward solve on the lane mapping of the diagonal fast path: the LPP
+// lanes that share a problem in fwd_diag_kernel also solve it when its P is NOT diagonal.
+//
+// Lane s of a group owns rows s*E .. s*E+E-1 (E = N / LPP) of P, of its powers (power iteration) and of
+// M^-1 = (P + (rho+mu) I)^-1, all in registers; a mat-vec is one all-gather of the vector over the group (quad_perm
+// DPP broadcasts, LPP <= 4) and E*N multiply-adds per lane; the explicit inverse at a rho update is an in-place
+// Gauss-Jordan sweep whose pivot row is broadcast from its owner.  A wave therefore advances ALL problems of its
+// tile at once (32 at N = 8, LPP = 2) where the per-problem fallback (dense_core.h dense_fwd_problem) took them
+// one by one -- 25x on a dense batch through DQQ_P_AUTO.
+//
+// Algorithm, update order, constants and stopping tests are the reference's (Solver::solveQP / solveQCQP /
+// solveBoxQP / solveSignedBoxQP, Solver.cpp:61-123, 521-582, 198-261, 374-439; power_iteration :46-59): the ADMM
+// iteration is the very text of the diagonal path (admm_diag_body.inc) with the diagonal scale replaced by the
+// mat-vec with M^-1 and the E reciprocals by the inverse.  As in fwd_lane_dense.hip: the factorisation reads the
+// LOWER triangle of P only (Eigen's llt(), Solver.cpp:76), the power iteration and nothing else the full matrix;
+// the 100 power steps of the QCQP are six matrix squarings and three mat-vecs with exact power-of-two rescaling.
+// Ulp-level departures: Gauss-Jordan instead of LLT + substitutions (same pivots d_k > 0 <=> LLT succeeds), group
+// (tree) sums for the 2-norms, FMA contraction, 1-ulp reciprocal / reciprocal square root.
+#pragma once
+
+#include "admm_core.h"
+
+namespace dqq {
+
+#if defined(__HIPCC__)
+
+constexpr bool group_dense_supported(int n, int lpp) { return lpp <= 4 && n % lpp == 0 && (n / lpp) * n <= 32; }
+
+template <int N, int LPP>
+struct GroupRows {
+    static constexpr int E = N / LPP;
+    static_assert(LPP == 1 || LPP == 2 || LPP == 4, "quad_perm broadcasts");
+
+    // the value lane J of the group holds
+    template <int J>
+    static DQQ_D double bcast(double v)
+    {
+        if constexpr (LPP == 1) return v;
+        else if constexpr (LPP == 2) return dpp_f64<J | (J << 2) | ((2 + J) << 4) | ((2 + J) << 6)>(v);
+        else return dpp_f64<J | (J << 2) | (J << 4) | (J << 6)>(v);
+    }
+    static DQQ_D double bcast_from(double v, int j) // j: a constant after unrolling
+    {
+        if constexpr (LPP == 1) return v;
+        else if constexpr (LPP == 2) return j == 0 ? bcast<0>(v) : bcast<1>(v);
+        else return j == 0 ? bcast<0>(v) : j == 1 ? bcast<1>(v) : j == 2 ? bcast<2>(v) : bcast<3>(v);
+    }
+    // every lane's E entries -> the whole vector, in coordinate order
+    static DQQ_D void gather(const double (&own)[E], double (&full)[N])
+    {
+#pragma unroll
+        for (int j = 0; j < LPP; ++j)
+#pragma unroll
+            for (int e = 0; e < E; ++e) full[j * E + e] = bcast_from(own[e], j);
+    }
+    // y = A x for the lane's rows of A
+    static DQQ_D void matvec(const double (&A)[E][N], const double (&own)[E], double (&y)[E])
+    {
+        double full[N];
+        gather(own, full);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            double t = 0.0;
+#pragma unroll
+            for (int c = 0; c < N; ++c) t += A[e][c] * full[c];
+            y[e] = t;
+        }
+    }
+    // rows s*E.. of the matrix as stored
+    static DQQ_D void load_rows(const double* __restrict__ Pg, int s, double (&A)[E][N])
+    {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int c = 0; c < N; c += 2) {
+                const double2 t = *reinterpret_cast<const double2*>(Pg + (s * E + e) * N + c);
+                A[e][c] = t.x;
+                A[e][c + 1] = t.y;
+            }
+    }
+    // rows s*E.. of the symmetric matrix the LOWER triangle of P defines (what llt() factorises), diagonal `md`
+    static DQQ_D void load_lower_symmetric(const double* __restrict__ Pg, int s, const double (&md)[E],
+                                           double (&A)[E][N])
+    {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int g = s * E + e;
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                const int hi = g > c ? g : c, lo = g > c ? c : g;
+                A[e][c] = Pg[hi * N + lo];
+            }
+#pragma unroll
+            for (int j = 0; j < LPP; ++j) A[e][j * E + e] = (s == j) ? md[e] : A[e][j * E + e];
+        }
+    }
+    // A <- A^-1 in place (Gauss-Jordan without pivoting: A symmetric positive definite, else `bad`)
+    static DQQ_D void invert(double (&A)[E][N], int s, bool& bad)
+    {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int j = k / E, ek = k % E;
+            double rk[N];
+#pragma unroll
+            for (int c = 0; c < N; ++c) rk[c] = bcast_from(A[ek][c], j);
+            bad = bad || !(rk[k] > 0.0);
+            const double pinv = fast_rcp(rk[k]);
+#pragma unroll
+            for (int c = 0; c < N; ++c) rk[c] = (c == k) ? pinv : rk[c] * pinv;
+            const bool owner = (s == j);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const double f = A[e][k];
+#pragma unroll
+                for (int c = 0; c < N; ++c) {
+                    const double upd = (c == k) ? -(f * pinv) : A[e][c] - f * rk[c];
+                    A[e][c] = (e == ek && owner) ? rk[c] : upd;
+                }
+            }
+        }
+    }
+};
+
+// Pg: this problem's P (N x N, row-major).  q, rad, lo, hi, sg, x, valid, return value: as admm_fwd_diag.
+template <int KIND, int N, int LPP>
+DQQ_D int group_dense_fwd(const double* __restrict__ Pg, const double (&q)[N / LPP], const double* rad, double eps,
+                          double mu, int max_iter, int adaptive, bool valid, double (&x)[N / LPP],
+                          const double* lo = nullptr, const double* hi = nullptr, const double* sg = nullptr)
+{
+    constexpr int E = N / LPP;
+    constexpr bool QP_LIKE = (KIND != 1);
+    using G = LaneGroup<LPP>;
+    using R = GroupRows<N, LPP>;
+    const int s = (threadIdx.x & 63) % LPP;
+
+    double A[E][N]; // rows of P, of its powers, then of M^-1
+    if (valid) {
+        R::load_rows(Pg, s, A);
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int c = 0; c < N; ++c) A[e][c] = (c % E == e) ? 1.0 : 0.0; // keeps the arithmetic finite
+    }
+    double md[E]; // the diagonal of P + (rho+mu) I, accumulated as the reference does (:98-100)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        md[e] = A[e][e];
+#pragma unroll
+        for (int j = 1; j < LPP; ++j) md[e] = (s == j) ? A[e][j * E + e] : md[e];
+    }
+
+    // ---- power_iteration, Solver.cpp:46-59 (10 steps for the QP-like solvers :71, 100 for the QCQP :530)
+    double L;
+    {
+        double v[E];
+        const double c0 = 1.0 / sqrt((double)N);
+        double ss = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) ss += c0 * c0;
+        const double nn = sqrt(ss);
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = c0 / nn;
+        if constexpr (QP_LIKE) {
+#pragma unroll 1
+            for (int k = 0; k < 10; ++k) {
+                double Av[E];
+                R::matvec(A, v, Av);
+                double t = 0.0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) t += Av[e] * Av[e];
+                t = G::sum(t);
+                const double inv = t > 0 ? fast_rsqrt(t) : 1.0; // normalised every step (Solver.cpp:53)
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[e] = Av[e] * inv;
+            }
+        } else {
+            // P^100 v0 = P^64 (P^32 (P^4 v0)); every squared matrix and vector rescaled by an exact power of two
+#pragma unroll 1
+            for (int sq = 1; sq <= 6; ++sq) {
+                double T2[E][N];
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    double rowk[N];
+#pragma unroll
+                    for (int c = 0; c < N; ++c) rowk[c] = R::bcast_from(A[k % E][c], k / E);
+#pragma unroll
+                    for (int e = 0; e < E; ++e)
+#pragma unroll
+                        for (int c = 0; c < N; ++c) T2[e][c] = (k == 0) ? A[e][0] * rowk[c] : T2[e][c] + A[e][k] * rowk[c];
+                }
+                double dmax = 0.0;
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+#pragma unroll
+                    for (int c = 0; c < N; ++c) dmax = fmax(dmax, fabs(T2[e][c]));
+                dmax = G::max(dmax);
+                int ex = 0;
+                if (dmax > 0.0 && dmax < 1.79e308) (void)frexp(dmax, &ex);
+#pragma unroll
+                for (int e = 0; e < E; ++e)
+#pragma unroll
+                    for (int c = 0; c < N; ++c) A[e][c] = ldexp(T2[e][c], -ex);
+                if (sq == 2 || sq == 5 || sq == 6) { // A = P^4, P^32, P^64 up to a power of two
+                    double Av[E];
+                    R::matvec(A, v, Av);
+                    double vm = 0.0;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) vm = fmax(vm, fabs(Av[e]));
+                    vm = G::max(vm);
+                    int ev = 0;
+                    if (vm > 0.0 && vm < 1.79e308) (void)frexp(vm, &ev);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) v[e] = ldexp(Av[e], -ev);
+                }
+            }
+            double t = 0.0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) t += v[e] * v[e];
+            t = G::sum(t);
+            const double inv = t > 0 ? fast_rsqrt(t) : 1.0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = v[e] * inv;
+            if (valid) R::load_rows(Pg, s, A); // the Rayleigh quotient is taken with P itself
+        }
+        double Pv[E];
+        R::matvec(A, v, Pv);
+        double t = 0.0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) t += v[e] * Pv[e];
+        L = G::sum(t);
+    }
+
+    // ---- Solver.cpp:72-77 / 531-536
+    double p40, p15;
+    G::pow_pair(L / mu, p40, p15);
+    double rho = sqrt(mu * L) * p40;
+    double tau_inc = p15, tau_dec = tau_inc;
+    double inv_rho = fast_rcp(rho);
+    bool bad = !(rho > 0.0) || !(rho < 1.79e308);
+    double qp[E], l2[E], u[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        md[e] += rho + mu;
+        qp[e] = q[e];
+        l2[e] = 0.0;
+        u[e] = 0.0;
+    }
+    if (valid) R::load_lower_symmetric(Pg, s, md, A);
+    R::invert(A, s, bad);
+
+#define DQQ_ADMM_GENERAL_P 1
+#define DQQ_ADMM_SOLVE(l)                                                                                             \
+    do {                                                                                                              \
+        double rhs_[E];                                                                                               \
+        _Pragma("unroll") for (int e_ = 0; e_ < E; ++e_) rhs_[e_] = rho * l2[e_] - u[e_] - qp[e_];                    \
+        R::matvec(A, rhs_, l);                                                                                        \
+    } while (0)
+#define DQQ_ADMM_REFACTOR(delta)                                                                                      \
+    do {                                                                                                              \
+        _Pragma("unroll") for (int e_ = 0; e_ < E; ++e_) md[e_] += (delta);                                           \
+        R::load_lower_symmetric(Pg, s, md, A);                                                                        \
+        R::invert(A, s, bad);                                                                                         \
+    } while (0)
+    int rho_up = 0, cpt = 0, iters = 0;
+    if (valid) {
+        for (int it = 0; it < max_iter; ++it) {
+#define DQQ_ADMM_ON_STOP break
+#include "admm_diag_body.inc"
+#undef DQQ_ADMM_ON_STOP
+        }
+    }
+#undef DQQ_ADMM_REFACTOR
+#undef DQQ_ADMM_SOLVE
+#undef DQQ_ADMM_GENERAL_P
+    bad = G::max(bad ? 1.0 : 0.0) > 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) x[e] = bad ? NAN : l2[e];
+    return iters;
+}
+
+#endif // __HIPCC__
+
+} // namespace dqq

@@ -155,6 +155,9 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
  *   "wpb"            waves per workgroup of the diagonal kernels (1 or 4; 0 = built-in)
  *   "fuse_fallback"  DQQ_P_AUTO, small N: solve non-diagonal tiles inside the fast kernel (1), queue them
  *                    for the dense kernel launched behind it (0), or decide from B (-1, default)
+ *   "fwd_compact"    diagonal fast path, N = 8: repack the tiles of a workgroup as their problems stop (1), or
+ *                    leave every tile to its wave (0, default: at the bench shape the barriers cost more than the
+ *                    saved wave-iterations; it pays for heavy-tailed iteration counts).  Bit-identical results.
  *   "dense_teams"    general path, backward: pack 64/T problems per wave for small N (1, default) or one
  *                    problem per wave (0)
  *   "block_bwd"      general path, QCQP 22 <= N <= 64 / box QP 11 <= N <= 32 backward: workgroup kernel on the

@@ -1,0 +1,91 @@
+"""Workgroup-level repacking of the N = 8 forward tiles (csrc/admm_compact.h) must not change a single bit.
+
+The problems of a tile stop at different iterations; the compacting kernel moves the ones still running between
+the waves of a workgroup.  Where a problem runs does not enter its arithmetic, so x and the iteration counts must
+equal those of the plain kernel (option fwd_compact = 0) exactly -- for full and ragged batches, for iteration
+budgets that end before / at / between checkpoints, for long solves that cross many checkpoints, and when a
+workgroup meets a non-diagonal tile (it then runs the plain per-wave path)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(kind, d, eps, max_iter, compact, layout=0):
+    from diffqcqp_amd import _capi, ops
+    _capi.set_option("fwd_compact", compact)
+    try:
+        B, N = d["q"].shape[0], d["q"].shape[1]
+        x = torch.full((B, N, 1), float("nan"), dtype=torch.float64, device="cuda")
+        P = d["P"] if layout == 0 else torch.diagonal(d["P"], dim1=1, dim2=2).contiguous()
+        if kind == "qp":
+            _, it = ops.qp_forward(P, d["q"], eps, max_iter, layout=layout, out=x, return_iters=True)
+        else:
+            _, it = ops.qcqp_forward(P, d["q"], d["l_n"], d["mu"], eps, max_iter, layout=layout, out=x,
+                                     return_iters=True)
+        torch.cuda.synchronize()
+        return x.cpu().numpy(), it.cpu().numpy()
+    finally:
+        _capi.set_option("fwd_compact", 0)  # the default
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("B", [1, 31, 33, 127, 128, 129, 1000, 4099, 65536])
+def test_compaction_bit_identical(kind, B):
+    d = {k: v.cuda() for k, v in make_problem(kind, B, 8, 4242 + B).items()}
+    for eps, max_iter in ((1e-7, 1000), (1e-7, 14), (1e-7, 15), (1e-7, 16), (1e-7, 19), (1e-12, 1000), (1e-7, 1)):
+        xa, ia = _run(kind, d, eps, max_iter, 0)
+        xb, ib = _run(kind, d, eps, max_iter, 1)
+        assert np.array_equal(ia, ib), (eps, max_iter)
+        assert np.array_equal(xa, xb, equal_nan=True), (eps, max_iter)
+        assert (ib >= 1).all()
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+def test_compaction_compact_layout_and_oracle(kind):
+    from oracle import oracle
+    B = 4096
+    d0 = make_problem(kind, B, 8, 99)
+    d = {k: v.cuda() for k, v in d0.items()}
+    xa, ia = _run(kind, d, 1e-7, 1000, 0, layout=2)
+    xb, ib = _run(kind, d, 1e-7, 1000, 1, layout=2)
+    assert np.array_equal(ia, ib) and np.array_equal(xa, xb)
+    n = 512
+    P, q = d0["P"][:n].numpy(), d0["q"][:n].numpy()
+    if kind == "qp":
+        xo, io = oracle.qp_fwd_batch(P, q, 1e-7, 1000)
+    else:
+        xo, io = oracle.qcqp_fwd_batch(P, q, d0["l_n"][:n].numpy(), d0["mu"][:n].numpy(), 1e-7, 1000)
+    assert np.array_equal(io, ib[:n])
+    assert np.abs(xo - xb[:n]).max() < 1e-12
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+def test_compaction_with_non_diagonal_tiles(kind):
+    B = 2048
+    d = {k: v.cuda() for k, v in make_problem(kind, B, 8, 7, structure="dense").items()}
+    P = torch.diag_embed(torch.diagonal(d["P"], dim1=1, dim2=2)).contiguous()
+    P[5::300] = d["P"][5::300]  # a few workgroups meet a dense tile
+    d["P"] = P
+    xa, ia = _run(kind, d, 1e-7, 1000, 0)
+    xb, ib = _run(kind, d, 1e-7, 1000, 1)
+    assert np.array_equal(ia, ib) and np.array_equal(xa, xb)
+
+
+def test_compaction_heavy_tail_distribution():
+    """Wide spread of iteration counts (p over ten decades, the reference's figure workload): many checkpoints, most
+    waves of a workgroup end early."""
+    B, N = 8192, 8
+    g = torch.Generator().manual_seed(3)
+    p = torch.exp(20 * torch.rand(B, N, generator=g, dtype=torch.float64) - 10)
+    d = {"P": torch.diag_embed(p).cuda(), "q": (2 * torch.rand(B, N, 1, generator=g, dtype=torch.float64) - 1).cuda(),
+         "l_n": torch.rand(B, N // 2, 1, generator=g, dtype=torch.float64).cuda(),
+         "mu": torch.rand(B, N // 2, 1, generator=g, dtype=torch.float64).cuda()}
+    for kind in ("qp", "qcqp"):
+        xa, ia = _run(kind, d, 1e-10, 1000, 0)
+        xb, ib = _run(kind, d, 1e-10, 1000, 1)
+        assert np.array_equal(ia, ib) and np.array_equal(xa, xb, equal_nan=True)
+        assert ia.max() > 60
