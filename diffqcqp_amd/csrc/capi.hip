@@ -97,6 +97,9 @@ static int fwd_dispatch(int kind, dqq::FwdArgs& a, void* workspace, size_t works
         return (int)dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), g_fuse.load(), s, nullptr);
     }
     if (a.layout == DQQ_P_DENSE || !fast_ok) {
+        if (a.layout == DQQ_P_DENSE && fast_ok && dqq::g_lane_dense.load() != 0 && g_fuse.load() != 0 &&
+            dqq::fwd_diag_takes_dense(kind, a.N, a.B))
+            return (int)dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), 1, s, nullptr);
         if (!dense_ok) return DQQ_E_UNSUPPORTED_N;
         return (int)dqq::launch_fwd_dense(kind, a, false, s);
     }

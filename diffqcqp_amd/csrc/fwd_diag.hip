@@ -23,6 +23,7 @@
 #include "admm_compact.h"
 #include "admm_core.h"
 #include "dense_core.h"
+#include "group_dense.h"
 #include "launch.h"
 #include "stream_tile.h"
 
@@ -55,7 +56,10 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
     __shared__ int s_cnt[2];
     static_assert(!CMP || (WPB > 1 && KIND < 2), "compaction: QP / QCQP, several waves per workgroup");
     [[maybe_unused]] __shared__ typename std::conditional<CMP, CompactLds<(KIND == 1) ? 1 : 0, N / LPP>, int>::type s_cmp;
-    [[maybe_unused]] bool wg_dense = false; // CMP: some tile of this workgroup is not diagonal
+    [[maybe_unused]] bool wg_dense = false;
+    // FUSE, N <= 8: a non-diagonal tile is solved on the same lane mapping, all its problems at once (group_dense.h)
+    constexpr bool GD = FUSE && group_dense_supported(KIND, N, LPP);
+    [[maybe_unused]] bool dense_tile = false; // CMP: some tile of this workgroup is not diagonal
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long tile = (long)blockIdx.x * WPB + wave;
@@ -77,6 +81,11 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
             double2 t = valid ? *reinterpret_cast<const double2*>(pp + e) : make_double2(1.0, 1.0);
             p[e] = t.x; p[e + 1] = t.y;
         }
+    } else if (GD && layout == DQQ_P_DENSE) {
+        // the caller declares P general: no diagonal to look for, every tile takes the group solve
+        dense_tile = true;
+#pragma unroll
+        for (int e = 0; e < E; ++e) p[e] = 1.0;
     } else {
         const double* Pw = P + first * (long)(N * N);
         const int limit = nvalid * N * N; // doubles of P that belong to this tile
@@ -86,7 +95,9 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
         const bool tile_dense = __any(nz != 0); // wave-uniform
         if constexpr (CMP) wg_dense = __syncthreads_or(tile_dense) != 0;
         if (tile_dense && flags_out != nullptr && valid && (lane % LPP) == 0) flags_out[first + pl] = 0;
-        if constexpr (FUSE) {
+        if constexpr (GD) {
+            dense_tile = tile_dense;
+        } else if constexpr (FUSE) {
             if (tile_dense) {
                 for (int j = 0; j < nvalid; ++j)
                     dense_fwd_problem<KIND>(P, q, l_n, mu_c, v_sign, x, iters, first + j, N, eps, mu_prox, max_iter,
@@ -157,8 +168,18 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
             return;
         }
     }
-    const int it = admm_fwd_diag<KIND, E, LaneGroup<LPP>>(p, qv, rad, N, eps, mu_prox, max_iter, adaptive, valid, xv,
-                                                          lo, hi, sg);
+    int it = 0;
+    bool solved = false;
+    if constexpr (GD) {
+        if (dense_tile) {
+            it = group_dense_fwd<KIND, N, LPP>(P + (first + pl) * (long)(N * N), qv, rad, eps, mu_prox, max_iter,
+                                               adaptive, valid, xv, lo, hi, sg);
+            solved = true;
+        }
+    }
+    if (!solved)
+        it = admm_fwd_diag<KIND, E, LaneGroup<LPP>>(p, qv, rad, N, eps, mu_prox, max_iter, adaptive, valid, xv, lo, hi,
+                                                    sg);
 #ifdef DQQ_TIMELINE
     {
         int m = valid ? it : 0, s = valid ? it : 0;
@@ -174,8 +195,8 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
         for (int e = 0; e < E; e += 2) *reinterpret_cast<double2*>(xx + e) = make_double2(xv[e], xv[e + 1]);
         if (iters != nullptr && (lane % LPP) == 0) iters[first + pl] = it;
         // hand the verified diagonal to the backward of the same problems (it then skips the P stream)
-        if (flags_out != nullptr && (lane % LPP) == 0) flags_out[first + pl] = 1;
-        if (pdiag_out != nullptr) {
+        if (flags_out != nullptr && (lane % LPP) == 0 && !dense_tile) flags_out[first + pl] = 1;
+        if (pdiag_out != nullptr && !dense_tile) {
             double* pp = pdiag_out + first * N + lane * E;
 #pragma unroll
             for (int e = 0; e < E; e += 2) *reinterpret_cast<double2*>(pp + e) = make_double2(p[e], p[e + 1]);
@@ -270,11 +291,21 @@ static bool launch_kind(const FwdArgs& a, int lpp, int wpb, bool fuse, hipStream
 }
 
 // The in-kernel dense fallback costs the fast path registers (occupancy), which only matters once the
-// batch is large enough to want more than two waves per SIMD; below that it saves the extra launch.
-bool fwd_diag_fuses_fallback(int N, long B) { return fwd_diag_supported(N) && fwd_diag_fuses(N) && B <= 131072; }
+// batch is large enough to want more than two waves per SIMD; below that it saves the extra launch.  Only where
+// the fallback solves a whole tile at once (group_dense.h, N <= 8): the per-problem fallback of N = 16 makes a
+// dense batch 3-10x slower than the work-list route (4096 x 16: 735 vs 81 us), for 3 us saved on a diagonal one.
+bool fwd_diag_fuses_fallback(int N, long B)
+{
+    return fwd_diag_supported(N) && fwd_diag_fuses(N) && N <= 8 && B <= 131072;
+}
+
+// DQQ_P_DENSE batches the fused kernel's group solve (group_dense.h) takes from the lane-per-problem kernel:
+// N = 8 below 32 Ki problems, where 64 problems per wave leave most of the chip idle (4096 x 8: 44 vs 86 us).
+bool fwd_diag_takes_dense(int kind, int N, long B) { return kind < 2 && N == 8 && B <= 32768; }
 
 bool fwd_diag_will_fuse(int N, long B, int layout, int fuse_opt)
 {
+    if (layout == DQQ_P_DENSE) return true;
     return layout != DQQ_P_DIAG && fwd_diag_supported(N) && fwd_diag_fuses(N) &&
            (fuse_opt < 0 ? fwd_diag_fuses_fallback(N, B) : fuse_opt != 0);
 }
@@ -285,8 +316,15 @@ hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fus
                            bool* needs_fallback)
 {
     if (wpb != 1 && wpb != 4) wpb = 4;
-    if (lpp <= 0) lpp = fwd_diag_default_lpp(a.N, a.B);
     const bool fuse = fwd_diag_will_fuse(a.N, a.B, a.layout, fuse_opt);
+    if (lpp <= 0) {
+        lpp = fwd_diag_default_lpp(a.N, a.B);
+        // fused: a lane mapping the in-kernel general solve exists for (group_dense.h), if there is one
+        int count = 0;
+        const int* c = lpp_choices(a.N, count);
+        for (int i = 0; fuse && i < count && !group_dense_supported(kind, a.N, lpp); ++i)
+            if (c[i] > lpp) lpp = c[i];
+    }
     if (needs_fallback) *needs_fallback = (a.layout == DQQ_P_AUTO) && !fuse;
     hipError_t e = hipErrorInvalidValue;
     auto dispatch = [&](int l) {

@@ -24,7 +24,12 @@ namespace dqq {
 
 #if defined(__HIPCC__)
 
-constexpr bool group_dense_supported(int n, int lpp) { return lpp <= 4 && n % lpp == 0 && (n / lpp) * n <= 32; }
+// (rows per lane) x N matrix entries per lane: 32 keeps the QP / QCQP kernels under 256 VGPRs (two waves per SIMD,
+// as without it); the box kinds carry three more vectors and get half of that
+constexpr bool group_dense_supported(int kind, int n, int lpp)
+{
+    return lpp <= 4 && n % lpp == 0 && (n / lpp) * n <= (kind < 2 ? 32 : 16);
+}
 
 template <int N, int LPP>
 struct GroupRows {

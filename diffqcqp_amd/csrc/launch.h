@@ -152,6 +152,7 @@ hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fus
                            bool* needs_fallback);
 // the launchers' own decision, for the dispatcher: true = non-diagonal tiles are solved inside the fast kernel
 bool fwd_diag_will_fuse(int N, long B, int layout, int fuse_opt);
+bool fwd_diag_takes_dense(int kind, int N, long B); // DQQ_P_DENSE batches solved by the fused kernel's group solve
 bool bwd_diag_will_fuse(int kind, int N, long B, int layout, int fuse_opt);
 // does the general path have a kernel for this size at all
 bool fwd_dense_supported(int kind, int N);

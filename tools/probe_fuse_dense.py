@@ -25,3 +25,14 @@ for B in (4096, 65536):
             _capi.set_option("fuse_fallback",fo)
             row.append("%s qp %.0f qcqp %.0f"%(name,t(lambda: ops.qp_forward(d["P"],d["q"],1e-7,1000,layout=lay,out=x)), t(lambda: ops.qcqp_forward(d["P"],d["q"],d["l_n"],d["mu"],1e-7,1000,layout=lay,out=x))))
         print(B,N," | ".join(row))
+print("backward")
+for B in (4096, 65536):
+    for N in (4, 8):
+        d={k:v.cuda() for k,v in make_problem("qcqp",B,N,7,structure="dense").items()}
+        g=torch.randn(B,N,1,dtype=torch.float64,device="cuda")
+        xq=ops.qp_forward(d["P"],d["q"],1e-7,1000,layout=1); xc=ops.qcqp_forward(d["P"],d["q"],d["l_n"],d["mu"],1e-7,1000,layout=1)
+        row=[]
+        for name,lay,fo in (("DENSE",1,-1),("AUTO fuse",0,1),("AUTO list",0,0)):
+            _capi.set_option("fuse_fallback",fo)
+            row.append("%s qp %.0f qcqp %.0f"%(name,t(lambda: ops.qp_backward(d["P"],d["q"],xq,g,layout=lay)), t(lambda: ops.qcqp_backward(d["P"],d["q"],d["l_n"],d["mu"],xc,g,layout=lay))))
+        print(B,N," | ".join(row))
