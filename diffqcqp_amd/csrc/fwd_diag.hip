@@ -74,6 +74,40 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
     constexpr int EB = (KIND >= 2) ? E : 1;
     double lo[EB], hi[EB], sg[EB]; // box kinds: l_n = l_min, mu_c = l_max, per coordinate
 
+    // q and the constraint data first: their latency hides behind the stream of P (0.8 us of a 30 us launch)
+    {
+        const double* qq = q + first * N + lane * E;
+#pragma unroll
+        for (int e = 0; e < E; e += 2) {
+            double2 t = valid ? *reinterpret_cast<const double2*>(qq + e) : make_double2(0.0, 0.0);
+            qv[e] = t.x; qv[e + 1] = t.y;
+        }
+    }
+    if (KIND == 1) {
+        const long co = first * (N / 2) + lane * (E / 2);
+#pragma unroll
+        for (int c = 0; c < E / 2; ++c) rad[c] = valid ? l_n[co + c] * mu_c[co + c] : 1.0; // pybindings.cpp:57
+    } else {
+#pragma unroll
+        for (int c = 0; c < E / 2; ++c) rad[c] = 0.0;
+    }
+    if constexpr (KIND >= 2) {
+        const long bo = first * N + lane * E;
+#pragma unroll
+        for (int e = 0; e < E; e += 2) {
+            const double2 a = valid ? *reinterpret_cast<const double2*>(l_n + bo + e) : make_double2(0.0, 0.0);
+            const double2 b = valid ? *reinterpret_cast<const double2*>(mu_c + bo + e) : make_double2(0.0, 0.0);
+            lo[e] = a.x; lo[e + 1] = a.y;
+            hi[e] = b.x; hi[e + 1] = b.y;
+            sg[e] = sg[e + 1] = 0.0;
+            if (KIND == 3) {
+                const double2 c = valid ? *reinterpret_cast<const double2*>(v_sign + bo + e) : make_double2(0.0, 0.0);
+                sg[e] = (double)((c.x > 0) - (c.x < 0));       // cwiseSign, Solver.cpp:395
+                sg[e + 1] = (double)((c.y > 0) - (c.y < 0));
+            }
+        }
+    }
+
     if (layout == DQQ_P_DIAG) {
         const double* pp = P + first * N + lane * E;
 #pragma unroll
@@ -114,39 +148,6 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
     }
 
     DQQ_TL(1);
-    {
-        const double* qq = q + first * N + lane * E;
-#pragma unroll
-        for (int e = 0; e < E; e += 2) {
-            double2 t = valid ? *reinterpret_cast<const double2*>(qq + e) : make_double2(0.0, 0.0);
-            qv[e] = t.x; qv[e + 1] = t.y;
-        }
-    }
-    if (KIND == 1) {
-        const long co = first * (N / 2) + lane * (E / 2);
-#pragma unroll
-        for (int c = 0; c < E / 2; ++c) rad[c] = valid ? l_n[co + c] * mu_c[co + c] : 1.0; // pybindings.cpp:57
-    } else {
-#pragma unroll
-        for (int c = 0; c < E / 2; ++c) rad[c] = 0.0;
-    }
-    if constexpr (KIND >= 2) {
-        const long bo = first * N + lane * E;
-#pragma unroll
-        for (int e = 0; e < E; e += 2) {
-            const double2 a = valid ? *reinterpret_cast<const double2*>(l_n + bo + e) : make_double2(0.0, 0.0);
-            const double2 b = valid ? *reinterpret_cast<const double2*>(mu_c + bo + e) : make_double2(0.0, 0.0);
-            lo[e] = a.x; lo[e + 1] = a.y;
-            hi[e] = b.x; hi[e + 1] = b.y;
-            sg[e] = sg[e + 1] = 0.0;
-            if (KIND == 3) {
-                const double2 c = valid ? *reinterpret_cast<const double2*>(v_sign + bo + e) : make_double2(0.0, 0.0);
-                sg[e] = (double)((c.x > 0) - (c.x < 0));       // cwiseSign, Solver.cpp:395
-                sg[e + 1] = (double)((c.y > 0) - (c.y < 0));
-            }
-        }
-    }
-
     DQQ_TL(2);
     if constexpr (CMP) {
         if (!wg_dense) {
