@@ -288,7 +288,15 @@ static hipError_t launch_wpb(const BwdArgs& a, int wpb, bool fuse, hipStream_t s
 
 bool bwd_diag_supported(int N) { return N == 2 || N == 4 || N == 8 || N == 16 || N == 32 || N == 64; }
 
-bool bwd_diag_fuses_fallback(int N, long B) { return bwd_diag_fuses(N) && bwd_diag_supported(N) && B <= 131072; }
+// The backward's in-kernel general routine (dense_core.h dense_bwd_problem) takes the problems of a non-diagonal
+// tile one at a time, a whole wave each: a dense batch pays 126 / 467 us (QP / QCQP, 4096 x 8) where the work-list
+// route -- one more launch, ~3 us, then the team kernel -- takes 33 / 43.  A real contact problem's P is dense, so
+// the extra launch is the default; the fused form is kept where a launch is a tenth of the whole pass (batches
+// that fill the chip: 32 Ki problems and more).
+bool bwd_diag_fuses_fallback(int N, long B)
+{
+    return bwd_diag_fuses(N) && bwd_diag_supported(N) && B >= 32768 && B <= 131072;
+}
 
 template <int KIND>
 static hipError_t launch_kind(const BwdArgs& a, int wpb, bool fuse, hipStream_t s)

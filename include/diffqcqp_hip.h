@@ -154,10 +154,11 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
  *   "fwd_lpp"        lanes per problem of the diagonal forward kernel (0 = built-in choice from B)
  *   "wpb"            waves per workgroup of the diagonal kernels (1 or 4; 0 = built-in)
  *   "fuse_fallback"  DQQ_P_AUTO, N <= 16: solve non-diagonal tiles inside the fast kernel (1), queue them
- *                    for the dense kernel launched behind it (0), or decide from (N, B) (-1, default: inside for
- *                    N <= 8 and B <= 131072, where the forward solves a whole tile at once on the fast path's own
- *                    lane mapping; the backward's in-kernel routine still takes one problem per wave at a time,
- *                    so a batch known to be dense is served best by DQQ_P_DENSE or by 0 here)
+ *                    for the dense kernel launched behind it (0), or decide from (N, B) (-1, default: the
+ *                    forward inside for N <= 8 and B <= 131072, where it solves a whole tile at once on the fast
+ *                    path's own lane mapping; the backward, whose in-kernel routine takes one problem per wave at
+ *                    a time, only for 32768 <= B <= 131072 -- a large batch known to be dense is served best by
+ *                    DQQ_P_DENSE or by 0 here)
  *   "fwd_compact"    diagonal fast path, N = 8: repack the tiles of a workgroup as their problems stop (1), or
  *                    leave every tile to its wave (0, default: at the bench shape the barriers cost more than the
  *                    saved wave-iterations; it pays for heavy-tailed iteration counts).  Bit-identical results.
