@@ -56,7 +56,8 @@ def needs_build():
 
 def _compile(unit, flags, objdir, verbose):
     obj = os.path.join(objdir, unit.replace(".hip", ".o"))
-    cmd = [_hipcc()] + COMMON + flags + ["-I", INCLUDE, "-c", os.path.join(CSRC, unit), "-o", obj]
+    extra = os.environ.get("DQQ_EXTRA_FLAGS", "").split()  # developer experiments (-D...)
+    cmd = [_hipcc()] + COMMON + flags + extra + ["-I", INCLUDE, "-c", os.path.join(CSRC, unit), "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
