@@ -260,7 +260,7 @@ static hipError_t launch_bwd_block_sys(const BwdArgs& a, bool use_worklist, hipS
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::LDS_BYTES);
     if (e != hipSuccess) return e;
     const long cap = 256L * 8;
-    const unsigned grid = use_worklist ? 512u : (unsigned)(a.B < cap ? (a.B > 0 ? a.B : 1) : cap);
+    const unsigned grid = (unsigned)(a.B < (use_worklist ? 512L : cap) ? (a.B > 0 ? a.B : 1) : (use_worklist ? 512L : cap));
     return launch(kernel, dim3(grid), dim3(256), S::LDS_BYTES, s, a.P, a.q, a.l_n, a.mu, a.x, a.grad_x, a.grad_P,
                        a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.N, a.epsilon, a.ir_steps, a.ws,
                        use_worklist ? 1 : 0);

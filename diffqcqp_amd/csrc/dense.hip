@@ -104,7 +104,7 @@ static DenseGeom dense_geom(int lds_doubles, long B, bool use_worklist)
     // the device, so a fixed 512 workgroups are dispatched (an empty list costs one short launch)
     const long cap = 256L * 16 / g.wpb * (g.wpb > 1 ? 2 : 1);
     const long need = (B + g.wpb - 1) / g.wpb;
-    g.grid = use_worklist ? 512u : (unsigned)(need < cap ? (need > 0 ? need : 1) : cap);
+    g.grid = (unsigned)(need < (use_worklist ? 512L : cap) ? (need > 0 ? need : 1) : (use_worklist ? 512L : cap));
     return g;
 }
 
@@ -151,7 +151,7 @@ static hipError_t launch_bwd_team(const BwdArgs& a, bool use_worklist, hipStream
     const long per_block = (long)wpb * TP;
     const long need = (a.B + per_block - 1) / per_block;
     const long cap = 256L * 8;
-    const unsigned grid = use_worklist ? 512u : (unsigned)(need < cap ? (need > 0 ? need : 1) : cap);
+    const unsigned grid = (unsigned)(need < (use_worklist ? 512L : cap) ? (need > 0 ? need : 1) : (use_worklist ? 512L : cap));
     auto kernel = bwd_dense_kernel<KIND, T>;
     hipError_t e = set_lds(kernel, lds_bytes);
     if (e != hipSuccess) return e;

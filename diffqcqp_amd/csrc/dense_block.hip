@@ -240,7 +240,7 @@ static hipError_t launch_block(const FwdArgs& a, bool use_worklist, hipStream_t 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     if (e != hipSuccess) return e;
     const long cap = 256L * (N == 32 ? 3 : 2) * 2; // persistent: 2 (N=64, LDS) or 3 (N=32, VGPRs) workgroups per CU, x2 for balance
-    const unsigned grid = use_worklist ? 512u : (unsigned)(a.B < cap ? (a.B > 0 ? a.B : 1) : cap);
+    const unsigned grid = (unsigned)(a.B < (use_worklist ? 512L : cap) ? (a.B > 0 ? a.B : 1) : (use_worklist ? 512L : cap));
     return launch(kernel, dim3(grid), dim3(256), G::LDS_BYTES, s, a.P, a.q, a.l_n, a.mu, a.v, a.x, a.B, a.eps, a.mu_prox,
                        a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0);
 }
@@ -388,7 +388,7 @@ static hipError_t launch_block_bwd(const BwdArgs& a, bool use_worklist, hipStrea
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     if (e != hipSuccess) return e;
     const long cap = 256L * 2 * 4;
-    const unsigned grid = use_worklist ? 512u : (unsigned)(a.B < cap ? (a.B > 0 ? a.B : 1) : cap);
+    const unsigned grid = (unsigned)(a.B < (use_worklist ? 512L : cap) ? (a.B > 0 ? a.B : 1) : (use_worklist ? 512L : cap));
     return launch(kernel, dim3(grid), dim3(256), G::LDS_BYTES, s, a.P, a.q, a.x, a.grad_x, a.grad_P, a.grad_q, a.B,
                        a.epsilon, a.ir_steps, a.ws, use_worklist ? 1 : 0);
 }

@@ -214,7 +214,7 @@ static hipError_t launch_wave64(const FwdArgs& a, bool use_worklist, hipStream_t
     // one wave per problem, dispatched by the hardware as waves retire (iteration counts differ per problem);
     // work-list mode: a fixed grid of 8 waves per CU claims the entries one at a time
     const long cap = 1L << 22;
-    const unsigned grid = use_worklist ? 2048u : (unsigned)(a.B < cap ? a.B : cap);
+    const unsigned grid = (unsigned)(a.B < (use_worklist ? 2048L : cap) ? (a.B > 0 ? a.B : 1) : (use_worklist ? 2048L : cap));
     return launch(fwd_dense_wave64_kernel<KIND, NT, PAD>, dim3(grid), dim3(64), 0, s, a.P, a.q, a.l_n, a.mu, a.v, a.x, a.B,
                   a.N, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0);
 }
@@ -493,7 +493,7 @@ template <int NT, bool PAD>
 static hipError_t launch_bwd_wave_small(const BwdArgs& a, bool use_worklist, hipStream_t s)
 {
     const long cap = 1L << 22;
-    const unsigned grid = use_worklist ? 2048u : (unsigned)(a.B < cap ? a.B : cap);
+    const unsigned grid = (unsigned)(a.B < (use_worklist ? 2048L : cap) ? (a.B > 0 ? a.B : 1) : (use_worklist ? 2048L : cap));
     return launch(bwd_dense_wave_qp_kernel<NT, PAD>, dim3(grid), dim3(64), 0, s, a.P, a.q, a.x, a.grad_x, a.grad_P, a.grad_q,
                   a.B, a.N, a.epsilon, a.ir_steps, a.ws, use_worklist ? 1 : 0);
 }
@@ -511,7 +511,7 @@ hipError_t launch_bwd_dense_wave64(int kind, const BwdArgs& a, bool use_worklist
     if (a.N == 32) return launch_bwd_wave_small<2, false>(a, use_worklist, s);
     if (a.N < 32) return launch_bwd_wave_small<2, true>(a, use_worklist, s);
     if (a.N < 64) { // padded 4 x 4 tiles: K in a scratch slice per wave of a persistent grid
-        const unsigned grid = use_worklist ? 2048u : (unsigned)(a.B < 2048 ? a.B : 2048);
+        const unsigned grid = (unsigned)(a.B < 2048 ? (a.B > 0 ? a.B : 1) : 2048);
         double* scratch = nullptr;
         hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(double) * 4096 * (size_t)grid, s);
         if (e != hipSuccess) return e;
@@ -522,7 +522,7 @@ hipError_t launch_bwd_dense_wave64(int kind, const BwdArgs& a, bool use_worklist
     }
     if (a.grad_P == nullptr) return hipErrorInvalidValue;
     const long cap = 1L << 22;
-    const unsigned grid = use_worklist ? 2048u : (unsigned)(a.B < cap ? a.B : cap);
+    const unsigned grid = (unsigned)(a.B < (use_worklist ? 2048L : cap) ? (a.B > 0 ? a.B : 1) : (use_worklist ? 2048L : cap));
     return launch(bwd_dense_wave64_qp_kernel<false>, dim3(grid), dim3(64), 0, s, a.P, a.q, a.x, a.grad_x, a.grad_P,
                   a.grad_q, a.B, a.N, a.epsilon, a.ir_steps, a.ws, use_worklist ? 1 : 0, nullptr);
 }
