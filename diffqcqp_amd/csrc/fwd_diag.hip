@@ -118,6 +118,7 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
     } else if (GD && layout == DQQ_P_DENSE) {
         // the caller declares P general: no diagonal to look for, every tile takes the group solve
         dense_tile = true;
+        wg_dense = true; // (CMP: no tile of this launch takes the diagonal arithmetic, nothing to repack)
 #pragma unroll
         for (int e = 0; e < E; ++e) p[e] = 1.0;
     } else {

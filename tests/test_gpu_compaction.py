@@ -20,7 +20,7 @@ def _run(kind, d, eps, max_iter, compact, layout=0):
     try:
         B, N = d["q"].shape[0], d["q"].shape[1]
         x = torch.full((B, N, 1), float("nan"), dtype=torch.float64, device="cuda")
-        P = d["P"] if layout == 0 else torch.diagonal(d["P"], dim1=1, dim2=2).contiguous()
+        P = d["P"] if layout != 2 else torch.diagonal(d["P"], dim1=1, dim2=2).contiguous()
         if kind == "qp":
             _, it = ops.qp_forward(P, d["q"], eps, max_iter, layout=layout, out=x, return_iters=True)
         else:
@@ -73,6 +73,17 @@ def test_compaction_with_non_diagonal_tiles(kind):
     xa, ia = _run(kind, d, 1e-7, 1000, 0)
     xb, ib = _run(kind, d, 1e-7, 1000, 1)
     assert np.array_equal(ia, ib) and np.array_equal(xa, xb)
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+def test_compaction_option_with_dense_layout(kind):
+    """DQQ_P_DENSE batches of N = 8 are routed into the same kernel (group solve): the compaction option must
+    leave them alone (found by tools/fuzz_small.py)."""
+    d = {k: v.cuda() for k, v in make_problem(kind, 300, 8, 11, structure="dense").items()}
+    xa, ia = _run(kind, d, 1e-7, 1000, 0, layout=1)
+    xb, ib = _run(kind, d, 1e-7, 1000, 1, layout=1)
+    assert np.array_equal(ia, ib) and np.array_equal(xa, xb)
+    assert np.isfinite(xb).all() and ib.min() >= 1 and ib.max() > 5
 
 
 def test_compaction_heavy_tail_distribution():

@@ -1,0 +1,58 @@
+"""Randomised parity of the small-N forward routes against the oracle: random kind, N in {2,4,8}, batch size, lanes per
+problem, structure (diag / dense / mixed / non-symmetric), layout, fused or work-list fallback, compaction, eps and
+iteration budget.  usage: python tools/fuzz_small.py [trials] [seed]"""
+import os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import make_problem
+from diffqcqp_amd import _capi, ops
+from oracle import oracle as O
+
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+LPP = {2: [1], 4: [1, 2], 8: [1, 2, 4]}
+worst, bad = 0.0, 0
+for t in range(trials):
+    kind = rng.choice(["qp", "qcqp", "box", "sbox"])
+    N = int(rng.choice([2, 4, 8]))
+    B = int(rng.choice([1, 3, 31, 32, 33, 64, 100, 257, 1000, 4097]))
+    structure = str(rng.choice(["diag", "dense", "mixed", "nonsym"]))
+    layout = int(rng.choice([0, 0, 1])) if structure != "diag" else int(rng.choice([0, 2]))
+    if structure == "mixed": layout = 0
+    eps = float(rng.choice([1e-7, 1e-7, 1e-10, 1e-5]))
+    max_iter = int(rng.choice([1000, 1000, 1, 7, 16, 40]))
+    opts = {"fwd_lpp": int(rng.choice([0] + LPP[N])), "fuse_fallback": int(rng.choice([-1, 0, 1])),
+            "fwd_compact": int(rng.choice([0, 1])), "wpb": int(rng.choice([0, 1, 4]))}
+    d = make_problem(kind, B, N, 9000 + t, "dense" if structure == "nonsym" else structure)
+    if structure == "nonsym":
+        g = torch.Generator().manual_seed(t)
+        d["P"] = (d["P"] + torch.triu(torch.rand(B, N, N, generator=g, dtype=torch.float64), diagonal=1) * 0.05).contiguous()
+    P, q = d["P"].numpy(), d["q"].numpy()
+    if kind == "qp":
+        xo, ito = O.qp_fwd_batch(P, q, eps, max_iter, nthreads=16)
+    elif kind == "qcqp":
+        xo, ito = O.qcqp_fwd_batch(P, q, d["l_n"].numpy(), d["mu"].numpy(), eps, max_iter, nthreads=16)
+    else:
+        v = d["v"].numpy() if kind == "sbox" else None
+        xo, ito = O.boxqp_fwd_batch(P, q, d["l_min"].numpy(), d["l_max"].numpy(), eps, max_iter, v=v, nthreads=16)
+    for k, v in opts.items(): _capi.set_option(k, v)
+    g = {k: v.cuda() for k, v in d.items()}
+    Pin = g["P"] if layout != 2 else torch.diagonal(g["P"], dim1=1, dim2=2).contiguous()
+    if kind == "qp":
+        xh, ith = ops.qp_forward(Pin, g["q"], eps, max_iter, layout=layout, return_iters=True)
+    elif kind == "qcqp":
+        xh, ith = ops.qcqp_forward(Pin, g["q"], g["l_n"], g["mu"], eps, max_iter, layout=layout, return_iters=True)
+    else:
+        xh, ith = ops.boxqp_forward(Pin, g["q"], g["l_min"], g["l_max"], eps, max_iter, v=g.get("v"), layout=layout,
+                                    return_iters=True)
+    err = float(np.abs(xh.cpu().numpy() - xo).max())
+    same = float((ith.cpu().numpy() == ito).mean())
+    worst = max(worst, err)
+    ok = err <= 1e-6 and same >= (0.97 if B >= 100 else 0.0) and np.isfinite(xh.cpu().numpy()).all()
+    if not ok:
+        bad += 1
+        print("FAIL", t, kind, N, B, structure, layout, eps, max_iter, opts, "err %.2e iters equal %.4f" % (err, same), flush=True)
+for k, v in {"fwd_lpp": 0, "fuse_fallback": -1, "fwd_compact": 0, "wpb": 0}.items(): _capi.set_option(k, v)
+print("%d trials, %d failures, worst |dx| %.2e" % (trials, bad, worst))
