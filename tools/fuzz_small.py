@@ -1,6 +1,6 @@
-"""Randomised parity of the small-N forward routes against the oracle: random kind, N in {2,4,8}, batch size, lanes per
-problem, structure (diag / dense / mixed / non-symmetric), layout, fused or work-list fallback, compaction, eps and
-iteration budget.  usage: python tools/fuzz_small.py [trials] [seed]"""
+"""Randomised parity of the forward routes against the oracle: random kind, N (small set by default, `big` as third
+argument: 2..70 incl. odd sizes), batch size, lanes per problem, structure (diag / dense / mixed / non-symmetric), layout, fused or work-list fallback, compaction, eps and
+iteration budget.  usage: python tools/fuzz_small.py [trials] [seed] [big]"""
 import os, sys
 import numpy as np
 import torch
@@ -12,18 +12,25 @@ from oracle import oracle as O
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-LPP = {2: [1], 4: [1, 2], 8: [1, 2, 4]}
+LPP = {2: [1], 4: [1, 2], 8: [1, 2, 4], 16: [2, 4, 8], 32: [4, 8, 16], 64: [8, 16, 32]}
+BIG = len(sys.argv) > 3
+SIZES = [2, 4, 8] if not BIG else [2, 3, 4, 5, 6, 8, 10, 12, 16, 17, 20, 24, 32, 33, 40, 48, 56, 64, 70]
 worst, bad = 0.0, 0
 for t in range(trials):
     kind = rng.choice(["qp", "qcqp", "box", "sbox"])
-    N = int(rng.choice([2, 4, 8]))
+    N = int(rng.choice(SIZES))
+    if kind == "qcqp" and N % 2: N += 1
     B = int(rng.choice([1, 3, 31, 32, 33, 64, 100, 257, 1000, 4097]))
+    if N > 16: B = min(B, 100)
+    if N > 8: B = min(B, 1000)
     structure = str(rng.choice(["diag", "dense", "mixed", "nonsym"]))
-    layout = int(rng.choice([0, 0, 1])) if structure != "diag" else int(rng.choice([0, 2]))
+    fast = N in LPP
+    layout = int(rng.choice([0, 0, 1])) if structure != "diag" else int(rng.choice([0, 2]) if fast else 0)
     if structure == "mixed": layout = 0
     eps = float(rng.choice([1e-7, 1e-7, 1e-10, 1e-5]))
     max_iter = int(rng.choice([1000, 1000, 1, 7, 16, 40]))
-    opts = {"fwd_lpp": int(rng.choice([0] + LPP[N])), "fuse_fallback": int(rng.choice([-1, 0, 1])),
+    opts = {"fwd_lpp": int(rng.choice([0] + LPP.get(N, []))), "dense_wave64": int(rng.choice([0, 1])), "dense_block": int(rng.choice([0, 1])),
+            "lane_dense": int(rng.choice([0, 1])), "small_fwd": int(rng.choice([0, 1])), "fuse_fallback": int(rng.choice([-1, 0, 1])),
             "fwd_compact": int(rng.choice([0, 1])), "wpb": int(rng.choice([0, 1, 4]))}
     d = make_problem(kind, B, N, 9000 + t, "dense" if structure == "nonsym" else structure)
     if structure == "nonsym":
@@ -54,5 +61,6 @@ for t in range(trials):
     if not ok:
         bad += 1
         print("FAIL", t, kind, N, B, structure, layout, eps, max_iter, opts, "err %.2e iters equal %.4f" % (err, same), flush=True)
-for k, v in {"fwd_lpp": 0, "fuse_fallback": -1, "fwd_compact": 0, "wpb": 0}.items(): _capi.set_option(k, v)
+for k, v in {"fwd_lpp": 0, "fuse_fallback": -1, "fwd_compact": 0, "wpb": 0, "dense_wave64": 1, "dense_block": 1, "lane_dense": 1,
+             "small_fwd": 1}.items(): _capi.set_option(k, v)
 print("%d trials, %d failures, worst |dx| %.2e" % (trials, bad, worst))
