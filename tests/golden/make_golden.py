@@ -24,12 +24,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, os.path.dirname(HERE))
 from conftest import make_problem  # noqa: E402
 from oracle import oracle as O  # noqa: E402
+import reference_inputs as R  # noqa: E402
 
 torch.set_default_dtype(torch.double)
 
 
 def run(kind, d, eps, max_iter):
-    P, q, g = d["P"].numpy(), d["q"].numpy(), d["grad_x"].numpy()
+    P, q, g = d["P"].numpy(), d["q"].numpy(), d["grad_x"].double().numpy()
     out = {"P": P, "q": q, "grad_x": g, "eps": eps, "max_iter": max_iter}
     if kind == "qp":
         x, it = O.qp_fwd_batch(P, q, eps, max_iter)
@@ -53,8 +54,56 @@ def run(kind, d, eps, max_iter):
     return out
 
 
+def stack(problems, kind, seed):
+    """[(P, q[, radius])...] of one size -> a batch in the layouts of qcqp.py (radius as l_n with mu = 1, the way the
+    C++ driver hands `l_n` straight to Solver::solveQCQP); grad_x: row 0 = e_1 (`grad_l3[1] = 1.`, Solver.cpp:771),
+    the others seeded N(0,1) (the driver leaves `grad_l` uninitialised, Solver.cpp:723)."""
+    n = problems[0][1].size
+    B = len(problems)
+    g = torch.Generator().manual_seed(seed)
+    gx = torch.randn(B, n, 1, generator=g)
+    gx[0] = 0.0
+    gx[0, 1, 0] = 1.0
+    d = {"P": torch.from_numpy(np.stack([p[0] for p in problems])).contiguous(),
+         "q": torch.from_numpy(np.stack([p[1] for p in problems])).reshape(B, n, 1).contiguous(), "grad_x": gx}
+    if kind == "qcqp":
+        d["l_n"] = torch.from_numpy(np.stack([p[2] for p in problems])).reshape(B, n // 2, 1).contiguous()
+        d["mu"] = torch.ones(B, n // 2, 1)
+    return d
+
+
+def reference_cases():
+    """ref_*.npz: the matrices Solver::test() hard-codes (reference_inputs.py), every way that driver (or a line it
+    comments out) solves them; rd_*.npz: seeded rank-deficient dense batches, the regime G4 stands for."""
+    cases = {}
+    Pm, qm, lm = R.m2_singular()
+    Pf, qf, lf = R.m2_first()
+    cases["ref_m2_qp"] = run("qp", stack([(Pm, qm), (Pf, qf)], "qp", 2001), 1e-10, 1000)            # :712
+    cases["ref_m2_qp_maxiter1"] = run("qp", stack([(Pm, qm), (Pf, qf)], "qp", 2001), 1e-10, 1)      # :729
+    cases["ref_m2_qcqp"] = run("qcqp", stack([(Pm, qm, lm), (Pf, qf, lf)], "qcqp", 2002), 1e-10, 1000)  # :711
+    P2, q2 = R.g2_product()
+    g = torch.Generator().manual_seed(2003)
+    l_ng = ((2 * torch.rand(6, generator=g) - 1) + 1).numpy() * 0.1     # :803-804 (Random + Ones) * .1
+    cases["ref_g2_qp"] = run("qp", stack([(P2, q2)], "qp", 2004), 1e-10, 10000)                     # :811
+    cases["ref_g2_qcqp"] = run("qcqp", stack([(P2, q2, l_ng), (P2, q2, l_ng * 100000)], "qcqp", 2005), 1e-10,
+                               100000)                                                             # :805, :813
+    Pb, qb, radii = R.g_blockdiag()
+    cases["ref_gblock_qp"] = run("qp", stack([(Pb, qb)], "qp", 2006), 1e-10, 10000)
+    cases["ref_gblock_qcqp"] = run("qcqp", stack([(Pb, qb, r) for r in radii], "qcqp", 2007), 1e-10, 100000)  # :871
+    P4, q4, l4 = R.g4_delassus()
+    cases["ref_g4_qp"] = run("qp", stack([(P4, q4), (P4, -q4)], "qp", 2008), 1e-10, 1000)
+    cases["ref_g4_qcqp"] = run("qcqp", stack([(P4, q4, l4), (P4, -q4, l4)], "qcqp", 2009), 1e-10, 1000)
+    for fam in ("lowrank", "duprows"):
+        for N, B in ((8, 24), (32, 8), (64, 3)):
+            for kind in ("qp", "qcqp"):
+                cases["rd_%s_%s_n%d" % (fam, kind, N)] = run(kind, R.rank_deficient(kind, B, N, 7000 + N, fam), 1e-7,
+                                                             1000)
+    return cases
+
+
 def main():
-    cases = {
+    cases = reference_cases()
+    cases.update({
         "qp_diag_n8": run("qp", make_problem("qp", 48, 8, 1002), 1e-7, 1000),
         "qcqp_diag_n8": run("qcqp", make_problem("qcqp", 48, 8, 1003), 1e-7, 1000),
         "qp_diag_n32": run("qp", make_problem("qp", 12, 32, 1004), 1e-7, 1000),
@@ -67,7 +116,7 @@ def main():
         "box_diag_n8": run("box", make_problem("box", 48, 8, 1201), 1e-7, 1000),
         "box_dense_n8": run("box", make_problem("box", 24, 8, 1202, "dense"), 1e-7, 1000),
         "sbox_diag_n8": run("sbox", make_problem("sbox", 48, 8, 1203), 1e-7, 1000),
-    }
+    })
     # README.md:35-38 verbatim: degenerate (q >= 0 => x = 0 after one iteration)
     g = torch.Generator().manual_seed(1001)
     B, N = 10, 8

@@ -15,6 +15,9 @@ import torch
 from conftest import make_problem
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# ref_*.npz / rd_*.npz (the reference's own matrices, rank-deficient P) have their own tests with scale-relative tolerances
+GENERIC_FIXTURES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
+                          if not os.path.basename(p).startswith(("ref_", "rd_")))
 
 
 def test_seed5_inputs_match_authors_constants():
@@ -282,7 +285,7 @@ def test_warm_start_is_dead(oracle):
     assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))), ids=os.path.basename)
+@pytest.mark.parametrize("path", GENERIC_FIXTURES, ids=os.path.basename)
 def test_oracle_reproduces_golden(oracle, path):
     """The committed fixtures are what the oracle computes (here and on the GPU box's host)."""
     d = np.load(path)
@@ -309,6 +312,56 @@ def test_oracle_reproduces_golden(oracle, path):
     assert np.allclose(x, d["x"], rtol=0, atol=1e-11)
     assert np.array_equal(st, d["ir_steps"])
     assert np.allclose(gP, d["grad_P"], rtol=1e-9, atol=1e-12) and np.allclose(gq, d["grad_q"], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "ref_*.npz")) +
+                                        glob.glob(os.path.join(GOLDEN, "rd_*.npz"))), ids=os.path.basename)
+def test_oracle_reproduces_reference_inputs(oracle, path):
+    """ref_*.npz: the matrices the reference hard-codes in Solver::test() (Solver.cpp:697-923; inputs only -- the
+    reference holds no expected values); rd_*.npz: seeded rank-deficient dense P.  Solutions reach 1.6e7, so the
+    forward tolerance is relative to the solution's scale; the backward runs on the fixture's x (IEEE-exact)."""
+    d = np.load(path)
+    eps, mi = float(d["eps"]), int(d["max_iter"])
+    if "l_n" in d.files:
+        x, it = oracle.qcqp_fwd_batch(d["P"], d["q"], d["l_n"], d["mu"], eps, mi)
+        gP, gq, gl, gm, st = oracle.qcqp_bwd_batch(d["P"], d["q"], d["l_n"], d["mu"], d["x"], d["grad_x"])
+        assert np.allclose(gl, d["grad_l_n"], rtol=1e-9, atol=1e-12) and np.allclose(gm, d["grad_mu"], rtol=1e-9, atol=1e-12)
+    else:
+        x, it = oracle.qp_fwd_batch(d["P"], d["q"], eps, mi)
+        gP, gq, st = oracle.qp_bwd_batch(d["P"], d["q"], d["x"], d["grad_x"])
+    assert np.array_equal(it, d["iters"])
+    assert np.abs(x - d["x"]).max() <= 1e-9 * max(1.0, np.abs(d["x"]).max())
+    assert np.array_equal(st, d["ir_steps"])
+    assert np.allclose(gP, d["grad_P"], rtol=1e-9, atol=1e-12) and np.allclose(gq, d["grad_q"], rtol=1e-9, atol=1e-12)
+
+
+def test_reference_inputs_are_the_literals_and_behave_as_their_structure_says(oracle):
+    """What can be said about the reference's own matrices without the reference: the literals have the structure
+    SURVEY 8(c)(v) describes, and the oracle's answers satisfy the optimality conditions the structure implies."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import reference_inputs as R
+    P, q, l_n = R.m2_singular()
+    assert np.linalg.matrix_rank(P) == 2 and np.count_nonzero(P) == 2                  # singular
+    x = oracle.solveQP(P, q, None, 1e-10, 1e-7, 1000)
+    assert abs(x[0] - 8000 / 0.0005) <= 1e-6 * 1.6e7 and np.all(x[1:] == 0)            # -q0/p0 = 1.6e7; x >= 0
+    x1 = oracle.solveQP(P, q, None, 1e-10, 1e-7, 1)                                     # Solver.cpp:729: one iteration
+    assert 0 < x1[0] < x[0]
+    xq = oracle.solveQCQP(P, q, l_n, np.ones(2), None, 1e-10, 1e-7, 1000)
+    assert abs(np.hypot(xq[0], xq[1]) - 1e4) <= 1e-6 * 1e4                              # on the 1e4 friction disk
+    P4, q4, l4 = R.g4_delassus()
+    assert np.allclose(P4, P4.T) and np.linalg.matrix_rank(P4) == 3
+    assert np.array_equal(P4[0], P4[4]) and np.array_equal(P4[1], P4[3]) and np.array_equal(P4[2], P4[6])
+    assert np.array_equal(P4[5], P4[7])
+    x4 = oracle.solveQCQP(P4, q4, l4, np.ones(4), None, 1e-10, 1e-7, 1000)
+    assert np.all(np.hypot(x4[0::2], x4[1::2]) <= l4 * (1 + 1e-9))                      # feasible
+    assert np.allclose(np.hypot(x4[0::2], x4[1::2]), l4, rtol=1e-6)                     # every contact slides
+    P2, q2 = R.g2_product()
+    assert np.allclose(P2, P2.T) and np.linalg.cond(P2) > 1e20
+    Pb, qb, radii = R.g_blockdiag()
+    xb = oracle.solveQCQP(Pb, qb, radii[0], np.ones(2), None, 1e-10, 1e-7, 100000)
+    assert xb[2] == 0 and xb[3] == 0                                                    # the zero-radius contact
+    assert abs(np.hypot(xb[0], xb[1]) - radii[0][0]) <= 1e-9
 
 
 def test_oracle_openmp_matches_serial(oracle):
