@@ -176,7 +176,7 @@ hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipSt
 {
     if (a.B == 0) return hipSuccess;
     if (bwd_small_supported(kind, a.N) && g_small_bwd.load() != 0) return launch_bwd_small(kind, a, use_worklist, s);
-    if (bwd_dense_wave64_supported(kind, a.N) && (a.grad_P != nullptr || a.N != 64) && g_dense_wave64.load() != 0)
+    if (bwd_dense_wave64_supported(kind, a.N) && g_dense_wave64.load() != 0)
         return launch_bwd_dense_wave64(kind, a, use_worklist, s);
     if (bwd_dense_block_supported(kind, a.N) && g_dense_block.load() != 0)
         return launch_bwd_dense_block(kind, a, use_worklist, s);

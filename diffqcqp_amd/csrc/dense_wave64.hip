@@ -20,6 +20,7 @@
 // the lower triangle of P enters the factorisation, while the power iteration multiplies by the full P (:51).
 #include "kkt_core.h"
 #include "launch.h"
+#include "wave_chol.h"
 #include "wave_tile.h"
 
 namespace dqq {
@@ -246,72 +247,28 @@ hipError_t launch_fwd_dense_wave64(int kind, const FwdArgs& a, bool use_worklist
     }
 }
 
-// ---------------------------------------------------------------- backward (QP), N = 64
+// ---------------------------------------------------------------- backward (QP), 16 < N <= 64
 // One wave per problem; the composition of pybindings.cpp:24-30 -> Solver::dualFromPrimalQP (Solver.cpp:125-134),
 // Solver::solveDerivativesQP (:136-196), Solver::iterative_refinement (:15-44) and the gradient assembly of
 // qcqp.py:48-51, on the system in the ORIGINAL index order with the active rows / columns masked
 // (A~[a][k] = P[a][k] if a and k are inactive, l_a if a = k is active, 0 otherwise -- a symmetric permutation of the
 // reference's blkdiag(diag(l_A), P_II), see dense_block.hip).
 //
-// P is read ONCE (64 loads in flight, tile layout of P^T in registers): gamma = -(P l + q), then the masks are
-// applied in place and A^T b follows from the same registers.  K = A~ A~^T + mu I is accumulated on the matrix
-// cores in two halves of eight tiles (A~ 128 registers + a half of K 64) and parked, in tile order (every store and
-// load a fully coalesced 512 bytes), in the 32 KiB of grad_P that belong to this problem -- that slot is written
-// with the actual gradient only at the very end.  K comes back for the block sweep (-K^-1 in place), and the
-// refinement residual K x - A^T b (:30) streams it once more from the same slot (L2-hot) instead of keeping a second
-// 128-register matrix alive.  grad_P == NULL (no scratch): the caller routes to the workgroup kernel.
-template <int TK>
-static DQQ_D void load_tile_row_tileorder(v4d (&T)[4], const double* __restrict__ Ks, int lane)
-{
-#pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) T[tj][r] = (Ks + ((TK * 4 + tj) * 4 + r) * 64)[lane];
-}
-
-template <int TK>
-static DQQ_D void stream_tileorder_row(MatvecStream& mv, const double* __restrict__ Ks, int lane)
-{
-    v4d T[4];
-    load_tile_row_tileorder<TK>(T, Ks, lane);
-    mv.add_row<TK>(T);
-}
-
-template <int HALF>
-static DQQ_D void bwd_qp_gram_half(const v4d (&A)[4][4], double* __restrict__ Ks, int lane)
-{
-    const int g = lane >> 4, n = lane & 15;
-    const bool on_diag = (n & 3) == g;
-    const v4d zero = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int ta = 2 * HALF + h;
-        v4d Kt[4] = {zero, zero, zero, zero};
-#pragma unroll
-        for (int tk = 0; tk < 4; ++tk)
-#pragma unroll
-            for (int tb = 0; tb < 4; ++tb) Kt[tb] = tile_xty(Kt[tb], A[tk][ta], A[tk][tb]); // sum_k A~[a][k] A~[b][k]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Kt[ta][r] += (on_diag && (n >> 2) == r) ? kMuIr : 0.0;   // + mu_ir I, :21
-#pragma unroll
-        for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) (Ks + ((ta * 4 + tb) * 4 + r) * 64)[lane] = Kt[tb][r];
-    }
-}
-
-// PAD (48 < N < 64, padded with the identity to 64): the problem's grad_P slot is smaller than K, so K is parked in
-// a per-wave slice of `scratch` (stream-ordered allocation, persistent grid) instead.
-template <bool PAD>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_dense_wave64_qp_kernel(
+// P is read ONCE (tile layout of P^T in registers): gamma = -(P l + q), then the masks are applied in place and A^T b
+// follows from the same registers.  The UPPER tiles of K = A~ A~^T + mu I are accumulated on the matrix cores
+// (NT (NT+1) / 2 tiles), kept twice: one copy is factored and inverted in place (wave_chol.h: block Cholesky + explicit
+// inverse, the reference's llt() + solveInPlace(Identity), :22-23), the other serves the refinement residual
+// K x - A^T b (:30).  Nothing is parked in memory (round 2 parked K in the grad_P slot and streamed it back twice:
+// 2.6x the algorithmic traffic); products with the symmetric matrices use the upper tiles and their transposes.
+// N is padded with the identity to 16 NT (PAD): a padded coordinate is inactive with x = g = 0, its block of K is
+// 1 + mu and its solution entry stays zero.
+template <int NT, bool PAD>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT >= 3 ? 2 : 3))) void bwd_dense_chol_qp_kernel(
     const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ x,
-    const double* __restrict__ grad_x, double* grad_P, double* __restrict__ grad_q, long B, int N, double dual_eps,
-    int* __restrict__ ir_steps, int* __restrict__ ws, int use_worklist, double* scratch)
+    const double* __restrict__ grad_x, double* __restrict__ grad_P, double* __restrict__ grad_q, long B, int N,
+    double dual_eps, int* __restrict__ ir_steps, int* __restrict__ ws, int use_worklist)
 {
     const long count = use_worklist ? (long)ws[kWsCount] : B;
-
     for (long w = blockIdx.x;; w += gridDim.x) {
         if (use_worklist) { // (an empty list is left untouched: nobody would reset the counter)
             if (count == 0) break;
@@ -325,153 +282,65 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // wave-uniform by construction; readfirstlane tells the compiler so (P's addressing then uses an SGPR base)
         const long prob = __builtin_amdgcn_readfirstlane(use_worklist ? ws[kWsEntries + w] : (int)w);
         const double* Pg = P + prob * (long)(N * N);
-        double* Gp = grad_P != nullptr ? grad_P + prob * (long)(N * N) : nullptr;
-        double* Ks = PAD ? scratch + (long)blockIdx.x * 4096 : Gp;   // K's 4096 doubles until the gradient is written
-        const bool live = !PAD || lane < N;
+        const bool live = (NT == 4 && !PAD) || lane < N;
         const double xi = live ? x[prob * N + lane] : 0.0, gi = live ? grad_x[prob * N + lane] : 0.0;
         const double qi = live ? q[prob * N + lane] : 0.0;
-        WaveTile64 W;
-        load_tiles_transposed<4, PAD>(W.G, Pg, N, lane); // W.G[tk][ta][r] of lane (g,n) = P[16ta+n][16tk+4r+g]
-        // dualFromPrimalQP, Solver.cpp:125-134, and the active set of solveDerivativesQP, :139-147
-        double gamma = -(W.matvec(xi, xsrc) + qi);
-        if (xi > dual_eps) gamma = 0;
-        const bool is_act = live && gamma < -kActiveEps;
-        const unsigned long long am = __ballot(is_act);
-        // A~ in place: zero where the row a = 16ta+n or the column k = 16tk+4r+g is active, l_a on the diagonal of
-        // an active a (:148-158)
+        WaveChol<NT> C;
+        v4d Kc[NT][NT];
+        double Ab;
+        bool is_act;
+        {
+            WaveTile<NT> A;
+            load_tiles_transposed<NT, PAD>(A.G, Pg, N, lane);                 // A.G[tk][ta][r] = P[16ta+n][16tk+4r+g]
+            // dualFromPrimalQP, Solver.cpp:125-134, and the active set of solveDerivativesQP, :139-147
+            double gamma = -(A.matvec(xi, xsrc) + qi);
+            if (xi > dual_eps) gamma = 0;
+            is_act = live && gamma < -kActiveEps;
+            const unsigned long long am = __ballot(is_act);
 #pragma unroll
-        for (int tk = 0; tk < 4; ++tk) {
-            const double dk = lane_gather(xi, 16 * tk + n);
+            for (int tk = 0; tk < NT; ++tk) {                                 // A~ in place, :148-158
+                const double dk = lane_gather(xi, 16 * tk + n);
 #pragma unroll
-            for (int ta = 0; ta < 4; ++ta)
+                for (int ta = 0; ta < NT; ++ta)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool row_act = (am >> (16 * ta + n)) & 1ull, col_act = (am >> (16 * tk + 4 * r + g)) & 1ull;
-                    double t = (row_act || col_act) ? 0.0 : W.G[tk][ta][r];
-                    if (ta == tk) t = (row_act && 4 * r + g == n) ? dk : t;
-                    W.G[tk][ta][r] = t;
-                }
-        }
-        double Ab = W.matvec(is_act ? 0.0 : gi, xsrc);                        // A^T b (:19), b = [0; grad_I]
-        if (is_act) Ab = 0.0;
-        bwd_qp_gram_half<0>(W.G, Ks, lane);                                   // K = A~ A~^T + mu_ir I (:20-21)
-        bwd_qp_gram_half<1>(W.G, Ks, lane);
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) W.G[ti][tj][r] = (Ks + ((ti * 4 + tj) * 4 + r) * 64)[lane];
-        bool bad = false;
-        block_sweep_inverse<4>(W.G, lane, bad);                               // :22-23; W.G = -K^-1
-        const double KinvAb = -W.matvec(Ab, xsrc);                            // :27
-        double xs = 0.0;
-        IrControl ctl;
-        ctl.init();
-        int steps = 0;
-        for (int it = 0; it < kIrMaxIter; ++it) {
-            steps = it + 1;
-            xs = KinvAb - kMuIr * W.matvec(xs, xsrc);                         // :29
-            MatvecStream mv;                                                  // K xs, K streamed from its slot
-            mv.begin(xs, xsrc);
-            stream_tileorder_row<0>(mv, Ks, lane);
-            stream_tileorder_row<1>(mv, Ks, lane);
-            stream_tileorder_row<2>(mv, Ks, lane);
-            stream_tileorder_row<3>(mv, Ks, lane);
-            const double d = mv.finish() - Ab;                                // :30
-            const double res = sqrt(wave_sum64(d * d));                       // :31
-            if (ctl.update(res)) break;                                       // :32-41
-        }
-        const double dl = bad ? NAN : (is_act ? 0.0 : xs);                    // :187-191
-        if (live && grad_q != nullptr) grad_q[prob * N + lane] = -dl;        // qcqp.py:49
-        if (Gp != nullptr) {
-            for (int k = 0; k < N; ++k) {                                     // qcqp.py:48: -(dl l^T)
-                const double v = -(lane_bcast(dl, k) * xi);
-                if (live) __builtin_nontemporal_store(v, Gp + k * N + lane);
+                    for (int r = 0; r < 4; ++r) {
+                        const bool row_act = (am >> (16 * ta + n)) & 1ull, col_act = (am >> (16 * tk + 4 * r + g)) & 1ull;
+                        double t = (row_act || col_act) ? 0.0 : A.G[tk][ta][r];
+                        if (ta == tk) t = (row_act && 4 * r + g == n) ? dk : t;
+                        A.G[tk][ta][r] = t;
+                    }
             }
-        }
-        if (ir_steps != nullptr && lane == 0) ir_steps[prob] = steps;
-    }
-    if (use_worklist && threadIdx.x == 0) worklist_release(ws, count, (int)gridDim.x);
-}
-
-// ---------------------------------------------------------------- backward (QP), 16 < N <= 48
-// The same composition as above for 2 x 2 and 3 x 3 tiles: here A~ (NT^2 tiles), K = A~ A~^T + mu I and a copy of K
-// for the refinement residual all fit the registers of a wave (NT = 3: 18 tiles = 144 VGPRs while K is accumulated,
-// then K^-1 + K), so nothing is parked in memory.  N is padded with the identity to 16 NT (PAD): a padded coordinate
-// is inactive with x = g = 0, its block of K is 1 + mu and its solution entry stays zero.
-template <int NT, bool PAD>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT == 3 ? 2 : 3))) void bwd_dense_wave_qp_kernel(
-    const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ x,
-    const double* __restrict__ grad_x, double* __restrict__ grad_P, double* __restrict__ grad_q, long B, int N,
-    double dual_eps, int* __restrict__ ir_steps, int* __restrict__ ws, int use_worklist)
-{
-    const long count = use_worklist ? (long)ws[kWsCount] : B;
-    for (long w = blockIdx.x;; w += gridDim.x) {
-        if (use_worklist) {
-            if (count == 0) break;
-            w = __builtin_amdgcn_readfirstlane(threadIdx.x == 0 ? atomicAdd(&ws[kWsNext], 1) : 0);
-        }
-        if (w >= count) break;
-        int lane = threadIdx.x;
-        asm volatile("" : "+v"(lane));
-        const int g = lane >> 4, n = lane & 15;
-        const int xsrc = 4 * n + g;
-        const long prob = __builtin_amdgcn_readfirstlane(use_worklist ? ws[kWsEntries + w] : (int)w);
-        const double* Pg = P + prob * (long)(N * N);
-        const bool live = lane < N;
-        const double xi = live ? x[prob * N + lane] : 0.0, gi = live ? grad_x[prob * N + lane] : 0.0;
-        const double qi = live ? q[prob * N + lane] : 0.0;
-        WaveTile<NT> A;
-        load_tiles_transposed<NT, PAD>(A.G, Pg, N, lane);                     // A.G[tk][ta][r] = P[16ta+n][16tk+4r+g]
-        // dualFromPrimalQP, Solver.cpp:125-134, and the active set of solveDerivativesQP, :139-147
-        double gamma = -(A.matvec(xi, xsrc) + qi);
-        if (xi > dual_eps) gamma = 0;
-        const bool is_act = live && gamma < -kActiveEps;
-        const unsigned long long am = __ballot(is_act);
-#pragma unroll
-        for (int tk = 0; tk < NT; ++tk) {                                     // A~ in place, :148-158
-            const double dk = lane_gather(xi, 16 * tk + n);
+            Ab = A.matvec(is_act ? 0.0 : gi, xsrc);                           // A^T b (:19), b = [0; grad_I]
+            if (is_act) Ab = 0.0;
+            const v4d zero = {0.0, 0.0, 0.0, 0.0};                            // K = A~ A~^T + mu_ir I (:20-21), upper tiles
+            const bool on_diag = (n & 3) == g;
 #pragma unroll
             for (int ta = 0; ta < NT; ++ta)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool row_act = (am >> (16 * ta + n)) & 1ull, col_act = (am >> (16 * tk + 4 * r + g)) & 1ull;
-                    double t = (row_act || col_act) ? 0.0 : A.G[tk][ta][r];
-                    if (ta == tk) t = (row_act && 4 * r + g == n) ? dk : t;
-                    A.G[tk][ta][r] = t;
+                for (int tb = ta; tb < NT; ++tb) {
+                    v4d acc = zero;
+#pragma unroll
+                    for (int tk = 0; tk < NT; ++tk) acc = tile_xty(acc, A.G[tk][ta], A.G[tk][tb]);
+                    if (ta == tb) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[r] += (on_diag && (n >> 2) == r) ? kMuIr : 0.0;
+                    }
+                    C.U[ta][tb] = acc;
+                    Kc[ta][tb] = acc;
                 }
         }
-        double Ab = A.matvec(is_act ? 0.0 : gi, xsrc);                        // A^T b (:19), b = [0; grad_I]
-        if (is_act) Ab = 0.0;
-        WaveTile<NT> K, Kc;                                                   // K = A~ A~^T + mu_ir I (:20-21)
-        const v4d zero = {0.0, 0.0, 0.0, 0.0};
-        const bool on_diag = (n & 3) == g;
-#pragma unroll
-        for (int ta = 0; ta < NT; ++ta)
-#pragma unroll
-            for (int tb = 0; tb < NT; ++tb) {
-                v4d acc = zero;
-#pragma unroll
-                for (int tk = 0; tk < NT; ++tk) acc = tile_xty(acc, A.G[tk][ta], A.G[tk][tb]);
-                if (ta == tb) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] += (on_diag && (n >> 2) == r) ? kMuIr : 0.0;
-                }
-                K.G[ta][tb] = acc;
-                Kc.G[ta][tb] = acc;
-            }
         bool bad = false;
-        block_sweep_inverse<NT>(K.G, lane, bad);                              // :22-23; K.G = -K^-1
-        const double KinvAb = -K.matvec(Ab, xsrc);                            // :27
+        C.factor(lane, bad);                                                  // :22
+        C.invert_in_place(lane);                                              // :23; C.U = upper tiles of K^-1
+        const double KinvAb = sym_upper_matvec<NT>(C.U, Ab, xsrc, lane);      // :27
         double xs = 0.0;
         IrControl ctl;
         ctl.init();
         int steps = 0;
         for (int it = 0; it < kIrMaxIter; ++it) {
             steps = it + 1;
-            xs = KinvAb - kMuIr * K.matvec(xs, xsrc);                         // :29
-            const double d = Kc.matvec(xs, xsrc) - Ab;                        // :30
+            xs = it == 0 ? KinvAb : KinvAb + kMuIr * sym_upper_matvec<NT>(C.U, xs, xsrc, lane); // :29 (first body: x = 0)
+            const double d = sym_upper_matvec<NT>(Kc, xs, xsrc, lane) - Ab;   // :30
             const double res = sqrt(wave_sum64(d * d));                       // :31
             if (ctl.update(res)) break;                                       // :32-41
         }
@@ -490,41 +359,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT == 3 ?
 }
 
 template <int NT, bool PAD>
-static hipError_t launch_bwd_wave_small(const BwdArgs& a, bool use_worklist, hipStream_t s)
+static hipError_t launch_bwd_chol(const BwdArgs& a, bool use_worklist, hipStream_t s)
 {
     const long cap = 1L << 22;
     const unsigned grid = (unsigned)(a.B < (use_worklist ? 2048L : cap) ? (a.B > 0 ? a.B : 1) : (use_worklist ? 2048L : cap));
-    return launch(bwd_dense_wave_qp_kernel<NT, PAD>, dim3(grid), dim3(64), 0, s, a.P, a.q, a.x, a.grad_x, a.grad_P, a.grad_q,
+    return launch(bwd_dense_chol_qp_kernel<NT, PAD>, dim3(grid), dim3(64), 0, s, a.P, a.q, a.x, a.grad_x, a.grad_P, a.grad_q,
                   a.B, a.N, a.epsilon, a.ir_steps, a.ws, use_worklist ? 1 : 0);
 }
 
-// QP backward: every 16 < N <= 64 (N <= 48 all in registers; N = 64 parks K in the grad_P slot and needs grad_P;
-// 48 < N < 64 parks it in scratch)
+// QP backward: every 16 < N <= 64, everything in registers, nothing allocated
 bool bwd_dense_wave64_supported(int kind, int N) { return kind == 0 && N > 16 && N <= 64; }
 
 hipError_t launch_bwd_dense_wave64(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
     if (!bwd_dense_wave64_supported(kind, a.N)) return hipErrorInvalidValue;
-    if (a.N == 48) return launch_bwd_wave_small<3, false>(a, use_worklist, s);
-    if (a.N > 32 && a.N < 48) return launch_bwd_wave_small<3, true>(a, use_worklist, s);
-    if (a.N == 32) return launch_bwd_wave_small<2, false>(a, use_worklist, s);
-    if (a.N < 32) return launch_bwd_wave_small<2, true>(a, use_worklist, s);
-    if (a.N < 64) { // padded 4 x 4 tiles: K in a scratch slice per wave of a persistent grid
-        const unsigned grid = (unsigned)(a.B < 2048 ? (a.B > 0 ? a.B : 1) : 2048);
-        double* scratch = nullptr;
-        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(double) * 4096 * (size_t)grid, s);
-        if (e != hipSuccess) return e;
-        e = launch(bwd_dense_wave64_qp_kernel<true>, dim3(grid), dim3(64), 0, s, a.P, a.q, a.x, a.grad_x, a.grad_P,
-                   a.grad_q, a.B, a.N, a.epsilon, a.ir_steps, a.ws, use_worklist ? 1 : 0, scratch);
-        const hipError_t f = hipFreeAsync(scratch, s);
-        return e != hipSuccess ? e : f;
-    }
-    if (a.grad_P == nullptr) return hipErrorInvalidValue;
-    const long cap = 1L << 22;
-    const unsigned grid = (unsigned)(a.B < (use_worklist ? 2048L : cap) ? (a.B > 0 ? a.B : 1) : (use_worklist ? 2048L : cap));
-    return launch(bwd_dense_wave64_qp_kernel<false>, dim3(grid), dim3(64), 0, s, a.P, a.q, a.x, a.grad_x, a.grad_P,
-                  a.grad_q, a.B, a.N, a.epsilon, a.ir_steps, a.ws, use_worklist ? 1 : 0, nullptr);
+    if (a.N == 64) return launch_bwd_chol<4, false>(a, use_worklist, s);
+    if (a.N > 48) return launch_bwd_chol<4, true>(a, use_worklist, s);
+    if (a.N == 48) return launch_bwd_chol<3, false>(a, use_worklist, s);
+    if (a.N > 32) return launch_bwd_chol<3, true>(a, use_worklist, s);
+    if (a.N == 32) return launch_bwd_chol<2, false>(a, use_worklist, s);
+    return launch_bwd_chol<2, true>(a, use_worklist, s);
 }
 
 } // namespace dqq
