@@ -960,3 +960,40 @@ def test_full_size_config5_dense_n64(oracle, ops):
     check_forward(x[idx], it[idx], xo, ito, min_match=0.9)
     gs, sts = hip_bwd(ops, "qp", dev(d), torch.from_numpy(xo).cuda())
     check_backward_exact(gs, sts, oracle_bwd(oracle, "qp", d, xo), exact=False)
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("structure", ["dense", "one_in_1000"])
+def test_full_size_b65536_n8_dense_p_through_auto(oracle, ops, kind, structure):
+    """A real contact problem's P is dense.  At the bench's batch size, through DQQ_P_AUTO (what QPFn2 / QCQPFn2 pass):
+    a fully dense batch and a diagonal batch with one dense problem in 1000, forward + backward.  The non-diagonal
+    tiles go through the work-list to the kernels DQQ_P_DENSE launches directly, so both routes must return the same
+    numbers for them; round 2 solved such tiles one problem per wave inside the fused backward for exactly
+    32 Ki <= B <= 128 Ki (10-100x slower).  A sample is checked against the oracle."""
+    B, N = 65536, 8
+    dd = make_problem(kind, B, N, 6100, "dense")
+    d = dict(dd)
+    if structure == "one_in_1000":
+        dg = make_problem(kind, B, N, 6100, "diag")
+        sel = (torch.arange(B) % 1000 == 1).view(B, 1, 1)
+        d["P"] = torch.where(sel, dd["P"], dg["P"]).contiguous()
+    g = dev(d)
+    xa, ita = hip_fwd(ops, kind, g, layout=0)
+    xd, itd = hip_fwd(ops, kind, g, layout=1)
+    nd = torch.arange(B) % 1000 == 1 if structure == "one_in_1000" else torch.ones(B, dtype=torch.bool)
+    assert np.abs(npy(xa) - npy(xd)).max() <= 1e-9 and (npy(ita) == npy(itd)).mean() >= 0.9999
+    ga, sa = hip_bwd(ops, kind, g, xd, layout=0)
+    gd, sd = hip_bwd(ops, kind, g, xd, layout=1)
+    assert np.array_equal(npy(sa), npy(sd))
+    for a, b in zip(ga, gd):
+        a, b = npy(a), npy(b)
+        assert np.array_equal(a[nd.numpy()], b[nd.numpy()]), "non-diagonal problems: AUTO and DENSE differ"
+        assert np.allclose(a, b, rtol=1e-9, atol=1e-12)
+    idx = np.concatenate([np.nonzero(nd.numpy())[0][:256], np.arange(0, B, 257)[:256]])
+    sub = {k: v[idx] for k, v in d.items()}
+    xo, ito = oracle_fwd(oracle, kind, sub)
+    assert np.abs(npy(xa)[idx] - xo).max() <= X_TOL and (npy(ita)[idx] == ito).mean() >= 0.99
+    ref = oracle_bwd(oracle, kind, sub, npy(xd)[idx])
+    assert np.array_equal(npy(sa)[idx], ref[-1])
+    for a, b in zip(ga, ref[:-1]):
+        assert np.allclose(npy(a)[idx], b, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(b).max()))
