@@ -23,6 +23,12 @@ Timing: W warm-up steps, then R regions of EXACTLY K steps, each bracketed by ba
 on both sides and reduced with MAX over the ranks; `ms_per_step` / `value` are the MEDIAN region (min / max in
 `repeats`), so a short K is not a single sub-millisecond sample.
 
+Default run (no --config): on ONE GPU the headline step, followed by short runs of BASELINE configs 2, 3, 4, 5
+(`per_config`: 3 regions each, dominant kernel, roofline fractions, CPU baseline) and the dense-P check (`dense_p_n8`),
+so that one driver-run line carries every workload.  Under torch.distributed.run (WORLD_SIZE set; any number of
+ranks) the line is configs[3] -- the batch SPLIT over the ranks, RCCL all-gather of x, with and without the gather --
+and the weak-scaling headline is the sub-record `weak_headline`.
+
 Rank 0 prints ONE JSON line.  Besides the contract keys:
   roofline      the launch with the largest mean duration: algorithmic bytes / its duration from
                 HIP events on the launch stream vs 8 TB/s; `moved` = the bytes that launch really reads + writes
@@ -30,6 +36,8 @@ Rank 0 prints ONE JSON line.  Besides the contract keys:
                 for the compute-bound config 5 also the FP64 figure (`fp64`)
   cpu_baseline  the oracle (C port of the reference algorithm) on this box's host cores, bounded sample
   kernels       per-launch breakdown;   cold   the same step over rotating input/output sets (> 256 MiB cache)
+  environment   clocks / power cap (rocm-smi) and GPU_MAX_HW_QUEUES of this box; single_stream = the same step on one
+                stream -- boxes of the pool differ by up to ~9 %, compare rounds on both figures
 """
 import argparse
 import json
@@ -201,73 +209,53 @@ WORKLOADS = {
 }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, default=0, choices=(0, 2, 3, 4, 5),
-                    help="BASELINE.json configs entry (1-based); 0 = the headline step (configs 2'+3)")
-    ap.add_argument("--repeats", type=int, default=10, help="timed regions of exactly --steps steps; the median is reported")
-    ap.add_argument("--streams", type=int, default=2, choices=(1, 2),
-                    help="headline only: 2 = the QP chain and the QCQP chain on two HIP streams")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--no-cold", action="store_true")
-    args = ap.parse_args()
+def gpu_environment():
+    """Clocks, power cap and queue setting of this box (boxes of the pool differ by up to ~9 %).
+    Best effort: rocm-smi may be missing or slow; nothing here is required for the measurement."""
+    import subprocess
+    env = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "device": torch.cuda.get_device_name(0)}
+    try:
+        p = torch.cuda.get_device_properties(0)
+        env.update({"compute_units": p.multi_processor_count, "clock_rate_khz_reported": getattr(p, "clock_rate", None)})
+    except Exception:
+        pass
+    try:
+        txt = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showmaxpower", "--showpower", "--showperflevel",
+                              "--json"], capture_output=True, text=True, timeout=20).stdout
+        card = next(iter(json.loads(txt).values()))
+        keep = ("sclk", "mclk", "fclk", "Max Graphics Package Power", "Average Graphics Package Power",
+                "Current Socket Graphics Package Power", "Performance Level")
+        env["rocm_smi"] = {k: v for k, v in card.items() if any(t.lower() in k.lower() for t in keep)}
+    except Exception as e:  # noqa: BLE001
+        env["rocm_smi"] = "unavailable (%s)" % type(e).__name__
+    return env
 
-    # Everything the native libraries print on stdout (RCCL prints its version banner there) goes to
-    # stderr; the one JSON line is written to the real stdout at the end.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-        args.gpus = world
-    assert torch.cuda.is_available(), "bench.py needs the GPU (the hot path is a HIP kernel; there is no CPU path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    import torch.distributed as dist
-    # DQQ_BENCH_FORCE_DIST=1 exercises the RCCL path (init, barrier, all-gather) with a single rank
-    use_dist = world > 1 or os.environ.get("DQQ_BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL
-
-    from diffqcqp_amd import build, _capi, parallel
-    if rank == 0:
-        build.build()
-    if use_dist:
-        dist.barrier()
-    _capi.lib()
-
-    desc, families, B_total, scaling, cpu_n = WORKLOADS[args.config]
+def measure(cfg, args, ctx, light=False):
+    """One workload -> its record (rank 0; None on the other ranks).  light: a per_config sub-record -- 3 regions, no
+    cold set, no single-stream context."""
+    rank, world, dev, use_dist = ctx["rank"], ctx["world"], ctx["dev"], ctx["use_dist"]
+    dist, parallel, _capi = ctx["dist"], ctx["parallel"], ctx["capi"]
+    desc, families, B_total, scaling, cpu_n = WORKLOADS[cfg]
     if scaling == "strong":
         lo, hi = parallel.shard_bounds(B_total, rank, world)
         B_rank = hi - lo
     else:
         B_rank = B_total
-    gather = args.config == 4          # the path's one exchange step
-    steps = max(args.steps, 1)
-    if args.config == 5 and args.steps == 100 and args.repeats == 10:
-        steps, args.repeats = 5, 5     # a step is ~7.5 ms of a 4.3 GB working set: bound the default run
-    if args.config == 4 and args.steps == 100:
+    gather = cfg == 4                  # the path's one exchange step (SURVEY.md 8e)
+    steps, repeats, warmup = max(args.steps, 1), max(args.repeats, 1), max(args.warmup, 1)
+    if cfg == 5 and args.steps == 100 and args.repeats == 10:
+        steps, repeats = 5, 5          # a step is ~6 ms of a 4.3 GB working set: bound the default run
+    if cfg == 4 and args.steps == 100:
         steps = 20
+    if light:
+        steps, repeats, warmup = {2: 50, 3: 50, 4: 10, 5: 3, 0: 50, 6: 20}[cfg], 3, 3
 
-    chains = [Chain(k, B_rank, n, st, bw, dev, 1000 + 17 * args.config + 7919 * rank + 31 * i)
+    chains = [Chain(k, B_rank, n, st, bw, dev, 1000 + 17 * cfg + 7919 * rank + 31 * i)
               for i, (k, n, st, bw) in enumerate(families)]
     main_stream = torch.cuda.current_stream()
     sh = main_stream.cuda_stream
-    side = torch.cuda.Stream() if (len(chains) == 2 and args.streams == 2) else None
+    side = ctx["side"] if (len(chains) == 2 and args.streams == 2) else None
     streams = [sh, side.cuda_stream if side is not None else sh]
     x_all = None
 
@@ -319,31 +307,32 @@ def main():
     timed = step_and_gather if gather else step
 
     # ---- warm-up (also warms RCCL's all-gather)
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(warmup):
         timed()
     drain()
     # ---- timed regions: R times EXACTLY K steps
-    times = sorted(region(timed, steps) for _ in range(max(args.repeats, 1)))
+    times = sorted(region(timed, steps) for _ in range(repeats))
     elapsed = times[len(times) // 2]
     if gather and use_dist:
         assert x_all.shape[0] == B_total
-
     extra = {}
     if gather:   # the same regions without the exchange step
-        tn = sorted(region(step, steps) for _ in range(max(args.repeats // 2, 1)))
+        tn = sorted(region(step, steps) for _ in range(max(repeats // 2, 1)))
         extra["without_gather"] = {"ms_per_step": tn[len(tn) // 2] / steps * 1e3,
                                    "value": B_total * steps / tn[len(tn) // 2],
-                                   "allgather_bytes_per_rank": B_rank * families[0][1] * 8}
-    if side is not None:   # context: the same steps strictly on one stream
+                                   "allgather_bytes_per_rank": B_rank * families[0][1] * 8,
+                                   "rccl_world": dist.get_world_size() if use_dist else 1}
+    if side is not None and not light:   # context: the same steps strictly on one stream
         save, side = side, None
         t1 = sorted(region(step, steps) for _ in range(3))
         side = save
         extra["single_stream"] = {"ms_per_step": t1[1] / steps * 1e3,
                                   "value_this_rank": sum(c.B for c in chains) * steps / t1[1],
-                                  "note": "all launches of a step on one stream (what one problem family alone sees)"}
+                                  "note": "all launches of a step on one stream (what one problem family alone sees); "
+                                          "the figure to compare across boxes and rounds next to the two-stream one"}
 
     # ---- cold variant: rotate input AND output sets so that a step never finds its data in the 256 MiB Infinity Cache
-    if args.config in (0, 2, 3) and not args.no_cold and world == 1:
+    if cfg in (0, 2, 3) and not args.no_cold and world == 1 and not light:
         per_set = sum(sum(v.numel() * v.element_size() for v in c.sets[0].values()) for c in chains)
         nsets = max(3, int(np.ceil(768 * 2**20 / per_set)))
         cold = [Chain(c.kind, c.B, c.N, c.structure, c.backward, dev, 5000 + 13 * i, nsets=nsets)
@@ -357,7 +346,7 @@ def main():
         for _ in range(nsets):
             cold_step()
         drain()
-        tc = sorted(region(cold_step, steps) for _ in range(max(args.repeats // 2, 3)))
+        tc = sorted(region(cold_step, steps) for _ in range(max(repeats // 2, 3)))
         chains = hot
         extra["cold"] = {"sets": nsets, "bytes_per_set": per_set, "ms_per_step": tc[len(tc) // 2] / steps * 1e3,
                          "value": sum(c.B for c in chains) * steps / tc[len(tc) // 2],
@@ -371,7 +360,7 @@ def main():
     all_diag = all(c.structure == "diag" for c in chains)
     if all_diag:
         _capi.set_option("auto_fallback", 0)
-    nrep = 5 if args.config == 5 else (20 if args.config == 4 else 100)
+    nrep = 5 if cfg == 5 else (20 if cfg == 4 else (30 if light else 100))
     launches = [(c, w) for c in chains for w in range(len(c.names))]
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in launches]
           for _ in range(nrep)]
@@ -400,11 +389,12 @@ def main():
         "moved_GBps": kernels[dom]["moved_GBps"], "frac_vs_measured_copy_bw_6290": kernels[dom]["algo_GBps"] / 6290.0,
         "step_algo_GBps_kernels_alone": step_algo / (sum(k["mean_us"] for k in kernels.values()) * 1e-6) / 1e9,
         "step_algo_GBps_as_timed": step_algo / (elapsed / steps) / 1e9,
+        "step_frac_as_timed": step_algo / (elapsed / steps) / 1e9 / HBM_PEAK_GBS,
         "timing": "HIP events on the launch stream around each launch, mean of %d" % nrep,
     }
     # HBM traffic and VALU instruction counts are PMC measurements of a separate rocprofv3 run (tools/profile.sh):
     # quoted from the committed summary of the same workload, with its provenance, never measured by this run
-    tag = {0: "", 2: "_cfg2", 3: "_cfg3", 4: "_cfg4", 5: "_cfg5"}[args.config]
+    tag = {0: "", 2: "_cfg2", 3: "_cfg3", 4: "_cfg4", 5: "_cfg5", 6: "_cfg6"}[cfg]
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest%s.json" % tag)
     if os.path.exists(pmc_path):
         try:
@@ -415,13 +405,17 @@ def main():
                                          "measured by this run)" % (os.path.basename(pmc_path), allp.get("_tag", "?"))
             if "SQ_INSTS_VALU" in pmc:
                 floor_us = pmc["SQ_INSTS_VALU"] / 1024.0 * 2.08e-3
+                # the N = 8 forward kernels are bound by FP64 VALU issue, not by HBM: the binding
+                # roofline is reported next to the nominal one
                 roofline["fp64_valu_issue"] = {
-                    "valu_insts_per_launch": pmc["SQ_INSTS_VALU"], "issue_floor_ns_per_wave_inst": 2.08,
-                    "floor_us": floor_us, "frac": floor_us / kernels[dom]["mean_us"],
-                    "source": roofline["traffic_source"]}
+                    "bound": "fp64_valu_issue", "valu_insts_per_launch": pmc["SQ_INSTS_VALU"],
+                    "issue_floor_ns_per_wave_inst": 2.08, "floor_us": floor_us,
+                    "frac": floor_us / kernels[dom]["mean_us"], "source": roofline["traffic_source"]}
+                if floor_us / kernels[dom]["mean_us"] > roofline["frac"]:
+                    roofline["binding"] = "fp64_valu_issue"
         except Exception:
             pass
-    if args.config == 5:
+    if cfg == 5:
         # compute-bound: FP64 flops with the reference's cost profile: per problem 2N^2 per mat-vec
         # (iterations + 11 power-iteration products), 2.33 N^3 per factorisation + explicit inverse (3.5 per solve
         # on this family), backward A^T A + LLT + inverse 4.33 N^3
@@ -438,28 +432,30 @@ def main():
             "frac": fl[dom] / (kernels[dom]["mean_us"] * 1e-6) / 1e12 / FP64_PEAK_TFLOPS,
             "note": "this config is FP64-compute-bound (SURVEY.md 8(d)): the HBM fraction above is capped at ~30-55 %",
         }
+        roofline["binding"] = "fp64"
 
     if rank != 0:
-        dist.barrier()
-        dist.destroy_process_group()
-        return
+        del chains
+        torch.cuda.empty_cache()
+        return None
 
     units_per_step = (B_total if scaling == "strong" else sum(c.B for c in chains) * world)
     out = {
-        "metric": "QP+QCQP solves/sec (fwd+bwd)" if args.config != 2 else "QP forward solves/sec",
+        "metric": "QP+QCQP solves/sec (fwd+bwd)" if cfg != 2 else "QP forward solves/sec",
         "value": units_per_step * steps / elapsed, "unit": "solves/s",
-        "n_gpus": world, "steps": steps, "warmup": args.warmup,
+        "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": desc + "; eps=1e-7 max_iter=1000 mu_prox=1e-7",
-            "baseline_config": args.config if args.config else "2'+3 (headline)",
+            "baseline_config": cfg if cfg else "2'+3 (headline)",
             "B_total": B_total if scaling == "strong" else sum(c.B for c in chains) * world,
             "B_this_rank": [c.B for c in chains], "N": [c.N for c in chains],
             "p_layout": "auto (off-diagonals verified in-kernel; non-diagonal tiles go to the general kernel)",
             "launch": "eager, one C-ABI call per pass" + (", the two families on two streams" if side is not None else ""),
             "sharding": ("batch split over the ranks, no data-path collective; RCCL all-gather of x per step"
                          if gather else ("batch shards, no collective" if world > 1 else "single GPU")),
+            "rccl_world": dist.get_world_size() if use_dist else 1,
         },
         "repeats": {"R": len(times), "ms_per_step_median": elapsed / steps * 1e3, "ms_per_step_min": times[0] / steps * 1e3,
                     "ms_per_step_max": times[-1] / steps * 1e3,
@@ -476,6 +472,8 @@ def main():
         from oracle import oracle as O
         cores = O.max_threads()
         n = min(cpu_n, chains[0].B)
+        if light:
+            n = max(n // 4, 256)
         for c in chains:
             c.cpu_solves_per_s(min(n, 512), cores)   # spin up the OpenMP team
         rates = [max(c.cpu_solves_per_s(n, cores) for _ in range(2)) for c in chains]
@@ -488,7 +486,139 @@ def main():
                       "2 passes over the first %d problems of each family of this workload" % n,
             "single_thread_value": one, "single_thread_sample": "same, 1 thread, first %d problems" % n1}
         out["gpu_over_cpu_all_cores"] = out["value"] / tot
-    os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    del chains
+    torch.cuda.empty_cache()
+    return out
+
+
+def condensed(rec):
+    """A per_config sub-record: what VERDICT r2 #4 asks to be driver-measured for every BASELINE config."""
+    rl = rec["roofline"]
+    out = {"workload": rec["config"]["workload"], "ms_per_step": rec["ms_per_step"], "value": rec["value"],
+           "unit": rec["unit"], "steps": rec["steps"], "regions": rec["repeats"]["R"],
+           "ms_per_step_min_max": [rec["repeats"]["ms_per_step_min"], rec["repeats"]["ms_per_step_max"]],
+           "dominant_kernel": rl["kernel"], "dominant_kernel_us": rec["kernels"][rl["kernel"]]["mean_us"],
+           "kernels_us": {k: v["mean_us"] for k, v in rec["kernels"].items()},
+           "roofline": {"bound": rl.get("binding", "hbm"), "hbm_frac": rl["frac"], "hbm_achieved_GBps": rl["achieved"],
+                        "step_hbm_frac_as_timed": rl["step_frac_as_timed"], "traffic": rl.get("traffic")}}
+    if "fp64" in rl:
+        out["roofline"]["fp64_frac"] = rl["fp64"]["frac"]
+        out["roofline"]["fp64_TFLOPs"] = rl["fp64"]["achieved"]
+    if "fp64_valu_issue" in rl:
+        out["roofline"]["fp64_valu_issue_frac"] = rl["fp64_valu_issue"]["frac"]
+    for k in ("without_gather", "cpu_baseline", "parity_max_abs_err_vs_oracle_sample", "gpu_over_cpu_all_cores"):
+        if k in rec:
+            out[k] = rec[k]
+    return out
+
+
+def dense_p_record(args, ctx):
+    """Dense 8x8 P (what a real contact problem presents) at the bench's batch size, QCQP forward + backward through
+    DQQ_P_AUTO (what QCQPFn2 passes) against DQQ_P_DENSE (the cliff must not come back)."""
+    dev = ctx["dev"]
+    sh = torch.cuda.current_stream().cuda_stream
+    rec = {}
+    for name, layout in (("auto", 0), ("dense", 1)):
+        c = Chain("qcqp", 65536, 8, "dense", True, dev, 4242, layout=layout)
+        for _ in range(3):
+            c.run(sh)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(10):
+                c.run(sh)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / 10)
+        rec[name + "_ms_per_fwd_bwd"] = sorted(ts)[1] * 1e3
+        if layout == 0 and not args.no_check:
+            rec["parity_max_abs_err_vs_oracle_sample"] = c.check(1024)
+        del c
+        torch.cuda.empty_cache()
+    rec["auto_over_dense"] = rec["auto_ms_per_fwd_bwd"] / rec["dense_ms_per_fwd_bwd"]
+    rec["workload"] = "B=65536 N=8 QCQP, P = S S^T/8 + 0.1 I (dense), forward+backward, one stream, median of 3 x 10 passes"
+    return rec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, default=None, choices=(0, 2, 3, 4, 5),
+                    help="BASELINE.json configs entry (1-based); 0 = the headline step (configs 2'+3).  Default: the "
+                         "headline on one GPU; with WORLD_SIZE > 1, configs[3] (the batch split over the ranks + RCCL "
+                         "all-gather) with the weak-scaling headline as a sub-record")
+    ap.add_argument("--repeats", type=int, default=10, help="timed regions of exactly --steps steps; the median is reported")
+    ap.add_argument("--streams", type=int, default=2, choices=(1, 2),
+                    help="headline only: 2 = the QP chain and the QCQP chain on two HIP streams")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-cold", action="store_true")
+    ap.add_argument("--no-per-config", action="store_true", help="default run only: skip the per_config sub-records")
+    args = ap.parse_args()
+
+    # Everything the native libraries print on stdout (RCCL prints its version banner there) goes to
+    # stderr; the one JSON line is written to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs the GPU (the hot path is a HIP kernel; there is no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    # DQQ_BENCH_FORCE_DIST=1 exercises the RCCL path (init, barrier, all-gather) with a single rank
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ   # under torch.distributed.run (any world size)
+    use_dist = world > 1 or os.environ.get("DQQ_BENCH_FORCE_DIST") == "1" or launched
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL
+
+    from diffqcqp_amd import build, _capi, parallel
+    if rank == 0:
+        build.build()
+    if use_dist:
+        dist.barrier()
+    _capi.lib()
+    ctx = {"rank": rank, "world": world, "dev": dev, "use_dist": use_dist, "dist": dist, "parallel": parallel,
+           "capi": _capi, "side": torch.cuda.Stream()}
+
+    default_run = args.config is None
+    # With more than one rank (or under torch.distributed.run) and no --config, the line is the workload north_star
+    # names for multi-GPU: configs[3], B=262144 N=32 split over the ranks with the RCCL all-gather of x
+    primary = args.config if args.config is not None else (4 if launched or world > 1 else 0)
+    out = measure(primary, args, ctx)
+    if default_run:
+        if primary == 4:
+            sub = measure(0, args, ctx, light=True)
+            if rank == 0:
+                out["weak_headline"] = condensed(sub)
+                out["weak_headline"]["note"] = "per GPU and step: the single-GPU headline workload on every rank, no " \
+                                               "collective (weak scaling); value = all ranks"
+        elif not args.no_per_config:
+            per = {}
+            for cfg in (2, 3, 4, 5):
+                per["config_%d" % cfg] = condensed(measure(cfg, args, ctx, light=True))
+            out["per_config"] = per
+            out["per_config_note"] = "BASELINE.json configs 2-5 (1-based) measured by THIS run: 3 regions each, HIP-event " \
+                                     "kernel durations, roofline fractions, CPU baseline on a bounded sample; config_4 is " \
+                                     "the whole B=262144 batch on this one GPU"
+            out["dense_p_n8"] = dense_p_record(args, ctx)
+    if rank == 0:
+        out["environment"] = gpu_environment()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
