@@ -31,6 +31,7 @@ _vp, _i, _d, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.
 # name -> argtypes, in the order of include/diffqcqp_hip.h
 SIGNATURES = {
     "dqq_workspace_bytes": ([_i64], _sz),
+    "dqq_scratch_bytes": ([_i, _i, _i, _i64], _sz),
     "dqq_max_n": ([_i], _i),
     "dqq_qp_fwd_f64": ([_vp, _vp, _vp, _i64, _i, _d, _d, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp], _i),
     "dqq_qp_bwd_f64": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp], _i),

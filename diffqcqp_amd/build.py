@@ -47,8 +47,21 @@ def _sources():
     return deps
 
 
+STAMP = os.path.join(LIBDIR, "build_flags.txt")
+
+
+def _flag_stamp():
+    """Everything besides the sources that decides what the library contains (DQQ_EXTRA_FLAGS: developer -D flags)."""
+    return " ".join(COMMON) + " | " + os.environ.get("DQQ_EXTRA_FLAGS", "")
+
+
 def needs_build():
     if not os.path.exists(LIB):
+        return True
+    try:
+        if open(STAMP).read() != _flag_stamp():
+            return True   # built with other flags (e.g. an experiment's -D...): never reuse it silently
+    except OSError:
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(p) > t for p in _sources() + [os.path.abspath(__file__)])
@@ -77,6 +90,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(_flag_stamp())
     return LIB
 
 

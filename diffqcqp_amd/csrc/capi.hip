@@ -47,10 +47,23 @@ int check_common(int64_t B, int N, int p_layout, bool qcqp)
     return 0;
 }
 
-int check_ws(const void* ws, size_t bytes, int64_t B)
+int check_ws(const void* ws, size_t bytes, int64_t B, size_t scratch_bytes = 0)
 {
-    if (ws == nullptr || bytes < dqq_workspace_bytes(B)) return DQQ_E_WORKSPACE;
+    if (ws == nullptr || bytes < dqq_workspace_bytes(B) + scratch_bytes) return DQQ_E_WORKSPACE;
     return 0;
+}
+
+// the scratch slice behind the work-list (dqq_scratch_bytes)
+double* scratch_of(void* ws, int64_t B)
+{
+    return reinterpret_cast<double*>(static_cast<char*>(ws) + dqq_workspace_bytes(B));
+}
+
+// A launch of the work-list chain failed: the entries the fast kernel queued will never be drained.  Re-zero the header
+// so that the stale count cannot leak into the next call on this workspace (best effort; the error is what is returned).
+void reset_worklist(void* ws, hipStream_t s)
+{
+    if (ws != nullptr) (void)hipMemsetAsync(ws, 0, sizeof(int) * dqq::kWsEntries, s);
 }
 
 } // namespace
@@ -63,6 +76,14 @@ size_t dqq_workspace_bytes(int64_t B)
     size_t n = (size_t)dqq::kWsEntries + (size_t)B;
     n = (n + 63) & ~(size_t)63;
     return n * sizeof(int);
+}
+
+size_t dqq_scratch_bytes(int kind, int pass, int N, int64_t B)
+{
+    if (B <= 0 || N < 1 || kind < 0 || kind > 3 || (pass != 0 && pass != 1)) return 0;
+    if (pass == 0) return dqq::fwd_needs_any(kind, N) ? dqq::any_scratch_bytes(kind, false, N, (long)B) : 0;
+    if (kind == dqq::kKindSignedBox) return 0; // no backward
+    return dqq::bwd_needs_any(kind, N) ? dqq::any_scratch_bytes(kind, true, N, (long)B) : 0;
 }
 
 int dqq_max_n(int kind) { return dqq::dense_max_n(kind); }
@@ -96,23 +117,32 @@ static int fwd_dispatch(int kind, dqq::FwdArgs& a, void* workspace, size_t works
         if (!fast_ok) return DQQ_E_UNSUPPORTED_N;
         return (int)dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), g_fuse.load(), s, nullptr);
     }
+    const size_t scratch = dqq_scratch_bytes(kind, 0, a.N, a.B); // > 0: the global-memory kernels take the call
     if (a.layout == DQQ_P_DENSE || !fast_ok) {
         if (a.layout == DQQ_P_DENSE && fast_ok && dqq::g_lane_dense.load() != 0 && g_fuse.load() != 0 &&
             dqq::fwd_diag_takes_dense(kind, a.N, a.B))
             return (int)dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), 1, s, nullptr);
         if (!dense_ok) return DQQ_E_UNSUPPORTED_N;
+        if (scratch > 0) {
+            if (int rc = check_ws(workspace, workspace_bytes, a.B, scratch)) return rc;
+            a.scratch = scratch_of(workspace, a.B);
+        }
         return (int)dqq::launch_fwd_dense(kind, a, false, s);
     }
     // DQQ_P_AUTO: fast path over every tile; non-diagonal tiles are solved inside it (small N) or
     // queued for the dense kernel launched right behind it
-    if (int rc = check_ws(workspace, workspace_bytes, a.B)) return rc;
+    if (int rc = check_ws(workspace, workspace_bytes, a.B, scratch)) return rc;
     a.ws = static_cast<int*>(workspace);
+    if (scratch > 0) a.scratch = scratch_of(workspace, a.B);
     const bool fused = dqq::fwd_diag_will_fuse(a.N, a.B, a.layout, g_fuse.load());
     if (!fused && !dense_ok) return DQQ_E_UNSUPPORTED_N; // a queued tile would never be solved: refuse up front
     bool needs_fallback = true;
     hipError_t e = dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), g_fuse.load(), s, &needs_fallback);
     if (e != hipSuccess) return (int)e;
-    if (needs_fallback && g_auto_fallback.load() != 0) e = dqq::launch_fwd_dense(kind, a, true, s);
+    if (needs_fallback && g_auto_fallback.load() != 0) {
+        e = dqq::launch_fwd_dense(kind, a, true, s);
+        if (e != hipSuccess) reset_worklist(workspace, s);
+    }
     return (int)e;
 }
 
@@ -125,18 +155,27 @@ static int bwd_dispatch(int kind, dqq::BwdArgs& a, void* workspace, size_t works
         if (!fast_ok) return DQQ_E_UNSUPPORTED_N;
         return (int)dqq::launch_bwd_diag(kind, a, g_wpb.load(), g_fuse.load(), s, nullptr);
     }
+    const size_t scratch = dqq_scratch_bytes(kind, 1, a.N, a.B);
     if (a.layout == DQQ_P_DENSE || !fast_ok) {
         if (!dense_ok) return DQQ_E_UNSUPPORTED_N;
+        if (scratch > 0) {
+            if (int rc = check_ws(workspace, workspace_bytes, a.B, scratch)) return rc;
+            a.scratch = scratch_of(workspace, a.B);
+        }
         return (int)dqq::launch_bwd_dense(kind, a, false, s);
     }
-    if (int rc = check_ws(workspace, workspace_bytes, a.B)) return rc;
+    if (int rc = check_ws(workspace, workspace_bytes, a.B, scratch)) return rc;
     a.ws = static_cast<int*>(workspace);
+    if (scratch > 0) a.scratch = scratch_of(workspace, a.B);
     const bool fused = dqq::bwd_diag_will_fuse(kind, a.N, a.B, a.layout, g_fuse.load());
     if (!fused && !dense_ok) return DQQ_E_UNSUPPORTED_N; // (box QP, N > 32): nothing could drain the work-list
     bool needs_fallback = true;
     hipError_t e = dqq::launch_bwd_diag(kind, a, g_wpb.load(), g_fuse.load(), s, &needs_fallback);
     if (e != hipSuccess) return (int)e;
-    if (needs_fallback && g_auto_fallback.load() != 0) e = dqq::launch_bwd_dense(kind, a, true, s);
+    if (needs_fallback && g_auto_fallback.load() != 0) {
+        e = dqq::launch_bwd_dense(kind, a, true, s);
+        if (e != hipSuccess) reset_worklist(workspace, s);
+    }
     return (int)e;
 }
 

@@ -63,43 +63,66 @@ __global__ __launch_bounds__(kAnyT) void bwd_any_kernel(
 }
 
 // persistent grid: two workgroups per CU when the batch is that large -- fewer when their scratch slices
-// (stride doubles each) would not fit a 4 GiB budget (N in the thousands)
-static unsigned any_grid(long B, bool use_worklist, long stride)
+// (stride doubles each) would not fit a 4 GiB budget (N in the thousands).  A function of (stride, B) only, in
+// work-list mode too (the list cannot hold more than B entries): the caller sizes the scratch from it.
+static unsigned any_grid(long B, long stride)
 {
     long cap = 512;
     const long budget = (4L << 30) / (8 * (stride > 0 ? stride : 1));
     if (cap > budget) cap = budget > 0 ? budget : 1;
-    return use_worklist ? (unsigned)cap : (unsigned)(B < cap ? (B > 0 ? B : 1) : cap);
+    return (unsigned)(B < cap ? (B > 0 ? B : 1) : cap);
 }
 
+static long any_fwd_stride(int N)
+{
+    const long mat = any_mat_doubles(N), vec = any_fwd_vec_doubles(N);
+    return (sizeof(double) * 2 * (size_t)mat <= kAnyLdsBytes) ? ((vec + 1) & ~1L) : ((2 * mat + vec + 1) & ~1L);
+}
+
+static long any_bwd_stride(int kind, int N)
+{
+    const int k = kind == kKindQP ? 0 : (kind == kKindQCQP ? 1 : 2);
+    const long mat = any_mat_doubles(any_bwd_rows(k, N)), vec = any_bwd_vec_doubles(k, N);
+    return (sizeof(double) * 2 * (size_t)mat <= kAnyLdsBytes) ? ((mat + vec + 1) & ~1L) : ((3 * mat + vec + 1) & ~1L);
+}
+
+size_t any_scratch_bytes(int kind, bool backward, int N, long B)
+{
+    if (B <= 0) return 0;
+    const long stride = backward ? any_bwd_stride(kind, N) : any_fwd_stride(N);
+    return sizeof(double) * (size_t)stride * any_grid(B, stride);
+}
+
+// The sizes beyond the register / LDS kernels of the general path (dqq_max_n): independent of the tuning knobs, so that
+// dqq_scratch_bytes is a function of (kind, pass, N, B) alone.
+bool fwd_needs_any(int kind, int N) { return N > dense_max_n(kind == kKindQCQP ? 1 : 0); }
+bool bwd_needs_any(int kind, int N) { return N > dense_max_n(kind == kKindQP ? 0 : (kind == kKindBox ? 3 : 2)); }
+
 template <typename Kern, typename... Args>
-static hipError_t launch_any(Kern kernel, size_t lds_bytes, long stride, long B, bool use_worklist, hipStream_t s,
+static hipError_t launch_any(Kern kernel, size_t lds_bytes, long stride, long B, double* scratch, hipStream_t s,
                              Args... args)
 {
-    const unsigned grid = any_grid(B, use_worklist, stride);
+    if (scratch == nullptr) return hipErrorInvalidValue; // capi.hip checks the workspace before it gets here
+    const unsigned grid = any_grid(B, stride);
     if (lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    double* scratch = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(double) * (size_t)stride * grid, s);
-    if (e != hipSuccess) return e;
-    e = launch(kernel, dim3(grid), dim3(kAnyT), lds_bytes, s, args..., scratch, stride);
-    const hipError_t f = hipFreeAsync(scratch, s);
-    return e != hipSuccess ? e : f;
+    return launch(kernel, dim3(grid), dim3(kAnyT), lds_bytes, s, args..., scratch, stride);
 }
 
 template <int KIND>
 static hipError_t launch_fwd_any_kind(const FwdArgs& a, bool use_worklist, hipStream_t s)
 {
-    const long mat = any_mat_doubles(a.N), vec = any_fwd_vec_doubles(a.N);
+    const long mat = any_mat_doubles(a.N);
     const size_t lds = sizeof(double) * 2 * (size_t)mat;
     const int wl = use_worklist ? 1 : 0;
+    const long stride = any_fwd_stride(a.N);
     if (lds <= kAnyLdsBytes)
-        return launch_any(fwd_any_kernel<KIND, true>, lds, (vec + 1) & ~1L, a.B, use_worklist, s, a.P, a.q, a.l_n, a.mu,
+        return launch_any(fwd_any_kernel<KIND, true>, lds, stride, a.B, a.scratch, s, a.P, a.q, a.l_n, a.mu,
                           a.v, a.x, a.B, a.N, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, wl);
-    return launch_any(fwd_any_kernel<KIND, false>, 0, (2 * mat + vec + 1) & ~1L, a.B, use_worklist, s, a.P, a.q, a.l_n,
+    return launch_any(fwd_any_kernel<KIND, false>, 0, stride, a.B, a.scratch, s, a.P, a.q, a.l_n,
                       a.mu, a.v, a.x, a.B, a.N, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, wl);
 }
 
@@ -118,14 +141,15 @@ hipError_t launch_fwd_any(int kind, const FwdArgs& a, bool use_worklist, hipStre
 template <int KIND>
 static hipError_t launch_bwd_any_kind(const BwdArgs& a, bool use_worklist, hipStream_t s)
 {
-    const long mat = any_mat_doubles(any_bwd_rows(KIND, a.N)), vec = any_bwd_vec_doubles(KIND, a.N);
+    const long mat = any_mat_doubles(any_bwd_rows(KIND, a.N));
     const size_t lds = sizeof(double) * 2 * (size_t)mat;
     const int wl = use_worklist ? 1 : 0;
+    const long stride = any_bwd_stride(KIND == 0 ? kKindQP : (KIND == 1 ? kKindQCQP : kKindBox), a.N);
     if (lds <= kAnyLdsBytes)
-        return launch_any(bwd_any_kernel<KIND, true>, lds, (mat + vec + 1) & ~1L, a.B, use_worklist, s, a.P, a.q, a.l_n,
+        return launch_any(bwd_any_kernel<KIND, true>, lds, stride, a.B, a.scratch, s, a.P, a.q, a.l_n,
                           a.mu, a.x, a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.N,
                           a.epsilon, a.ir_steps, a.ws, wl);
-    return launch_any(bwd_any_kernel<KIND, false>, 0, (3 * mat + vec + 1) & ~1L, a.B, use_worklist, s, a.P, a.q, a.l_n,
+    return launch_any(bwd_any_kernel<KIND, false>, 0, stride, a.B, a.scratch, s, a.P, a.q, a.l_n,
                       a.mu, a.x, a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.N,
                       a.epsilon, a.ir_steps, a.ws, wl);
 }

@@ -106,6 +106,7 @@ struct FwdArgs {
     int* ws;
     double* pdiag_out;         // optional (B,N): the diagonal of P, for the backward of the same problems
     unsigned char* flags_out;  // optional (B): 1 = the problem's tile was verified diagonal
+    double* scratch = nullptr; // caller's scratch behind the work-list (dqq_scratch_bytes), global-memory kernels only
 };
 
 struct BwdArgs {
@@ -129,6 +130,7 @@ struct BwdArgs {
     int layout;
     int* ir_steps;
     int* ws;
+    double* scratch = nullptr; // see FwdArgs
 };
 
 // Which N can solve their non-diagonal tiles inside the fast kernel (no fallback launch: an empty
@@ -178,6 +180,10 @@ bool fwd_dense_block_supported(int N);
 hipError_t launch_fwd_dense_block(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s);
 hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);
 // workgroup-per-problem kernels with the matrices in global memory: any N (general_any.hip)
+// bytes of scratch those kernels need for (kind, N, B): a slice per workgroup of a grid that depends on (N, B) only
+size_t any_scratch_bytes(int kind, bool backward, int N, long B);
+bool fwd_needs_any(int kind, int N); // does a call of this size reach them (whatever the tuning knobs say)
+bool bwd_needs_any(int kind, int N);
 hipError_t launch_fwd_any(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s);
 hipError_t launch_bwd_any(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);
 // statically sized team backward for even N <= 16, QP / QCQP (bwd_small.hip); launch_bwd_dense routes to it

@@ -33,17 +33,29 @@ class _device_guard:
             self.ctx.__exit__(*a)
 
 
-def _workspace(device, B, stream=None):
-    """Zero-initialised fallback work-list, cached per (device, stream); the kernels leave it empty again
-    (include/diffqcqp_hip.h: dqq_workspace_bytes)."""
+_MAX_WORKSPACES = 16   # cached (device, stream) pairs; the least recently used one is dropped beyond that
+
+
+def _workspace(device, B, stream=None, kind=0, pas=0, N=8):
+    """Zero-initialised fallback work-list (+ the scratch of the global-memory kernels behind it, when (kind, pas, N)
+    needs any), cached per (device, stream); the kernels leave the work-list empty again
+    (include/diffqcqp_hip.h: dqq_workspace_bytes, dqq_scratch_bytes)."""
     if stream is None:
         stream = _raw_stream(device.index)
     key = (device.index, stream)
+    lib = _capi.lib()
+    need = lib.dqq_workspace_bytes(int(B))
+    if N > 21:  # dqq_max_n: nothing below needs scratch
+        need += lib.dqq_scratch_bytes(int(kind), int(pas), int(N), int(B))
     ws = _workspaces.get(key)
-    if ws is None or ws.numel() < B + 64:
-        need = _capi.lib().dqq_workspace_bytes(int(B))
-        ws = torch.zeros(max(need // 4, 1024), dtype=torch.int32, device=device)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.zeros(max((need + 3) // 4, 1024), dtype=torch.int32, device=device)
+        _workspaces.pop(key, None)
         _workspaces[key] = ws
+        while len(_workspaces) > _MAX_WORKSPACES:
+            _workspaces.pop(next(iter(_workspaces)))
+    elif len(_workspaces) > 1:
+        _workspaces[key] = _workspaces.pop(key)  # most recently used last
     return ws
 
 
@@ -61,6 +73,16 @@ def _prep(t, name, shape=None):
     t = t.detach().contiguous()
     if shape is not None and tuple(t.shape) != tuple(shape):
         raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+    return t
+
+
+def _out(t, shape, name):
+    """A caller-provided output buffer: the kernels write float64 into it, so anything else must be refused here."""
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype is torch.float64 and t.is_contiguous() and tuple(t.shape) == tuple(shape)):
+        raise ValueError("%s must be a contiguous float64 GPU tensor of shape %s (got %s %s on %s)"
+                         % (name, tuple(shape), t.dtype, tuple(t.shape), t.device))
     return t
 
 
@@ -83,10 +105,10 @@ def qp_forward(P, q, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, layout=_cap
     cache: optional `diag_cache(q)` buffers; pass the same pair to qp_backward (P must be unchanged)."""
     B, N, pshape = _dims(P, q, layout)
     P, q = _prep(P, "P", pshape), _prep(q, "q", (B, N, 1))
-    x = out if out is not None else torch.empty((B, N, 1), dtype=torch.float64, device=q.device)
+    x = _out(out, (B, N, 1), "out") if out is not None else torch.empty((B, N, 1), dtype=torch.float64, device=q.device)
     iters = torch.empty(B, dtype=torch.int32, device=q.device) if return_iters else None
     stream = _raw_stream(q.device.index)
-    ws = _workspace(q.device, B, stream)
+    ws = _workspace(q.device, B, stream, 0, 0, N)
     with _device_guard(q.device):
         pd, fl = cache if cache is not None else (None, None)
         rc = _capi.lib().dqq_qp_fwd_f64(_ptr(P), _ptr(q), _ptr(x), B, N, float(eps), float(mu_prox), int(max_iter),
@@ -102,10 +124,10 @@ def qcqp_forward(P, q, l_n, mu, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, 
     B, N, pshape = _dims(P, q, layout)
     P, q = _prep(P, "P", pshape), _prep(q, "q", (B, N, 1))
     l_n, mu = _prep(l_n, "l_n", (B, N // 2, 1)), _prep(mu, "mu", (B, N // 2, 1))
-    x = out if out is not None else torch.empty((B, N, 1), dtype=torch.float64, device=q.device)
+    x = _out(out, (B, N, 1), "out") if out is not None else torch.empty((B, N, 1), dtype=torch.float64, device=q.device)
     iters = torch.empty(B, dtype=torch.int32, device=q.device) if return_iters else None
     stream = _raw_stream(q.device.index)
-    ws = _workspace(q.device, B, stream)
+    ws = _workspace(q.device, B, stream, 1, 0, N)
     with _device_guard(q.device):
         pd, fl = cache if cache is not None else (None, None)
         rc = _capi.lib().dqq_qcqp_fwd_f64(_ptr(P), _ptr(q), _ptr(l_n), _ptr(mu), _ptr(x), B, N, float(eps),
@@ -122,10 +144,10 @@ def boxqp_forward(P, q, l_min, l_max, eps, max_iter, v=None, mu_prox=1e-7, adapt
     B, N, pshape = _dims(P, q, layout)
     P, q = _prep(P, "P", pshape), _prep(q, "q", (B, N, 1))
     l_min, l_max = _prep(l_min, "l_min", (B, N, 1)), _prep(l_max, "l_max", (B, N, 1))
-    x = out if out is not None else torch.empty((B, N, 1), dtype=torch.float64, device=q.device)
+    x = _out(out, (B, N, 1), "out") if out is not None else torch.empty((B, N, 1), dtype=torch.float64, device=q.device)
     iters = torch.empty(B, dtype=torch.int32, device=q.device) if return_iters else None
     stream = _raw_stream(q.device.index)
-    ws = _workspace(q.device, B, stream)
+    ws = _workspace(q.device, B, stream, 2 if v is None else 3, 0, N)
     with _device_guard(q.device):
         pd, fl = cache if cache is not None else (None, None)
         tail = (B, N, float(eps), float(mu_prox), int(max_iter), int(bool(adaptive_rho)), layout, _ptr(iters), _ptr(pd),
@@ -149,13 +171,13 @@ def qp_backward(P, q, x, grad_x, need_P=True, need_q=True, layout=_capi.P_AUTO, 
     x, grad_x = _prep(x, "x", (B, N, 1)), _prep(grad_x, "grad_x", (B, N, 1))
     dev = q.device
     if out is not None:
-        gP, gq = out
+        gP, gq = _out(out[0], pshape, "out[0]"), _out(out[1], (B, N, 1), "out[1]")
     else:
         gP = torch.empty(pshape, dtype=torch.float64, device=dev) if need_P else None
         gq = torch.empty((B, N, 1), dtype=torch.float64, device=dev) if need_q else None
     steps = torch.empty(B, dtype=torch.int32, device=dev) if return_steps else None
     stream = _raw_stream(dev.index)
-    ws = _workspace(dev, B, stream)
+    ws = _workspace(dev, B, stream, 0, 1, N)
     with _device_guard(dev):
         pd, fl = cache if cache is not None else (None, None)
         rc = _capi.lib().dqq_qp_bwd_f64(_ptr(P), _ptr(q), _ptr(x), _ptr(grad_x), _ptr(gP), _ptr(gq), B, N,
@@ -176,7 +198,8 @@ def qcqp_backward(P, q, l_n, mu, x, grad_x, need=(True, True, True, True), layou
     x, grad_x = _prep(x, "x", (B, N, 1)), _prep(grad_x, "grad_x", (B, N, 1))
     dev = q.device
     if out is not None:
-        gP, gq, gl, gm = out
+        gP, gq = _out(out[0], pshape, "out[0]"), _out(out[1], (B, N, 1), "out[1]")
+        gl, gm = _out(out[2], (B, N // 2, 1), "out[2]"), _out(out[3], (B, N // 2, 1), "out[3]")
     else:
         gP = torch.empty(pshape, dtype=torch.float64, device=dev) if need[0] else None
         gq = torch.empty((B, N, 1), dtype=torch.float64, device=dev) if need[1] else None
@@ -184,7 +207,7 @@ def qcqp_backward(P, q, l_n, mu, x, grad_x, need=(True, True, True, True), layou
         gm = torch.empty((B, N // 2, 1), dtype=torch.float64, device=dev) if need[3] else None
     steps = torch.empty(B, dtype=torch.int32, device=dev) if return_steps else None
     stream = _raw_stream(dev.index)
-    ws = _workspace(dev, B, stream)
+    ws = _workspace(dev, B, stream, 1, 1, N)
     with _device_guard(dev):
         gam, dgam = duals if duals is not None else (None, None)
         pd, fl = cache if cache is not None else (None, None)
@@ -207,7 +230,8 @@ def boxqp_backward(P, q, l_min, l_max, x, grad_x, need=(True, True, True, True),
     x, grad_x = _prep(x, "x", (B, N, 1)), _prep(grad_x, "grad_x", (B, N, 1))
     dev = q.device
     if out is not None:
-        gP, gq, glo, ghi = out
+        gP, gq = _out(out[0], pshape, "out[0]"), _out(out[1], (B, N, 1), "out[1]")
+        glo, ghi = _out(out[2], (B, N, 1), "out[2]"), _out(out[3], (B, N, 1), "out[3]")
     else:
         gP = torch.empty(pshape, dtype=torch.float64, device=dev) if need[0] else None
         gq = torch.empty((B, N, 1), dtype=torch.float64, device=dev) if need[1] else None
@@ -215,7 +239,7 @@ def boxqp_backward(P, q, l_min, l_max, x, grad_x, need=(True, True, True, True),
         ghi = torch.empty((B, N, 1), dtype=torch.float64, device=dev) if need[3] else None
     steps = torch.empty((B, 2), dtype=torch.int32, device=dev) if return_steps else None
     stream = _raw_stream(dev.index)
-    ws = _workspace(dev, B, stream)
+    ws = _workspace(dev, B, stream, 2, 1, N)
     with _device_guard(dev):
         gam, dgam = duals if duals is not None else (None, None)
         pd, fl = cache if cache is not None else (None, None)

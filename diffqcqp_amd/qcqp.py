@@ -30,11 +30,32 @@ torch.set_default_dtype(torch.double)
 
 _FAST_N = (2, 4, 8, 16, 32, 64)
 
+# How the Functions below hand P to the C ABI (include/diffqcqp_hip.h: p_layout).  "auto" (default): every tile's
+# off-diagonals are verified in-kernel, diagonal tiles take the fast path, the others the general kernels -- nothing is
+# assumed.  "dense": straight to the general kernels, for callers who know their P is dense (a Delassus matrix): saves
+# the verifying pass.  A module-level default because the reference's signatures (qcqp.py:24, 144) have no slot for it.
+_LAYOUTS = {"auto": ops._capi.P_AUTO, "dense": ops._capi.P_DENSE}
+_default_layout = ops._capi.P_AUTO
+
+
+def set_default_layout(layout):
+    """layout: "auto" or "dense".  Returns the previous setting (as a string)."""
+    global _default_layout
+    prev = [k for k, v in _LAYOUTS.items() if v == _default_layout][0]
+    if layout not in _LAYOUTS:
+        raise ValueError("layout must be one of %s" % sorted(_LAYOUTS))
+    _default_layout = _LAYOUTS[layout]
+    return prev
+
+
+def get_default_layout():
+    return [k for k, v in _LAYOUTS.items() if v == _default_layout][0]
+
 
 def _cache_for(ctx, qd, n_inputs):
     """Buffers for the verified diagonal of P (forward -> backward of the same problems), only when a backward
     can follow (some input requires grad) and the diagonal fast path exists for this N."""
-    if qd.shape[1] in _FAST_N and any(ctx.needs_input_grad[:n_inputs]):
+    if _default_layout == ops._capi.P_AUTO and qd.shape[1] in _FAST_N and any(ctx.needs_input_grad[:n_inputs]):
         return ops.diag_cache(qd)
     return None
 
@@ -61,9 +82,10 @@ class QPFn2(Function):
             dev = _device_for(q)
             Pd, qd = P.detach().to(dev), q.detach().to(dev)
         cache = _cache_for(ctx, qd, 2)  # verified diagonal of P, reused by backward instead of re-reading P
-        l_2 = ops.qp_forward(Pd, qd, eps, max_iter, mu_prox, adaptive_rho=True, cache=cache)
+        l_2 = ops.qp_forward(Pd, qd, eps, max_iter, mu_prox, adaptive_rho=True, cache=cache, layout=_default_layout)
         ctx.save_for_backward(Pd, qd, l_2, *(cache or ()))
         ctx.home = q.device
+        ctx.layout = _default_layout  # the backward of these problems takes the same route
         return l_2 if q.is_cuda else l_2.to(q.device)
 
     @staticmethod
@@ -73,7 +95,7 @@ class QPFn2(Function):
         need_P, need_q = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         grad_P, grad_q = None, None
         if need_P or need_q:
-            grad_P, grad_q = ops.qp_backward(P, q, l, grad_l.to(l.device), need_P, need_q, cache=_saved_cache(saved))
+            grad_P, grad_q = ops.qp_backward(P, q, l, grad_l.to(l.device), need_P, need_q, cache=_saved_cache(saved), layout=ctx.layout)
             if ctx.home != l.device:
                 grad_P = None if grad_P is None else grad_P.to(ctx.home)
                 grad_q = None if grad_q is None else grad_q.to(ctx.home)
@@ -90,9 +112,10 @@ class QCQPFn2(Function):
             Pd, qd = P.detach().to(dev), q.detach().to(dev)
             lnd, mud = l_n.detach().to(dev), mu.detach().to(dev)
         cache = _cache_for(ctx, qd, 4)
-        l_2 = ops.qcqp_forward(Pd, qd, lnd, mud, eps, max_iter, mu_prox, adaptive_rho=True, cache=cache)
+        l_2 = ops.qcqp_forward(Pd, qd, lnd, mud, eps, max_iter, mu_prox, adaptive_rho=True, cache=cache, layout=_default_layout)
         ctx.save_for_backward(Pd, qd, lnd, mud, l_2, *(cache or ()))
         ctx.home = q.device
+        ctx.layout = _default_layout  # the backward of these problems takes the same route
         return l_2 if q.is_cuda else l_2.to(q.device)
 
     @staticmethod
@@ -102,7 +125,7 @@ class QCQPFn2(Function):
         need = tuple(ctx.needs_input_grad[0:4])
         grads = (None, None, None, None)
         if any(need):
-            grads = ops.qcqp_backward(P, q, l_n, mu, l, grad_l.to(l.device), need, cache=_saved_cache(saved))
+            grads = ops.qcqp_backward(P, q, l_n, mu, l, grad_l.to(l.device), need, cache=_saved_cache(saved), layout=ctx.layout)
             if ctx.home != l.device:
                 grads = tuple(None if g is None else g.to(ctx.home) for g in grads)
         return grads + (None, None, None, None)
@@ -125,9 +148,10 @@ class BoxQPFn2(Function):
             dev = _device_for(q)
             Pd, qd, lod, hid = (t.detach().to(dev) for t in tensors)
         cache = _cache_for(ctx, qd, 4)
-        l_2 = ops.boxqp_forward(Pd, qd, lod, hid, eps, max_iter, mu_prox=mu_prox, adaptive_rho=True, cache=cache)
+        l_2 = ops.boxqp_forward(Pd, qd, lod, hid, eps, max_iter, mu_prox=mu_prox, adaptive_rho=True, cache=cache, layout=_default_layout)
         ctx.save_for_backward(Pd, qd, lod, hid, l_2, *(cache or ()))
         ctx.home = q.device
+        ctx.layout = _default_layout  # the backward of these problems takes the same route
         return l_2 if q.is_cuda else l_2.to(q.device)
 
     @staticmethod
@@ -137,7 +161,7 @@ class BoxQPFn2(Function):
         need = tuple(ctx.needs_input_grad[0:4])
         grads = (None, None, None, None)
         if any(need):
-            grads = ops.boxqp_backward(P, q, l_min, l_max, l, grad_l.to(l.device), need, cache=_saved_cache(saved))
+            grads = ops.boxqp_backward(P, q, l_min, l_max, l, grad_l.to(l.device), need, cache=_saved_cache(saved), layout=ctx.layout)
             if ctx.home != l.device:
                 grads = tuple(None if g is None else g.to(ctx.home) for g in grads)
         return grads + (None, None, None, None)
@@ -156,7 +180,8 @@ class SignedBoxQPFn2(Function):
         else:
             dev = _device_for(q)
             Pd, qd, lod, hid, vd = (t.detach().to(dev) for t in tensors)
-        l_2 = ops.boxqp_forward(Pd, qd, lod, hid, eps, max_iter, v=vd, mu_prox=mu_prox, adaptive_rho=True)
+        l_2 = ops.boxqp_forward(Pd, qd, lod, hid, eps, max_iter, v=vd, mu_prox=mu_prox, adaptive_rho=True,
+                                layout=_default_layout)
         return l_2 if q.is_cuda else l_2.to(q.device)
 
     @staticmethod

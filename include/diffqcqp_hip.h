@@ -64,11 +64,20 @@ extern "C" {
  * streams. */
 size_t dqq_workspace_bytes(int64_t B);
 
+/* The C ABI never allocates: every buffer, scratch included, is the caller's.  For sizes beyond the register / LDS
+ * kernels of the general path (N > dqq_max_n(..), below) a workgroup-per-problem kernel works out of global memory and
+ * needs this many bytes of scratch IN ADDITION to dqq_workspace_bytes(B), in the same `workspace` buffer (the work-list
+ * first, the scratch behind it; no initialisation needed).  kind: 0 QP, 1 QCQP, 2 box QP, 3 signed box QP; pass: 0
+ * forward, 1 backward.  A function of its arguments alone; 0 for every size the register / LDS kernels hold (all
+ * BASELINE configs).  A call whose workspace is smaller than dqq_workspace_bytes(B) + dqq_scratch_bytes(..) returns
+ * DQQ_E_WORKSPACE -- with DQQ_P_DENSE too, which otherwise needs no workspace at all.  Since nothing is allocated
+ * or freed, a forward + backward pair can be captured into a HIP graph (tests/test_gpu_graph_capture.py). */
+size_t dqq_scratch_bytes(int kind, int pass, int N, int64_t B);
+
 /* There is no size limit (the reference has none, Solver.cpp:61): this returns the largest N the register / LDS
  * kernels of the general path hold -- kind 0 = QP forward/backward and the box forwards (64), 1 = QCQP forward (64),
  * 2 = QCQP backward (42), 3 = box QP backward (21).  Beyond it a workgroup-per-problem kernel works out of global
- * memory, in the reference's operation order, on scratch it takes from the stream-ordered allocator
- * (hipMallocAsync / hipFreeAsync on `stream`; the only calls that allocate). */
+ * memory, in the reference's operation order, on the caller's scratch (dqq_scratch_bytes). */
 int dqq_max_n(int kind);
 
 /* Replaces the loop qcqp.py:29-31 (QPFn2.forward -> diffqcqp.solveQP,
@@ -157,8 +166,7 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
  *                    for the dense kernel launched behind it (0), or decide from (N, B) (-1, default: the
  *                    forward inside for N <= 8 and B <= 131072, where it solves a whole tile at once on the fast
  *                    path's own lane mapping; the backward, whose in-kernel routine takes one problem per wave at
- *                    a time, only for 32768 <= B <= 131072 -- a large batch known to be dense is served best by
- *                    DQQ_P_DENSE or by 0 here)
+ *                    a time, never: its non-diagonal tiles are queued at every batch size)
  *   "fwd_compact"    diagonal fast path, N = 8: repack the tiles of a workgroup as their problems stop (1), or
  *                    leave every tile to its wave (0, default: at the bench shape the barriers cost more than the
  *                    saved wave-iterations; it pays for heavy-tailed iteration counts).  Bit-identical results.

@@ -37,6 +37,14 @@ def test_version_and_limits(lib):
     assert lib.dqq_max_n(0) == 64 and lib.dqq_max_n(1) == 64 and lib.dqq_max_n(2) == 42
     assert lib.dqq_workspace_bytes(0) >= 16
     assert lib.dqq_workspace_bytes(65536) >= 4 * 65536
+    # scratch of the global-memory kernels: the caller's, a function of (kind, pass, N, B); 0 for every BASELINE config
+    for kind, pas, N, B in ((0, 0, 8, 65536), (1, 0, 8, 65536), (1, 1, 8, 65536), (0, 0, 32, 262144), (0, 1, 32, 262144),
+                            (0, 0, 64, 65536), (0, 1, 64, 65536)):
+        assert lib.dqq_scratch_bytes(kind, pas, N, B) == 0
+    assert lib.dqq_scratch_bytes(0, 0, 65, 10) > 0 and lib.dqq_scratch_bytes(1, 1, 44, 10) > 0
+    assert lib.dqq_scratch_bytes(2, 1, 22, 10) > 0 and lib.dqq_scratch_bytes(3, 1, 200, 10) == 0
+    assert lib.dqq_scratch_bytes(0, 0, 65, 4) * 2 == lib.dqq_scratch_bytes(0, 0, 65, 8)   # a slice per workgroup
+    assert lib.dqq_scratch_bytes(0, 0, 65, 10 ** 6) == lib.dqq_scratch_bytes(0, 0, 65, 10 ** 7)  # persistent grid
 
 
 def test_argument_validation_without_gpu(lib):
@@ -55,6 +63,8 @@ def test_argument_validation_without_gpu(lib):
                                 None, None, None, None, 0, None) == -3
     assert lib.dqq_qcqp_bwd_f64(one, one, one, one, one, one, None, None, None, None, None, None, 4, 67, 1e-10, 1,
                                 None, None, None, None, 0, None) == -2  # odd N
+    # DQQ_P_DENSE beyond the register / LDS kernels: the scratch is the caller's, nothing is allocated inside
+    assert f(one, one, one, 4, 80, 1e-7, 1e-7, 10, 1, 1, None, None, None, None, 0, None) == -5
     assert lib.dqq_set_option(b"no_such_knob", 1) == -6
 
 

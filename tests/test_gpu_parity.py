@@ -772,7 +772,7 @@ def test_autograd_functions_match_reference_contract(oracle, ops):
     cache[1].zero_()  # no verified diagonal: the backward reads P
     out = QPFn2.backward(type("C", (), {"saved_tensors": (Pc.cuda(), qc.detach().cuda(), x1.detach().cuda()) + cache,
                                         "needs_input_grad": (False, True, False, False, False, False),
-                                        "home": torch.device("cpu")})(), torch.ones(10, 8, 1))
+                                        "home": torch.device("cpu"), "layout": 0})(), torch.ones(10, 8, 1))
     assert len(out) == 6 and out[0] is None and out[2:] == (None, None, None, None)
 
 
