@@ -70,14 +70,23 @@ DQQ_D double wave_sum64(double v)
     return (lane_bcast(m, 0) + lane_bcast(m, 16)) + (lane_bcast(m, 32) + lane_bcast(m, 48));
 }
 
-// max over the wave of |a| and of |b|: one butterfly for both
+// wave-uniform double held by lane `src` (compile-time) -> SGPR pair
+template <int SRC>
+DQQ_D double lane_to_sgpr(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), SRC), __builtin_amdgcn_readlane(__double2loint(v), SRC));
+}
+
+// max over the wave of |a| and of |b|: one butterfly for both, results wave-uniform (SGPRs)
 DQQ_D void wave_max2_abs(double a, double b, double& ma, double& mb)
 {
-    double lo, hi;
+    double lo, hi, e, o;
     swap32(a, b, lo, hi); // lo = {a[0..31] | b[0..31]}, hi = {a[32..63] | b[32..63]}
-    const double m = LaneGroup<16>::max(max_abs2(lo, hi));
-    ma = max_raw(lane_bcast(m, 0), lane_bcast(m, 16));
-    mb = max_raw(lane_bcast(m, 32), lane_bcast(m, 48));
+    const double m = LaneGroup<16>::max(max_abs2(lo, hi)); // rows 0,1: max |a| over rows {r, r+2}; rows 2,3: |b|
+    swap16(m, m, e, o);   // e = m of rows (0,0,2,2), o = m of rows (1,1,3,3)
+    const double mm = max_raw(e, o); // lanes 0..31: max |a|, lanes 32..63: max |b|
+    ma = lane_to_sgpr<0>(mm);
+    mb = lane_to_sgpr<32>(mm);
 }
 
 // acc += (lane BC of this lane's 16-lane row of x0) * m
@@ -86,6 +95,31 @@ DQQ_D void fmac_bcast(double& acc, double x0, double m)
 {
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x0), "v"(m), "n"(BC));
 }
+
+// 16 v_fmac_f64_dpp in ONE asm statement (tile row TI of a 4 x 4 matrix): between separate asm statements the
+// compiler's hazard recogniser, which cannot see the DPP operand inside, pads every hand-off with an s_nop
+#define DQQ_MATVEC_TROW16(G, TI)                                                                                \
+    asm("v_fmac_f64_dpp %0, %4, %5 row_newbcast:%21 row_mask:0xf bank_mask:0xf\n\t"                             \
+        "v_fmac_f64_dpp %1, %4, %6 row_newbcast:%21 row_mask:0xf bank_mask:0xf\n\t"                             \
+        "v_fmac_f64_dpp %2, %4, %7 row_newbcast:%21 row_mask:0xf bank_mask:0xf\n\t"                             \
+        "v_fmac_f64_dpp %3, %4, %8 row_newbcast:%21 row_mask:0xf bank_mask:0xf\n\t"                             \
+        "v_fmac_f64_dpp %0, %4, %9 row_newbcast:%22 row_mask:0xf bank_mask:0xf\n\t"                             \
+        "v_fmac_f64_dpp %1, %4, %10 row_newbcast:%22 row_mask:0xf bank_mask:0xf\n\t"                            \
+        "v_fmac_f64_dpp %2, %4, %11 row_newbcast:%22 row_mask:0xf bank_mask:0xf\n\t"                            \
+        "v_fmac_f64_dpp %3, %4, %12 row_newbcast:%22 row_mask:0xf bank_mask:0xf\n\t"                            \
+        "v_fmac_f64_dpp %0, %4, %13 row_newbcast:%23 row_mask:0xf bank_mask:0xf\n\t"                            \
+        "v_fmac_f64_dpp %1, %4, %14 row_newbcast:%23 row_mask:0xf bank_mask:0xf\n\t"                            \
+        "v_fmac_f64_dpp %2, %4, %15 row_newbcast:%23 row_mask:0xf bank_mask:0xf\n\t"                            \
+        "v_fmac_f64_dpp %3, %4, %16 row_newbcast:%23 row_mask:0xf bank_mask:0xf\n\t"                            \
+        "v_fmac_f64_dpp %0, %4, %17 row_newbcast:%24 row_mask:0xf bank_mask:0xf\n\t"                            \
+        "v_fmac_f64_dpp %1, %4, %18 row_newbcast:%24 row_mask:0xf bank_mask:0xf\n\t"                            \
+        "v_fmac_f64_dpp %2, %4, %19 row_newbcast:%24 row_mask:0xf bank_mask:0xf\n\t"                            \
+        "v_fmac_f64_dpp %3, %4, %20 row_newbcast:%24 row_mask:0xf bank_mask:0xf"                                 \
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])                                                        \
+        : "v"(x0), "v"(G[TI][0][0]), "v"(G[TI][1][0]), "v"(G[TI][2][0]), "v"(G[TI][3][0]), "v"(G[TI][0][1]),      \
+          "v"(G[TI][1][1]), "v"(G[TI][2][1]), "v"(G[TI][3][1]), "v"(G[TI][0][2]), "v"(G[TI][1][2]),              \
+          "v"(G[TI][2][2]), "v"(G[TI][3][2]), "v"(G[TI][0][3]), "v"(G[TI][1][3]), "v"(G[TI][2][3]),              \
+          "v"(G[TI][3][3]), "n"(4 * TI + 0), "n"(4 * TI + 1), "n"(4 * TI + 2), "n"(4 * TI + 3))
 
 template <int NT, int I>
 struct MatvecRows { // rows I, I+1, ... of the 4 NT broadcast steps (BC = I = 4 ti + r), unrolled at compile time
@@ -109,7 +143,14 @@ struct WaveTile {
     {
         const double x0 = dpp_source(lane_gather(x, xsrc)); // lane (g, n') <- x[4 n' + g]
         double a[4] = {0.0, 0.0, 0.0, 0.0};
-        MatvecRows<NT, 0>::run(G, x0, a);
+        if constexpr (NT == 4) {
+            DQQ_MATVEC_TROW16(G, 0);
+            DQQ_MATVEC_TROW16(G, 1);
+            DQQ_MATVEC_TROW16(G, 2);
+            DQQ_MATVEC_TROW16(G, 3);
+        } else {
+            MatvecRows<NT, 0>::run(G, x0, a);
+        }
         // a[tj] of lane (g,n) = partial sum of y[16 tj + n] over the columns = g (mod 4): reduce over g,
         // scattering tj = g (accumulators beyond NT are zero)
         double p, q2, s02, s13, e, o;
