@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : (KIND == 1 ? 4 :
     bool have_diag = false;
     if (pdiag != nullptr && flags != nullptr && layout == DQQ_P_AUTO)
         have_diag = __all(!valid || flags[first + pl] != 0);
-    constexpr bool AGG = !FUSE && N >= 32 && WPB > 1; // queue non-diagonal tiles with one atomic per workgroup
+    constexpr bool AGG = !FUSE && WPB > 1; // queue non-diagonal tiles with ONE atomic per workgroup (see launch.h)
     __shared__ int s_cnt[2];
     if (layout == DQQ_P_DIAG) {
         pv = valid ? *reinterpret_cast<const double2*>(P + first * N + 2 * lane) : make_double2(1.0, 1.0);

@@ -29,10 +29,15 @@
 
 namespace dqq {
 
+// N = 8, two lanes per problem (the bench shape), fused: four waves per SIMD (128 VGPRs) so that the forwards of two
+// problem families -- or a forward and a backward -- are co-resident on a SIMD
+#define DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE) \
+    __attribute__((amdgpu_waves_per_eu(((FUSE) && (N) == 8 && (LPP) <= 2 && (KIND) < 2) ? 4 : 1, 8)))
+
 // CMP: the tiles of a workgroup are repacked as their problems stop (admm_compact.h); a workgroup that meets a
 // non-diagonal tile runs the plain per-wave solve instead.
 template <int KIND, int N, int LPP, int WPB, bool FUSE, bool CMP = false>
-__global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __restrict__ P,
+__global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE) void fwd_diag_kernel(const double* __restrict__ P,
                                                             const double* __restrict__ q,
                                                             const double* __restrict__ l_n,
                                                             const double* __restrict__ mu_c,
@@ -52,13 +57,16 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
     // the dense kernel launched behind this one.
     constexpr int SMEM = (FUSE && dense_fwd_lds_doubles(N) > 64 * E) ? dense_fwd_lds_doubles(N) : 64 * E;
     __shared__ __attribute__((aligned(16))) double s_diag[WPB][SMEM];
-    constexpr bool AGG = !FUSE && N >= 32 && WPB > 1; // queue non-diagonal tiles with one atomic per workgroup
+    constexpr bool AGG = !FUSE && WPB > 1; // queue non-diagonal tiles with ONE atomic per workgroup (see launch.h)
     __shared__ int s_cnt[2];
     static_assert(!CMP || (WPB > 1 && KIND < 2), "compaction: QP / QCQP, several waves per workgroup");
     [[maybe_unused]] __shared__ typename std::conditional<CMP, CompactLds<(KIND == 1) ? 1 : 0, N / LPP>, int>::type s_cmp;
     [[maybe_unused]] bool wg_dense = false;
-    // FUSE, N <= 8: a non-diagonal tile is solved on the same lane mapping, all its problems at once (group_dense.h)
-    constexpr bool GD = FUSE && group_dense_supported(KIND, N, LPP);
+    // FUSE, N <= 8: a non-diagonal tile is solved by this wave, 64/LD problems at a time with LD = max(N/2, LPP) lanes
+    // per problem (group_dense.h): two rows of the matrices per lane keep the general solve inside the register
+    // budget of the diagonal arithmetic
+    constexpr int LD = (N / 2 > LPP) ? N / 2 : LPP;
+    constexpr bool GD = FUSE && N <= 8 && LD <= 4 && group_dense_supported(KIND, N, LD);
     [[maybe_unused]] bool dense_tile = false; // CMP: some tile of this workgroup is not diagonal
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -174,9 +182,16 @@ __global__ __launch_bounds__(64 * WPB) void fwd_diag_kernel(const double* __rest
     bool solved = false;
     if constexpr (GD) {
         if (dense_tile) {
-            it = group_dense_fwd<KIND, N, LPP>(P + (first + pl) * (long)(N * N), qv, rad, eps, mu_prox, max_iter,
-                                               adaptive, valid, xv, lo, hi, sg);
-            solved = true;
+            if constexpr (LD == LPP) {
+                it = group_dense_fwd<KIND, N, LPP>(P + (first + pl) * (long)(N * N), qv, rad, eps, mu_prox, max_iter,
+                                                   adaptive, valid, xv, lo, hi, sg);
+                solved = true;
+            } else {
+                group_dense_tile<KIND, N, LD, PPW>(P, q, l_n, mu_c, v_sign, x, iters, first, nvalid, eps, mu_prox, max_iter,
+                                                   adaptive, lane);
+                DQQ_TL(5);
+                return; // x / iters written in the general solve's own mapping; no barrier follows
+            }
         }
     }
     if (!solved)
@@ -321,11 +336,8 @@ hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fus
     const bool fuse = fwd_diag_will_fuse(a.N, a.B, a.layout, fuse_opt);
     if (lpp <= 0) {
         lpp = fwd_diag_default_lpp(a.N, a.B);
-        // fused: a lane mapping the in-kernel general solve exists for (group_dense.h), if there is one
-        int count = 0;
-        const int* c = lpp_choices(a.N, count);
-        for (int i = 0; fuse && i < count && !group_dense_supported(kind, a.N, lpp); ++i)
-            if (c[i] > lpp) lpp = c[i];
+        // a batch declared dense takes the general solve's own mapping (N/2 lanes per problem): one pass per tile
+        if (a.layout == DQQ_P_DENSE && a.N <= 8) lpp = a.N / 2;
     }
     if (needs_fallback) *needs_fallback = (a.layout == DQQ_P_AUTO) && !fuse;
     hipError_t e = hipErrorInvalidValue;

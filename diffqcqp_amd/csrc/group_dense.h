@@ -83,17 +83,25 @@ struct GroupRows {
                 A[e][c + 1] = t.y;
             }
     }
-    // rows s*E.. of the symmetric matrix the LOWER triangle of P defines (what llt() factorises), diagonal `md`
+    // rows s*E.. of the symmetric matrix the LOWER triangle of P defines (what llt() factorises), diagonal `md`.
+    // Entry (g, c) is P[g][c] for c <= g and P[c][g] beyond: both the row g and the column g are loaded, from ONE
+    // per-lane pointer each with compile-time offsets, and the side is chosen per entry.  (Indexed as
+    // Pg[max(g,c) * N + min(g,c)] every entry had its own per-lane 64-bit address, which the compiler hoisted out of
+    // the ADMM loop -- the refactorisation sits inside it -- and kept in ~30 VGPRs for the whole solve.)
     static DQQ_D void load_lower_symmetric(const double* __restrict__ Pg, int s, const double (&md)[E],
                                            double (&A)[E][N])
     {
+        const double* rowp = Pg + (s * E) * N; // rows s*E .. s*E+E-1, contiguous
+        const double* colp = Pg + s * E;       // columns s*E .. : entry [c][g] at colp[c * N + e]
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int g = s * E + e;
 #pragma unroll
-            for (int c = 0; c < N; ++c) {
-                const int hi = g > c ? g : c, lo = g > c ? c : g;
-                A[e][c] = Pg[hi * N + lo];
+            for (int c = 0; c < N; c += 2) {
+                const double2 r = *reinterpret_cast<const double2*>(rowp + e * N + c);
+                const double c0 = colp[c * N + e], c1 = colp[(c + 1) * N + e];
+                A[e][c] = (c <= g) ? r.x : c0;
+                A[e][c + 1] = (c + 1 <= g) ? r.y : c1;
             }
 #pragma unroll
             for (int j = 0; j < LPP; ++j) A[e][j * E + e] = (s == j) ? md[e] : A[e][j * E + e];
@@ -282,6 +290,62 @@ DQQ_D int group_dense_fwd(const double* __restrict__ Pg, const double (&q)[N / L
 #pragma unroll
     for (int e = 0; e < E; ++e) x[e] = bad ? NAN : l2[e];
     return iters;
+}
+
+// A non-diagonal tile of the fast path (TILE consecutive problems from `first`, `nvalid` of them real) solved with
+// LD = N/2 lanes per problem -- two coordinates, i.e. two rows of every matrix, per lane -- whatever lane mapping the
+// diagonal arithmetic of the calling kernel uses: 64/LD problems per pass, TILE / (64/LD) passes.  Why not on the
+// caller's mapping (round 2): with E = 4 rows of P and of M^-1 per lane the fused QP / QCQP kernels needed 242 / 250
+// VGPRs, two waves per SIMD; the two forwards of a step could not be co-resident and the step paid ~4 us for it
+// (DESIGN.md 3.1 (v)).  With two rows per lane the general solve fits the diagonal path's own budget (4 waves per
+// SIMD); a dense tile costs two passes of roughly 0.65x the instructions each.  Reads q (and the constraint data)
+// and writes x / iters itself, in the general solve's mapping.
+template <int KIND, int N, int LD, int TILE>
+DQQ_D void group_dense_tile(const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ l_n,
+                            const double* __restrict__ mu_c, const double* __restrict__ v_sign, double* __restrict__ x,
+                            int* __restrict__ iters, long first, int nvalid, double eps, double mu, int max_iter,
+                            int adaptive, int lane)
+{
+    constexpr int E = N / LD, PPP = 64 / LD; // coordinates per lane, problems per pass
+    static_assert(E >= 2 && E % 2 == 0 && TILE % PPP == 0, "whole contacts per lane, whole passes per tile");
+    constexpr int EB = (KIND >= 2) ? E : 1;
+    const int s = lane % LD;
+#pragma unroll 1
+    for (int pass = 0; pass < TILE / PPP; ++pass) {
+        const int pj = pass * PPP + lane / LD;
+        if (pass * PPP >= nvalid) break;            // wave-uniform
+        const bool valid = pj < nvalid;
+        const long prob = first + pj;
+        double qv[E], xv[E], rad[E / 2], lo[EB], hi[EB], sg[EB];
+#pragma unroll
+        for (int e = 0; e < E; e += 2) {
+            const double2 t = valid ? *reinterpret_cast<const double2*>(q + prob * N + s * E + e) : make_double2(0.0, 0.0);
+            qv[e] = t.x; qv[e + 1] = t.y;
+        }
+#pragma unroll
+        for (int c = 0; c < E / 2; ++c) {
+            const long co = prob * (N / 2) + s * (E / 2) + c;
+            rad[c] = (KIND == 1 && valid) ? l_n[co] * mu_c[co] : (KIND == 1 ? 1.0 : 0.0); // pybindings.cpp:57
+        }
+        if constexpr (KIND >= 2) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const long bo = prob * N + s * E + e;
+                lo[e] = valid ? l_n[bo] : 0.0;
+                hi[e] = valid ? mu_c[bo] : 0.0;
+                sg[e] = 0.0;
+                if (KIND == 3) { const double c = valid ? v_sign[bo] : 0.0; sg[e] = (double)((c > 0) - (c < 0)); } // :395
+            }
+        }
+        const int it = group_dense_fwd<KIND, N, LD>(P + prob * (long)(N * N), qv, rad, eps, mu, max_iter, adaptive, valid,
+                                                    xv, lo, hi, sg);
+        if (valid) {
+#pragma unroll
+            for (int e = 0; e < E; e += 2)
+                *reinterpret_cast<double2*>(x + prob * N + s * E + e) = make_double2(xv[e], xv[e + 1]);
+            if (iters != nullptr && s == 0) iters[prob] = it;
+        }
+    }
 }
 
 #endif // __HIPCC__
