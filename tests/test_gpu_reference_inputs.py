@@ -13,8 +13,9 @@ reach 1.6e7:
   backward  on the oracle's x: gradients within 1e-6 s of the reference formula.  On these systems the refinement loop
             (Solver.cpp:32-41) runs 1, 3, 4, 5 ... bodies depending on a residual that is rounding noise -- K = A^T A +
             1e-7 I has cond ~1e9 and beyond, and the oracle's own exit flips under a differently ordered evaluation
-            (oracle/README.md).  A kernel that evaluates the sums in the reference's order (N <= 16, every QCQP route)
-            must reproduce the step counts exactly; a re-associating kernel (QP, 16 < N <= 64: matrix cores) may leave
+            (oracle/README.md).  A kernel that evaluates the sums in the reference's order (N <= 16, QCQP N > 32)
+            must reproduce the step counts exactly; a re-associating kernel (matrix cores: QP 16 < N <= 64, QCQP
+            16 < N <= 32) may leave
             the loop at another body, and is then compared with the reference formula run for ITS number of bodies
             (orc_set_force_ir_steps) -- every problem is checked, none is excluded.
 """
@@ -103,9 +104,9 @@ def check_case(O, ops, kind, d, xo, ito, ref, eps, max_iter, exact_order, max_fl
 
 
 def _reference_order(kind, N):
-    # QP backward for 16 < N <= 64 runs on the matrix cores (re-associated sums); everything else on these sizes
-    # evaluates the refinement in the reference's order
-    return not (kind == "qp" and 16 < N <= 64)
+    # QP backward for 16 < N <= 64 and QCQP backward for 16 < N <= 32 run on the matrix cores (re-associated sums);
+    # everything else on these sizes evaluates the refinement in the reference's order
+    return not ((kind == "qp" and 16 < N <= 64) or (kind == "qcqp" and 16 < N <= 32))
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "ref_*.npz")) +

@@ -194,6 +194,8 @@ def run_family(name, kind, d, O, eps=1e-7, max_iter=1000, backward=True):
     for i in range(B):
         x, its[i], _ = solve(P[i], q[i], eps, max_iter, kind=kind, rad=None if kind == "qp" else ln[i] * mu[i])
         dx[i] = np.abs(x - xo[i, :, 0]).max()
+    xs = np.maximum(1.0, np.abs(xo).max(axis=(1, 2)))
+    dx = dx / xs   # relative to the solution's scale (the reference's own m2 problem has x = 1.6e7)
     out = {"family": name, "problems": B, "N": q.shape[1],
            "iteration_count_agreement": float((its == ito).mean()),
            "iteration_count_max_abs_difference": int(np.abs(its - ito).max()),
@@ -213,6 +215,24 @@ def run_family(name, kind, d, O, eps=1e-7, max_iter=1000, backward=True):
                 gq, st[i] = qcqp_backward(P[i], q[i], ln[i], mu[i], xo[i, :, 0], g[i])
             dg[i] = np.abs(gq - ref[1][i, :, 0]).max() / max(1.0, np.abs(ref[1][i]).max())
         same = st == ref[-1]
+        # where the exits differ: the oracle made to run THIS evaluation's number of bodies
+        dgf = np.zeros(B)
+        for steps in np.unique(st[~same]):
+            sel = np.nonzero((~same) & (st == steps))[0]
+            O.set_force_ir_steps(int(steps))
+            try:
+                if kind == "qp":
+                    fr = O.qp_bwd_batch(P[sel], d["q"].numpy()[sel], xo[sel], d["grad_x"].numpy()[sel], nthreads=8)
+                else:
+                    fr = O.qcqp_bwd_batch(P[sel], d["q"].numpy()[sel], d["l_n"].numpy()[sel], d["mu"].numpy()[sel], xo[sel],
+                                          d["grad_x"].numpy()[sel], nthreads=8)
+            finally:
+                O.set_force_ir_steps(0)
+            for k, i in enumerate(sel):
+                gq = (qp_backward(P[i], q[i], xo[i, :, 0], g[i]) if kind == "qp" else
+                      qcqp_backward(P[i], q[i], ln[i], mu[i], xo[i, :, 0], g[i]))[0]
+                dgf[i] = np.abs(gq - fr[1][k, :, 0]).max() / max(1.0, np.abs(fr[1][k]).max())
+        out["grad_q_max_rel_difference_at_this_evaluations_exit"] = float(dgf.max())
         out.update({"refinement_step_agreement": float(same.mean()),
                     "oracle_step_histogram": {int(k): int(v) for k, v in zip(*np.unique(ref[-1], return_counts=True))},
                     "grad_q_max_rel_difference_where_steps_agree": float(dg[same].max()) if same.any() else None,
@@ -250,6 +270,15 @@ def main():
         res.append(run_family("golden/" + name, kind, d, O, eps=eps, max_iter=mi))
         print(json.dumps(res[-1]), flush=True)
     # the BASELINE config distributions
+    # the regime the reference's own G4 stands for: rank-deficient dense P (tests/golden/reference_inputs.py)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import reference_inputs as R
+    for fam in ("lowrank", "duprows"):
+        for N, nb in ((8, 2000), (32, 1000), (64, 300)):
+            for kind in ("qp", "qcqp"):
+                d = R.rank_deficient(kind, min(nb, max(args.n // 5, 50)), N, 7000 + N, fam)
+                res.append(run_family("rank-deficient %s %s N=%d" % (fam, kind.upper(), N), kind, d, O))
+                print(json.dumps(res[-1]), flush=True)
     n = args.n
     fams = [("cfg2/3 QP diag N=8, p~U(.1,1.1)", "qp", 8, "diag", n), ("cfg3 QCQP diag N=8", "qcqp", 8, "diag", n),
             ("QP dense N=8 (S S^T/N + .1 I)", "qp", 8, "dense", n), ("QCQP dense N=8", "qcqp", 8, "dense", n),

@@ -94,6 +94,22 @@ def main():
             k, v = kv.split("=")
             _capi.set_option(k, int(v))
             print("option", k, "=", v)
+    if len(sys.argv) > 1 and sys.argv[1] == "qcqpbwd":  # QCQP backward 16 < N <= 32: wave kernel vs reference-order kernel
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from conftest import make_problem
+        for fam in ("dense", "lowrank", "duprows"):
+            for N in (24, 32):
+                B = 4096
+                if fam == "dense":
+                    d = {k: v.numpy() for k, v in make_problem("qcqp", B, N, 7100 + N, "dense").items()}
+                else:
+                    d = {k: v.numpy() for k, v in R.rank_deficient("qcqp", B, N, 7000 + N, fam).items()}
+                run(fam, "qcqp", d, 1e-7, 1000, layouts=(1,))
+                t = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in d.items()}
+                xh = ops.qcqp_forward(t["P"], t["q"], t["l_n"], t["mu"], 1e-7, 1000, layout=1)
+                ms = timed(lambda: ops.qcqp_backward(t["P"], t["q"], t["l_n"], t["mu"], xh, t["grad_x"], layout=1))
+                print("   backward %.3f ms per %d problems" % (ms, B), flush=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "qpbwd":   # only the QP backward of the rank-deficient families, timed
         for fam in ("lowrank", "duprows", "dense"):
             for N in (32, 64):
