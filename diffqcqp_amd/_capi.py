@@ -1,4 +1,7 @@
-"""ctypes binding of libdiffqcqp_hip.so (include/diffqcqp_hip.h).
+"""Python binding of libdiffqcqp_hip.so (include/diffqcqp_hip.h): the pybind11 module `_dqq`
+(csrc/pybind_module.cpp, built next to the library) when it is there, ctypes otherwise -- the same
+symbols, the same argument order, pointers as Python ints either way.  DQQ_BINDING=ctypes|pybind11
+forces one of them.
 
 The library is the product: if it is missing or cannot be loaded this module
 raises -- there is no CPU or PyTorch fallback behind it.
@@ -13,6 +16,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdiffqcqp_hip.so")
+PYMOD_PATH = os.path.join(_HERE, "lib", "_dqq.so")
 
 P_AUTO, P_DENSE, P_DIAG = 0, 1, 2
 
@@ -49,21 +53,52 @@ SIGNATURES = {
 }
 
 
+_binding = None
+
+
+def ctypes_lib():
+    """The library through ctypes (always available when the library is)."""
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "diffqcqp_amd: %s not found. Build it with `python -m diffqcqp_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    handle = ctypes.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError if the library does not export it
+        fn.argtypes = argtypes
+        fn.restype = restype
+    return handle
+
+
+def pybind_lib():
+    """The pybind11 module over the same C ABI, or None when it has not been built."""
+    if not (os.path.exists(PYMOD_PATH) and os.path.exists(LIB_PATH)):
+        return None
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_dqq", PYMOD_PATH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for name in SIGNATURES:
+        getattr(mod, name)  # AttributeError if the module does not bind it
+    return mod
+
+
 def lib():
-    """Load (once) and return the C-ABI library; raises if it is not there."""
-    global _lib
+    """Load (once) and return the C-ABI library (pybind11 module or ctypes handle: same call surface); raises if it
+    is not there."""
+    global _lib, _binding
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                "diffqcqp_amd: %s not found. Build it with `python -m diffqcqp_amd.build` "
-                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
-        handle = ctypes.CDLL(LIB_PATH)
-        for name, (argtypes, restype) in SIGNATURES.items():
-            fn = getattr(handle, name)  # AttributeError if the library does not export it
-            fn.argtypes = argtypes
-            fn.restype = restype
-        _lib = handle
+        want = os.environ.get("DQQ_BINDING", "")
+        mod = None if want == "ctypes" else pybind_lib()
+        if mod is None and want == "pybind11":
+            raise RuntimeError("diffqcqp_amd: DQQ_BINDING=pybind11 but %s is not built" % PYMOD_PATH)
+        _lib, _binding = (mod, "pybind11") if mod is not None else (ctypes_lib(), "ctypes")
     return _lib
+
+
+def binding():
+    lib()
+    return _binding
 
 
 def check(rc, what):
@@ -79,6 +114,10 @@ def set_option(name, value):
 
 
 def get_option(name):
+    if binding() == "pybind11":
+        rc, value = lib().dqq_get_option(name.encode())
+        check(rc, "dqq_get_option(%s)" % name)
+        return value
     v = _i(0)
     check(lib().dqq_get_option(name.encode(), ctypes.byref(v)), "dqq_get_option(%s)" % name)
     return v.value

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdiffqcqp_hip.so")
+PYMOD = os.path.join(LIBDIR, "_dqq.so")   # pybind11 module over the C ABI (csrc/pybind_module.cpp)
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-fvisibility=hidden",
@@ -57,7 +58,7 @@ def _flag_stamp():
 
 
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(PYMOD):
         return True
     try:
         if open(STAMP).read() != _flag_stamp():
@@ -91,9 +92,31 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    _build_pybind(verbose)
     with open(STAMP, "w") as f:
         f.write(_flag_stamp())
     return LIB
+
+
+def _build_pybind(verbose=False):
+    """The pybind11 module `_dqq` (host-only C++, g++): every C-ABI function under its own name.  Optional: without
+    pybind11 headers `_capi.py` binds the same symbols with ctypes."""
+    try:
+        import pybind11
+        import sysconfig
+    except ImportError:
+        return None
+    cxx = os.environ.get("CXX", "g++")
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-I", INCLUDE, "-I", pybind11.get_include(),
+           "-I", sysconfig.get_paths()["include"], os.path.join(CSRC, "pybind_module.cpp"), "-o", PYMOD,
+           "-L", LIBDIR, "-ldiffqcqp_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    try:
+        subprocess.check_call(cmd)
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    return PYMOD
 
 
 if __name__ == "__main__":

@@ -10,11 +10,17 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def lib():
+@pytest.fixture(scope="module", params=["ctypes", "pybind11"])
+def lib(request):
+    """Both faces of the C ABI: the ctypes handle and the pybind11 module `_dqq` (csrc/pybind_module.cpp) -- same
+    symbols, same argument order, pointers as Python ints."""
     from diffqcqp_amd import build, _capi
     build.build()
-    return _capi.lib()
+    if request.param == "ctypes":
+        return _capi.ctypes_lib()
+    mod = _capi.pybind_lib()
+    assert mod is not None, "the pybind11 module was not built (pybind11 headers are in this image)"
+    return mod
 
 
 def _declared_symbols():
@@ -48,7 +54,7 @@ def test_version_and_limits(lib):
 
 
 def test_argument_validation_without_gpu(lib):
-    one = ctypes.c_void_p(8)  # never dereferenced: the checks fail first
+    one = 8  # a pointer as a Python int, never dereferenced: the checks fail first
     f = lib.dqq_qp_fwd_f64
     assert f(one, one, one, -1, 8, 1e-7, 1e-7, 10, 1, 0, None, None, None, None, 0, None) == -2
     assert f(one, one, one, 4, 0, 1e-7, 1e-7, 10, 1, 0, None, None, None, None, 0, None) == -2

@@ -175,3 +175,35 @@ def test_functions_take_the_layout_from_the_module_default(oracle, ops):
     assert np.abs(res["dense"][0].cpu().numpy() - xo).max() <= 1e-6
     with pytest.raises(ValueError):
         qcqp.set_default_layout("diag")
+
+
+def test_ctypes_and_pybind11_bindings_agree(ops):
+    """The C ABI has two Python faces (diffqcqp_amd/_capi.py): the pybind11 module `_dqq` and ctypes.  Same symbols,
+    same arguments, same numbers; the pybind11 call is the cheaper one (it matters at B = 1)."""
+    import time
+    from diffqcqp_amd import _capi
+    d = make_problem("qcqp", 777, 8, 8600)
+    P, q, ln, mu = (d[k].cuda() for k in ("P", "q", "l_n", "mu"))
+    ws = ops._workspace(torch.device("cuda", 0), 777)
+    stream = torch.cuda.current_stream().cuda_stream
+    out, cost = {}, {}
+    for name, L in (("ctypes", _capi.ctypes_lib()), ("pybind11", _capi.pybind_lib())):
+        assert L is not None, name
+        x = torch.empty(777, 8, 1, device="cuda", dtype=torch.float64)
+        it = torch.empty(777, device="cuda", dtype=torch.int32)
+        args = (P.data_ptr(), q.data_ptr(), ln.data_ptr(), mu.data_ptr(), x.data_ptr(), 777, 8, 1e-7, 1e-7, 1000, 1, 0,
+                it.data_ptr(), None, None, ws.data_ptr(), ws.numel() * 4, stream)
+        assert L.dqq_qcqp_fwd_f64(*args) == 0
+        torch.cuda.synchronize()
+        out[name] = (x.clone(), it.clone())
+        bad = (P.data_ptr(), q.data_ptr(), ln.data_ptr(), mu.data_ptr(), x.data_ptr(), -1, 8, 1e-7, 1e-7, 1000, 1, 0,
+               None, None, None, None, 0, None)
+        t0 = time.perf_counter()
+        for _ in range(2000):
+            L.dqq_qcqp_fwd_f64(*bad)          # argument check only: returns DQQ_E_BAD_SIZE before any launch
+        cost[name] = (time.perf_counter() - t0) / 2000
+        assert L.dqq_qcqp_fwd_f64(*bad) == -2
+    assert torch.equal(out["ctypes"][0], out["pybind11"][0]) and torch.equal(out["ctypes"][1], out["pybind11"][1])
+    assert _capi.binding() in ("pybind11", "ctypes")
+    print("call overhead: ctypes %.2f us, pybind11 %.2f us" % (cost["ctypes"] * 1e6, cost["pybind11"] * 1e6))
+    assert cost["pybind11"] < cost["ctypes"]
