@@ -30,6 +30,7 @@ UNITS = {
     "dense_block.hip": ["-ffp-contract=fast"],
     "dense_wave64.hip": ["-ffp-contract=fast"],
     "bwd_wave_qcqp.hip": ["-ffp-contract=off"],
+    "bwd_wave_qcqp_big.hip": ["-ffp-contract=off"],
     "bwd_block.hip": ["-ffp-contract=off"],
     "fwd_lane_dense.hip": ["-ffp-contract=fast"],
     "fwd_small.hip": ["-ffp-contract=fast"],

@@ -179,6 +179,8 @@ hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipSt
     if (bwd_dense_wave64_supported(kind, a.N) && g_dense_wave64.load() != 0)
         return launch_bwd_dense_wave64(kind, a, use_worklist, s);
     if (bwd_wave_qcqp_supported(kind, a.N) && g_dense_wave64.load() != 0) return launch_bwd_wave_qcqp(a, use_worklist, s);
+    if (bwd_wave_qcqp_big_supported(kind, a.N) && g_dense_wave64.load() != 0)
+        return launch_bwd_wave_qcqp_big(a, use_worklist, s);
     if (bwd_dense_block_supported(kind, a.N) && g_dense_block.load() != 0)
         return launch_bwd_dense_block(kind, a, use_worklist, s);
     // Systems beyond the wave kernel's 64 rows (QP N > 64, QCQP N > 42, box N > 21): the global-memory kernel in the

@@ -322,7 +322,9 @@ bool fwd_diag_takes_dense(int kind, int N, long B) { return kind < 2 && N == 8 &
 
 bool fwd_diag_will_fuse(int N, long B, int layout, int fuse_opt)
 {
-    if (layout == DQQ_P_DENSE) return true;
+    // a batch declared dense is only ever sent here for the sizes whose general routine lives in this kernel
+    // (group_dense.h: N <= 8); anything else would queue tiles on a work-list the DENSE route does not have
+    if (layout == DQQ_P_DENSE) return fwd_diag_fuses(N) && N <= 8;
     return layout != DQQ_P_DIAG && fwd_diag_supported(N) && fwd_diag_fuses(N) &&
            (fuse_opt < 0 ? fwd_diag_fuses_fallback(N, B) : fuse_opt != 0);
 }

@@ -198,6 +198,9 @@ hipError_t launch_bwd_dense_wave64(int kind, const BwdArgs& a, bool use_worklist
 // wave-per-problem, register-resident QCQP backward for 16 < N <= 32 (bwd_wave_qcqp.hip); launch_bwd_dense routes to it
 bool bwd_wave_qcqp_supported(int kind, int N);
 hipError_t launch_bwd_wave_qcqp(const BwdArgs& a, bool use_worklist, hipStream_t s);
+// the same for 32 < N <= 64 with the system matrix streamed (bwd_wave_qcqp_big.hip)
+bool bwd_wave_qcqp_big_supported(int kind, int N);
+hipError_t launch_bwd_wave_qcqp_big(const BwdArgs& a, bool use_worklist, hipStream_t s);
 // workgroup-per-problem QP backward for N = 32, 64 (dense_block.hip); launch_bwd_dense routes to it
 bool bwd_dense_block_supported(int kind, int N);
 hipError_t launch_bwd_dense_block(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);

@@ -166,10 +166,7 @@ struct WaveChol {
 
     DQQ_D void factor(int lane, bool& bad)
     {
-        factor_step<0>(lane, bad);
-        if constexpr (NT > 1) factor_step<1>(lane, bad);
-        if constexpr (NT > 2) factor_step<2>(lane, bad);
-        if constexpr (NT > 3) factor_step<3>(lane, bad);
+        static_for<0, NT>([&](auto kc) __attribute__((always_inline)) { this->template factor_step<decltype(kc)::value>(lane, bad); });
     }
 
     // After factor(): the explicit inverse K^-1 = L^-T L^-1 (what the reference's llt().solveInPlace(Identity)
@@ -264,6 +261,19 @@ struct WaveChol {
         return x;
     }
 };
+
+// a[0..3] of lane (g,n) = partial sums of y[16 t + n] over the entries = g (mod 4) of the contraction: reduce over the
+// four 16-lane rows, scattering t = row (the tail of WaveTile::matvec); result: y[l] in lane l
+DQQ_D double reduce_scatter4(double a0, double a1, double a2, double a3)
+{
+    double p, q2, s02, s13, e, o;
+    swap32(a0, a2, p, q2);
+    s02 = p + q2;
+    swap32(a1, a3, p, q2);
+    s13 = p + q2;
+    swap16(s02, s13, e, o);
+    return e + o;
+}
 
 // y = S x for the symmetric S whose UPPER tiles are in Su (x, y one element per lane; xsrc = 4 (lane & 15) + (lane >> 4)):
 // the lower tiles are transposes of the upper ones, made on the matrix cores

@@ -32,8 +32,10 @@ def test_zero_radius_contacts(oracle, ops, N, structure, layout):
     assert np.all(npy(xh)[2] == 0.0) and np.all(npy(xh)[3] == 0.0)
     assert np.all(npy(xh)[0::4, 0:2, 0] == 0.0)
     grads, st = hip_bwd(ops, "qcqp", g, torch.from_numpy(xo).cuda(), layout=layout)
-    exact = structure == "diag"
-    check_backward_exact(grads, st, oracle_bwd(oracle, "qcqp", d, xo), exact=exact)
+    if structure == "diag":
+        check_backward_exact(grads, st, oracle_bwd(oracle, "qcqp", d, xo), exact=True)
+    else:
+        check_dense_backward(oracle, "qcqp", N, d, xo, grads, st, oracle_bwd(oracle, "qcqp", d, xo))
     assert np.all(npy(grads[2])[0::4, 0, 0] == 0.0) and np.all(npy(grads[3])[1::4, -1, 0] == 0.0)
 
 

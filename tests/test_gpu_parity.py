@@ -125,8 +125,7 @@ REASSOC_TOL = {"qp": (1e-7, 1e-7), "qcqp": (1e-6, 1e-6, 2e-5, 2e-5)}
 
 
 def check_backward_reassociated(oracle, kind, d, xo, grads, steps, ref, min_same=0.9):
-    """Kernels that evaluate the backward's sums in another order than the reference (matrix cores: QP 16 < N <= 64,
-    QCQP 16 < N <= 32): gradients within REASSOC_TOL where the refinement exit agrees; where it does not -- the exit
+    """Kernels that evaluate the backward's sums in another order than the reference (matrix cores: QP and QCQP, 16 < N <= 64): gradients within REASSOC_TOL where the refinement exit agrees; where it does not -- the exit
     test compares rounding noise with 1e-10, Solver.cpp:30-39 -- against the reference formula run for the kernel's
     own number of bodies (orc_set_force_ir_steps).  Every problem is checked."""
     tols = REASSOC_TOL[kind]
@@ -157,7 +156,7 @@ def check_backward_reassociated(oracle, kind, d, xo, grads, steps, ref, min_same
 
 def reassociating(kind, N):
     """Which default routes of the general (dense P) backward evaluate their sums on the matrix cores."""
-    return (kind == "qp" and 16 < N <= 64) or (kind == "qcqp" and 16 < N <= 32)
+    return kind in ("qp", "qcqp") and 16 < N <= 64
 
 
 def check_dense_backward(oracle, kind, N, d, xo, grads, steps, ref, min_same=0.75):
@@ -428,14 +427,19 @@ def test_workgroup_backward_for_large_systems(oracle, ops, kind, N, B):
 
 @pytest.mark.parametrize("kind,N,B", [("qcqp", 64, 40), ("qcqp", 50, 24), ("qcqp", 44, 24), ("box", 32, 48), ("box", 22, 30)])
 def test_reference_order_backward_beyond_the_wave_kernel(oracle, ops, kind, N, B):
-    """QCQP 42 < N <= 64 / box 21 < N <= 32 by default: the global-memory workgroup kernel in the reference's
-    operation order -- same 1e-9 bar (and identical refinement step counts) as the wave kernel below those sizes."""
+    """The global-memory workgroup kernel in the reference's operation order -- the default for box 21 < N <= 32, and for
+    QCQP 42 < N <= 64 behind dense_wave64 = 0 (the matrix-core kernels take 16 < N <= 64 since round 3): same 1e-9 bar
+    (and identical refinement step counts) as the LDS wave kernel below those sizes."""
     from diffqcqp_amd import _capi
     d = make_problem(kind, B, N, 730 + N, "dense")
     g = dev(d)
     if kind == "qcqp":
         xo, _ = oracle_fwd(oracle, kind, d)
-        grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
+        _capi.set_option("dense_wave64", 0)
+        try:
+            grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
+        finally:
+            _capi.set_option("dense_wave64", 1)
         check_backward_exact(grads, st, oracle_bwd(oracle, kind, d, xo), exact=False)
     else:
         xo = oracle.boxqp_fwd_batch(d["P"].numpy(), d["q"].numpy(), d["l_min"].numpy(), d["l_max"].numpy(), 1e-7, 1000,
@@ -1056,10 +1060,12 @@ def test_full_size_b65536_n8_dense_p_through_auto(oracle, ops, kind, structure):
         assert np.allclose(npy(a)[idx], b, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(b).max()))
 
 
-@pytest.mark.parametrize("N,B", [(18, 300), (20, 129), (24, 500), (26, 64), (30, 257), (32, 1024)])
+@pytest.mark.parametrize("N,B", [(18, 300), (20, 129), (24, 500), (26, 64), (30, 257), (32, 1024), (34, 96), (40, 200),
+                                 (46, 64), (48, 257), (50, 64), (56, 130), (62, 33), (64, 300)])
 def test_qcqp_backward_wave_kernel_16_to_32(oracle, ops, N, B):
-    """QCQP backward for a dense P, 16 < N <= 32: one wave per problem, the (N/2 + N)-unknown system in registers
-    (bwd_wave_qcqp.hip, block Cholesky).  Against the oracle on the oracle's x (tolerances: REASSOC_TOL, the
+    """QCQP backward for a dense P, 16 < N <= 64: one wave per problem, the factor of the (N/2 + N)-unknown system in
+    registers (N <= 32: bwd_wave_qcqp.hip, the system matrix too; beyond: bwd_wave_qcqp_big.hip, the matrix streamed;
+    block Cholesky).  Against the oracle on the oracle's x (tolerances: REASSOC_TOL, the
     reference's own evaluation-order noise) and against the LDS wave kernel in the reference's summation order
     (dense_wave64 = 0); refinement exits that differ are checked against the reference formula at the kernel's own
     exit (orc_set_force_ir_steps)."""

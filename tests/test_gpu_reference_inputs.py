@@ -13,9 +13,8 @@ reach 1.6e7:
   backward  on the oracle's x: gradients within 1e-6 s of the reference formula.  On these systems the refinement loop
             (Solver.cpp:32-41) runs 1, 3, 4, 5 ... bodies depending on a residual that is rounding noise -- K = A^T A +
             1e-7 I has cond ~1e9 and beyond, and the oracle's own exit flips under a differently ordered evaluation
-            (oracle/README.md).  A kernel that evaluates the sums in the reference's order (N <= 16, QCQP N > 32)
-            must reproduce the step counts exactly; a re-associating kernel (matrix cores: QP 16 < N <= 64, QCQP
-            16 < N <= 32) may leave
+            (oracle/README.md).  A kernel that evaluates the sums in the reference's order (N <= 16)
+            must reproduce the step counts exactly; a re-associating kernel (matrix cores: 16 < N <= 64) may leave
             the loop at another body, and is then compared with the reference formula run for ITS number of bodies
             (orc_set_force_ir_steps) -- every problem is checked, none is excluded.
 """
@@ -33,6 +32,9 @@ sys.path.insert(0, GOLDEN)
 import reference_inputs as R  # noqa: E402
 
 TOL = 1e-6
+# the QCQP's contact gradients (grad_l_n, grad_mu) through a re-associating kernel: the evaluation-order noise of the
+# reference's own formulas on these systems is up to 8.6e-6 (tests/test_gpu_parity.py: REASSOC_TOL, oracle/README.md)
+TOL_CONTACT_REASSOC = 2e-5
 
 
 @pytest.fixture(scope="module")
@@ -89,8 +91,9 @@ def check_case(O, ops, kind, d, xo, ito, ref, eps, max_iter, exact_order, max_fl
             assert same.all(), "%s: refinement step counts differ on %d problems" % (tag, (~same).sum())
         else:
             assert 1.0 - same.mean() <= max_flip, "%s: refinement exit differs on %.1f%%" % (tag, 100 * (1 - same.mean()))
-        for a, b in zip(gh, gref):
-            assert _rel(a[same], b[same]) <= TOL, "%s: gradient off by %.2e (same exit)" % (tag, _rel(a[same], b[same]))
+        tols = [TOL, TOL] + [TOL if exact_order else TOL_CONTACT_REASSOC] * 2
+        for a, b, tol in zip(gh, gref, tols):
+            assert _rel(a[same], b[same]) <= tol, "%s: gradient off by %.2e (same exit)" % (tag, _rel(a[same], b[same]))
         for steps in np.unique(sh[~same]):            # the reference formula at the exit the kernel took
             sel = np.nonzero((~same) & (sh == steps))[0]
             O.set_force_ir_steps(int(steps))
@@ -98,15 +101,15 @@ def check_case(O, ops, kind, d, xo, ito, ref, eps, max_iter, exact_order, max_fl
                 forced = _oracle_bwd(O, kind, {k: v[sel] for k, v in d.items()}, xo[sel])
             finally:
                 O.set_force_ir_steps(0)
-            for a, b in zip(gh, forced[:-1]):
-                assert _rel(a[sel], b) <= TOL, "%s: gradient off by %.2e at the kernel's own exit (%d bodies)" % (
+            for a, b, tol in zip(gh, forced[:-1], tols):
+                assert _rel(a[sel], b) <= tol, "%s: gradient off by %.2e at the kernel's own exit (%d bodies)" % (
                     tag, _rel(a[sel], b), steps)
 
 
 def _reference_order(kind, N):
-    # QP backward for 16 < N <= 64 and QCQP backward for 16 < N <= 32 run on the matrix cores (re-associated sums);
-    # everything else on these sizes evaluates the refinement in the reference's order
-    return not ((kind == "qp" and 16 < N <= 64) or (kind == "qcqp" and 16 < N <= 32))
+    # QP and QCQP backward for 16 < N <= 64 run on the matrix cores (re-associated sums); everything else evaluates the
+    # refinement in the reference's order
+    return not (16 < N <= 64)
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "ref_*.npz")) +

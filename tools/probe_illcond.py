@@ -98,8 +98,8 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from conftest import make_problem
         for fam in ("dense", "lowrank", "duprows"):
-            for N in (24, 32):
-                B = 4096
+            for N in ((24, 32) if len(sys.argv) < 3 else tuple(int(v) for v in sys.argv[2].split(","))):
+                B = 4096 if N <= 32 else 1024
                 if fam == "dense":
                     d = {k: v.numpy() for k, v in make_problem("qcqp", B, N, 7100 + N, "dense").items()}
                 else:
