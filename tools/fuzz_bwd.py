@@ -55,11 +55,15 @@ for t in range(trials):
         grads, st, gref, sref = out[:4], out[4].cpu().numpy()[:, 1], ref[:4], ref[5][:, 1]
     same = st == sref
     rel = 0.0
-    for a, b in zip(grads, gref):
+    # the QCQP's contact gradients through the matrix-core kernels (16 < N <= 64, dense_wave64 = 1): the evaluation-order
+    # noise of the reference's own formulas is up to 8.6e-6 there (tests/test_gpu_parity.py: REASSOC_TOL); judged at 2e-5
+    reassoc = kind == "qcqp" and 16 < N <= 64 and opts["dense_wave64"] == 1 and structure != "diag"
+    for k, (a, b) in enumerate(zip(grads, gref)):
         a, b = a.cpu().numpy()[same], b[same]
         if a.size:
             sc = np.maximum(1.0, np.abs(b).reshape(b.shape[0], -1).max(1)).reshape((-1,) + (1,) * (b.ndim - 1))
-            rel = max(rel, float((np.abs(a - b) / sc).max()))
+            r = float((np.abs(a - b) / sc).max())
+            rel = max(rel, r / 20 if (reassoc and k >= 2) else r)
     finite = all(np.isfinite(a.cpu().numpy()).all() for a in grads)
     worst = max(worst, rel)
     ok = rel <= 1e-6 and finite and (same.mean() >= 0.9 or B < 64)
