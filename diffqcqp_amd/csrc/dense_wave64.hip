@@ -91,6 +91,67 @@ static DQQ_D void set_tile_diagonal(v4d (&G)[NT][NT], double d, int lane)
     }
 }
 
+// The lower triangle of the symmetric matrix (what every refactorisation starts from), kept in LDS between
+// refactorisations: the off-diagonal lower tiles row-major with an odd row stride (17: a tile is read along its rows
+// for the lower half of the matrix and along its columns for the mirrored upper half, both conflict-free), the
+// diagonal tiles as packed lower triangles.  16.9 KiB for 4 x 4 tiles: eight waves per CU keep 135 of the 160 KiB.
+// Round 2 re-read P from global memory at every rho update: 1.94x the algorithmic HBM traffic.
+constexpr int kLowLd = 17;
+template <int NT>
+struct LowerLds {
+    static constexpr int NOFF = NT * (NT - 1) / 2;
+    static constexpr int DIAG0 = NOFF * 16 * kLowLd;
+    static constexpr int DOUBLES = DIAG0 + NT * 136;
+    static constexpr int tile_base(int ti, int tj) { return (ti * (ti - 1) / 2 + tj) * 16 * kLowLd; } // ti > tj
+};
+
+// G (tile layout of the symmetric matrix, as load_tiles_lower_symmetric leaves it) -> LDS
+template <int NT>
+static DQQ_D void store_lower_to_lds(const v4d (&G)[NT][NT], double* __restrict__ lds, int lane)
+{
+    using L = LowerLds<NT>;
+    const int g = lane >> 4, l = lane & 15;
+    const int rowpart = g * kLowLd + l;                 // entry (4 r + g, l) of a tile: + 4 r * kLowLd
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (ti > tj) {
+                    lds[L::tile_base(ti, tj) + 4 * r * kLowLd + rowpart] = G[ti][tj][r];
+                } else {
+                    const int a = 4 * r + g;                                // row inside the diagonal tile
+                    if (a >= l) lds[L::DIAG0 + 136 * ti + a * (a + 1) / 2 + l] = G[ti][ti][r];
+                }
+            }
+}
+
+template <int NT>
+static DQQ_D void load_lower_from_lds(v4d (&G)[NT][NT], const double* __restrict__ lds, int lane)
+{
+    using L = LowerLds<NT>;
+    const int g = lane >> 4, l = lane & 15;
+    const int rowpart = g * kLowLd + l;                 // S[16 ti + 4 r + g][16 tj + l], ti > tj: tile (ti,tj) along its rows
+    const int colpart = l * kLowLd + g;                 // ti < tj: tile (tj,ti) entry (l, 4 r + g): along its columns
+    const int tril = l * (l + 1) / 2 + g;               // diagonal tile, upper half: packed entry (l, 4 r + g)
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double v;
+                if (ti > tj) v = lds[L::tile_base(ti, tj) + 4 * r * kLowLd + rowpart];
+                else if (ti < tj) v = lds[L::tile_base(tj, ti) + 4 * r + colpart];
+                else {
+                    const int a = 4 * r + g;
+                    v = lds[L::DIAG0 + 136 * ti + ((a >= l) ? a * (a + 1) / 2 + l : tril + 4 * r)];
+                }
+                G[ti][tj][r] = v;
+            }
+}
+
 template <int KIND, int NT, bool PAD>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT == 4 ? 2 : (NT == 3 ? 3 : 4)))) void fwd_dense_wave64_kernel(
     const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ l_n,
@@ -100,6 +161,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT == 4 ?
     // KIND 2 / 3 (box / signed box QP): l_n = l_min, mu_c = l_max per coordinate.  PAD: N < 16 NT.
     constexpr bool QP_LIKE = (KIND != 1);
     const long count = use_worklist ? (long)ws[kWsCount] : B;
+    __shared__ __attribute__((aligned(16))) double s_lower[LowerLds<NT>::DOUBLES]; // one wave per workgroup
 
     for (long w = blockIdx.x;; w += gridDim.x) {
         // work-list mode: entries are claimed one at a time (iteration counts differ by 2x between problems; a fixed
@@ -151,11 +213,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT == 4 ?
         }
         double qp = qi, l2 = 0.0, l2p = 0.0, u = 0.0;
         int it_done = 0;
-        bool need_refactor = true;
+        bool need_refactor = true, first_factor = true;
         double inv_rho = 1.0 / rho;
         for (int it = 0; it < max_iter; ++it) {
             if (need_refactor) { // llt() + solveInPlace(Identity) of P + shift, Solver.cpp:76-77: W.G <- -(P + shift)^-1
-                load_tiles_lower_symmetric<NT, PAD>(W.G, Pg, N, lane);
+                if (first_factor) {      // from global memory once; the lower triangle stays in LDS for the rho updates
+                    load_tiles_lower_symmetric<NT, PAD>(W.G, Pg, N, lane);
+                    store_lower_to_lds<NT>(W.G, s_lower, lane);
+                    wave_lds_fence();
+                    first_factor = false;
+                } else {
+                    load_lower_from_lds<NT>(W.G, s_lower, lane);
+                }
                 set_tile_diagonal<NT>(W.G, mdiag, lane);
                 block_sweep_inverse<NT>(W.G, lane, bad);
                 need_refactor = false;
