@@ -162,6 +162,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT == 4 ?
     constexpr bool QP_LIKE = (KIND != 1);
     const long count = use_worklist ? (long)ws[kWsCount] : B;
     __shared__ __attribute__((aligned(16))) double s_lower[LowerLds<NT>::DOUBLES]; // one wave per workgroup
+    __shared__ __attribute__((aligned(16))) double s_tr[16 * kTrLd];                // tile transposes of the sweep
 
     for (long w = blockIdx.x;; w += gridDim.x) {
         // work-list mode: entries are claimed one at a time (iteration counts differ by 2x between problems; a fixed
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT == 4 ?
                     load_lower_from_lds<NT>(W.G, s_lower, lane);
                 }
                 set_tile_diagonal<NT>(W.G, mdiag, lane);
-                block_sweep_inverse<NT>(W.G, lane, bad);
+                block_sweep_inverse<NT>(W.G, lane, bad, s_tr);
                 need_refactor = false;
                 inv_rho = 1.0 / rho;
             }

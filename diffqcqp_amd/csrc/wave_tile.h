@@ -299,11 +299,32 @@ DQQ_D v4d tile_xty(v4d acc, const v4d& X, const v4d& Y)
     return acc;
 }
 
+// The transpose of a tile through a wave-private LDS buffer of 16 x 17 doubles: written along its rows, read along
+// its columns (the odd stride keeps both conflict-free).  8 LDS instructions instead of the 4 MFMAs of a product with
+// the identity -- and on MI355X an FP64 MFMA occupies the FP64 vector ALUs for 69 cycles, an LDS
+// round trip does not.
+constexpr int kTrLd = 17;
+DQQ_D v4d tile_transpose_lds(const v4d& T, double* __restrict__ buf, int lane)
+{
+    const int g = lane >> 4, n = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) buf[(4 * r + g) * kTrLd + n] = T[r];
+    wave_lds_fence();
+    v4d R;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) R[r] = buf[n * kTrLd + 4 * r + g];
+    wave_lds_fence(); // the buffer is free for the next tile
+    return R;
+}
+
 // In place: G (symmetric positive definite, tile layout) -> -G^-1, by four block sweeps:
-//   D = G_KK^-1;  B_J = D G_KJ;  G_IJ -= G_KI^T B_J (I, J != K);  G_JK = G_KJ^T D;  G_KJ = B_J;  G_KK = -D
-// Every product is an X^T Y (the matrix stays symmetric), 60 tile products = 240 MFMAs in all.
+//   D = G_KK^-1;  B_J = D G_KJ;  G_IJ -= G_KI^T B_J (I <= J, both != K);  G_JI = G_IJ^T;  G_KJ = B_J;  G_JK = B_J^T;
+//   G_KK = -D
+// The matrix stays symmetric, so only the upper half of the update and B_J are products on the matrix cores (3 + 6 per
+// step for 4 x 4 tiles); their mirror images are transposes through LDS (`trbuf`, 16 x 17 doubles).  Round 2 computed
+// all 15 tiles of a step as products (208 live MFMAs per sweep; now 144).
 template <int NT, int K>
-DQQ_D void block_sweep_step(v4d (&G)[NT][NT], int lane, bool& bad)
+DQQ_D void block_sweep_step(v4d (&G)[NT][NT], int lane, bool& bad, double* __restrict__ trbuf)
 {
     const v4d zero = {0.0, 0.0, 0.0, 0.0};
     const v4d D = diag16_inverse(G[K][K], lane, bad);
@@ -316,25 +337,30 @@ DQQ_D void block_sweep_step(v4d (&G)[NT][NT], int lane, bool& bad)
         if (I == K) continue;
         const v4d nX = -G[K][I];
 #pragma unroll
-        for (int J = 0; J < NT; ++J)
+        for (int J = I; J < NT; ++J)
             if (J != K) G[I][J] = tile_xty(G[I][J], nX, Bt[J]);
     }
 #pragma unroll
-    for (int J = 0; J < NT; ++J)
-        if (J != K) G[J][K] = tile_xty(zero, G[K][J], D);
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = I + 1; J < NT; ++J)
+            if (I != K && J != K) G[J][I] = tile_transpose_lds(G[I][J], trbuf, lane);
 #pragma unroll
     for (int J = 0; J < NT; ++J)
-        if (J != K) G[K][J] = Bt[J];
+        if (J != K) {
+            G[K][J] = Bt[J];
+            G[J][K] = tile_transpose_lds(Bt[J], trbuf, lane);
+        }
     G[K][K] = -D;
 }
 
 template <int NT>
-DQQ_D void block_sweep_inverse(v4d (&G)[NT][NT], int lane, bool& bad)
+DQQ_D void block_sweep_inverse(v4d (&G)[NT][NT], int lane, bool& bad, double* __restrict__ trbuf)
 {
-    block_sweep_step<NT, 0>(G, lane, bad);
-    if constexpr (NT > 1) block_sweep_step<NT, 1>(G, lane, bad);
-    if constexpr (NT > 2) block_sweep_step<NT, 2>(G, lane, bad);
-    if constexpr (NT > 3) block_sweep_step<NT, 3>(G, lane, bad);
+    block_sweep_step<NT, 0>(G, lane, bad, trbuf);
+    if constexpr (NT > 1) block_sweep_step<NT, 1>(G, lane, bad, trbuf);
+    if constexpr (NT > 2) block_sweep_step<NT, 2>(G, lane, bad, trbuf);
+    if constexpr (NT > 3) block_sweep_step<NT, 3>(G, lane, bad, trbuf);
 }
 
 } // namespace dqq
