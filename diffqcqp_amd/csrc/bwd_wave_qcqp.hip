@@ -30,6 +30,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     double dual_eps, int* __restrict__ ir_steps, int* __restrict__ ws, int use_worklist)
 {
     constexpr int NT = 3;
+    __shared__ __attribute__((aligned(16))) double s_trb[16 * kTrLd]; // tile transposes (one wave per workgroup)
     const long count = use_worklist ? (long)ws[kWsCount] : B;
     const int nc = N / 2;
     for (long w = blockIdx.x;; w += gridDim.x) {
@@ -133,16 +134,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         bool bad = false;
         C.factor(lane, bad);                                                  // :22
-        C.invert_in_place(lane);                                              // :23
-        const double KinvAb = sym_upper_matvec<NT>(C.U, Ab, xsrc, lane);      // :27
+        C.invert_in_place(lane, s_trb);                                              // :23
+        const double KinvAb = sym_upper_matvec<NT>(C.U, Ab, xsrc, lane, s_trb);      // :27
         double xs = 0.0;
         IrControl ctl;
         ctl.init();
         int steps = 0;
         for (int it = 0; it < kIrMaxIter; ++it) {
             steps = it + 1;
-            xs = it == 0 ? KinvAb : KinvAb + kMuIr * sym_upper_matvec<NT>(C.U, xs, xsrc, lane); // :29 (first body: x = 0)
-            const double d = sym_upper_matvec<NT>(Kc, xs, xsrc, lane) - Ab;   // :30
+            xs = it == 0 ? KinvAb : KinvAb + kMuIr * sym_upper_matvec<NT>(C.U, xs, xsrc, lane, s_trb); // :29 (first body: x = 0)
+            const double d = sym_upper_matvec<NT>(Kc, xs, xsrc, lane, s_trb) - Ab;   // :30
             const double res = sqrt(wave_sum64(d * d));                       // :31
             if (ctl.update(res)) break;                                       // :32-41
         }

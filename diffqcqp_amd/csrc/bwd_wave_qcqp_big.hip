@@ -104,10 +104,9 @@ DQQ_D void tile_dot4_of(double& acc, const v4d& tile, double x0c, double x0k)
 // (yc, yk) = S (vc, vk) for the symmetric S whose UPPER tiles are in Su
 template <int NX, int NCT>
 DQQ_D void sym_upper_matvec2(const v4d (&Su)[NX + NCT][NX + NCT], double vc, double vk, int xsrc, int lane, double& yc,
-                             double& yk)
+                             double& yk, double* __restrict__ trbuf)
 {
     constexpr int NT = NX + NCT;
-    const v4d I16 = identity_tile(lane);
     const double x0c = dpp_source(lane_gather(vc, xsrc)), x0k = dpp_source(lane_gather(vk, xsrc));
     double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; // a[0..3]: coordinate blocks, a[4..7]: contact blocks
     static_for<0, NT>([&](auto tjc) __attribute__((always_inline)) {
@@ -117,7 +116,7 @@ DQQ_D void sym_upper_matvec2(const v4d (&Su)[NX + NCT][NX + NCT], double vc, dou
             constexpr int TI = decltype(tic)::value;
             constexpr int AI = TI < NX ? TI : 4 + (TI - NX);
             tile_dot4_of<NX, TI>(a[AJ], Su[TI][TJ], x0c, x0k);
-            if constexpr (TI < TJ) tile_dot4_of<NX, TJ>(a[AI], tile_transpose(Su[TI][TJ], I16), x0c, x0k);
+            if constexpr (TI < TJ) tile_dot4_of<NX, TJ>(a[AI], tile_transpose_lds(Su[TI][TJ], trbuf, lane), x0c, x0k);
         });
     });
     yc = reduce_scatter4(a[0], a[1], a[2], a[3]);
@@ -134,6 +133,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 {
     constexpr int NT = NX + NCT;
     using Sys = QcqpSystem<NX, NCT>;
+    __shared__ __attribute__((aligned(16))) double s_trb[16 * kTrLd]; // tile transposes (one wave per workgroup)
     const long count = use_worklist ? (long)ws[kWsCount] : B;
     const int nc = N / 2;
     for (long w = blockIdx.x;; w += gridDim.x) {
@@ -225,9 +225,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
         }
         bool bad = false;
         C.factor(lane, bad);                                                  // :22
-        C.invert_in_place(lane);                                              // :23
+        C.invert_in_place(lane, s_trb);                                              // :23
         double Kc, Kk;                                                        // Kinv * Ab, :27
-        sym_upper_matvec2<NX, NCT>(C.U, Abc, Abk, xsrc, lane, Kc, Kk);
+        sym_upper_matvec2<NX, NCT>(C.U, Abc, Abk, xsrc, lane, Kc, Kk, s_trb);
         double xc = 0.0, xk = 0.0;
         IrControl ctl;
         ctl.init();
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
                 xc = Kc; xk = Kk;                                             // :29 (the first body multiplies x = 0)
             } else {
                 double yc, yk;
-                sym_upper_matvec2<NX, NCT>(C.U, xc, xk, xsrc, lane, yc, yk);
+                sym_upper_matvec2<NX, NCT>(C.U, xc, xk, xsrc, lane, yc, yk, s_trb);
                 xc = Kc + kMuIr * yc; xk = Kk + kMuIr * yk;
             }
             // residual (:30): K x - A dd = A (A^T x) + mu x - A dd, A streamed once more.  (The tiles do not depend on

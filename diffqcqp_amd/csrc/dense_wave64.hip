@@ -339,6 +339,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT >= 3 ?
     double dual_eps, int* __restrict__ ir_steps, int* __restrict__ ws, int use_worklist)
 {
     const long count = use_worklist ? (long)ws[kWsCount] : B;
+    __shared__ __attribute__((aligned(16))) double s_trb[16 * kTrLd]; // tile transposes (one wave per workgroup)
     for (long w = blockIdx.x;; w += gridDim.x) {
         if (use_worklist) { // (an empty list is left untouched: nobody would reset the counter)
             if (count == 0) break;
@@ -401,16 +402,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT >= 3 ?
         }
         bool bad = false;
         C.factor(lane, bad);                                                  // :22
-        C.invert_in_place(lane);                                              // :23; C.U = upper tiles of K^-1
-        const double KinvAb = sym_upper_matvec<NT>(C.U, Ab, xsrc, lane);      // :27
+        C.invert_in_place(lane, s_trb);                                              // :23; C.U = upper tiles of K^-1
+        const double KinvAb = sym_upper_matvec<NT>(C.U, Ab, xsrc, lane, s_trb);      // :27
         double xs = 0.0;
         IrControl ctl;
         ctl.init();
         int steps = 0;
         for (int it = 0; it < kIrMaxIter; ++it) {
             steps = it + 1;
-            xs = it == 0 ? KinvAb : KinvAb + kMuIr * sym_upper_matvec<NT>(C.U, xs, xsrc, lane); // :29 (first body: x = 0)
-            const double d = sym_upper_matvec<NT>(Kc, xs, xsrc, lane) - Ab;   // :30
+            xs = it == 0 ? KinvAb : KinvAb + kMuIr * sym_upper_matvec<NT>(C.U, xs, xsrc, lane, s_trb); // :29 (first body: x = 0)
+            const double d = sym_upper_matvec<NT>(Kc, xs, xsrc, lane, s_trb) - Ab;   // :30
             const double res = sqrt(wave_sum64(d * d));                       // :31
             if (ctl.update(res)) break;                                       // :32-41
         }

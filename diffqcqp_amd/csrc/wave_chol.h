@@ -182,13 +182,14 @@ struct WaveChol {
     // with 1e-10.  Through substitutions that noise is ~1e-14 and the loop always leaves after one body; through
     // the explicit inverse -- entries ~1e7 on a singular P -- it is ~1e-11 ... 1e-10 and the reference takes three
     // bodies on 10-95 % of such problems (tools/probe_illcond.py).  Same formulas as the reference => same coin.
-    DQQ_D void invert_in_place(int lane)
+    // trbuf: 16 x 17 doubles of wave-private LDS for the tile transposes (tile_transpose_lds: an FP64 MFMA keeps the
+    // FP64 vector ALUs busy for 69 cycles on this chip, an LDS round trip does not)
+    DQQ_D void invert_in_place(int lane, double* __restrict__ trbuf)
     {
         const v4d zero = {0.0, 0.0, 0.0, 0.0};
-        const v4d I16 = identity_tile(lane);
         static_for<0, NT>([&](auto jc) __attribute__((always_inline)) {
             constexpr int J = decltype(jc)::value;
-            const v4d Vj = tile_transpose(U[J][J], I16);         // (L^-1)_jj; U[J][J] (= W_j) stays until the end of column j
+            const v4d Vj = tile_transpose_lds(U[J][J], trbuf, lane); // (L^-1)_jj; U[J][J] (= W_j) stays until the end of column j
             static_for<J + 1, NT>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int I = decltype(ic)::value;
                 v4d S = tile_xty(zero, U[J][I], Vj);             // k = j: U_ji^T (L^-1)_jj
@@ -276,11 +277,10 @@ DQQ_D double reduce_scatter4(double a0, double a1, double a2, double a3)
 }
 
 // y = S x for the symmetric S whose UPPER tiles are in Su (x, y one element per lane; xsrc = 4 (lane & 15) + (lane >> 4)):
-// the lower tiles are transposes of the upper ones, made on the matrix cores
+// the lower tiles are transposes of the upper ones, made through LDS (trbuf: 16 x 17 doubles, wave-private)
 template <int NT>
-DQQ_D double sym_upper_matvec(const v4d (&Su)[NT][NT], double x, int xsrc, int lane)
+DQQ_D double sym_upper_matvec(const v4d (&Su)[NT][NT], double x, int xsrc, int lane, double* __restrict__ trbuf)
 {
-    const v4d I16 = identity_tile(lane);
     const double x0 = dpp_source(lane_gather(x, xsrc)); // lane (g, n') <- x[4 n' + g]
     double a[4] = {0.0, 0.0, 0.0, 0.0};
     static_for<0, NT>([&](auto tjc) __attribute__((always_inline)) {
@@ -288,7 +288,7 @@ DQQ_D double sym_upper_matvec(const v4d (&Su)[NT][NT], double x, int xsrc, int l
         static_for<0, TJ + 1>([&](auto tic) __attribute__((always_inline)) {
             constexpr int TI = decltype(tic)::value;
             tile_dot4<4 * TI>(a[TJ], Su[TI][TJ], x0);                     // rows of block TI into block TJ
-            if constexpr (TI < TJ) tile_dot4<4 * TJ>(a[TI], tile_transpose(Su[TI][TJ], I16), x0);
+            if constexpr (TI < TJ) tile_dot4<4 * TJ>(a[TI], tile_transpose_lds(Su[TI][TJ], trbuf, lane), x0);
         });
     });
     double p, q2, s02, s13, e, o;
