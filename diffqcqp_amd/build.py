@@ -22,7 +22,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math
           "-Wall", "-Wno-unused-function"]
 # translation unit -> extra flags
 UNITS = {
-    "fwd_diag.hip": ["-ffp-contract=fast"],
+    "fwd_diag.hip": ["-ffp-contract=fast-honor-pragmas"],
     "bwd_diag.hip": ["-ffp-contract=off"],
     "dense.hip": ["-ffp-contract=off"],
     "general_any.hip": ["-ffp-contract=off"],

@@ -45,9 +45,20 @@ namespace dqq {
 // Reciprocals of E positive numbers from ONE reciprocal (of their product) and 3(E-1) multiplications: 14 instead
 // of 20 instructions at E = 4.  Each result carries ~3 roundings instead of 1.  A product that leaves the double
 // range (entries beyond ~1e75) or a non-positive factor falls back to one reciprocal per entry.
+// E = 4 (N = 8 on two lanes per problem, ...) goes two by two, so that its reciprocals are bit-identical to the ones
+// the same problem gets on twice the lanes with E = 2 (admm_fwd_diag_respread moves problems between the two).
 template <int E>
 DQQ_HD void rcp_all(const double (&m)[E], double (&inv)[E])
 {
+    if constexpr (E == 4) {
+        const double a[2] = {m[0], m[1]}, b[2] = {m[2], m[3]};
+        double ia[2], ib[2];
+        rcp_all<2>(a, ia);
+        rcp_all<2>(b, ib);
+        inv[0] = ia[0]; inv[1] = ia[1]; inv[2] = ib[0]; inv[3] = ib[1];
+        return;
+    }
+    // (E != 4 from here on)
     double pre[E];
     pre[0] = m[0];
 #pragma unroll
@@ -93,5 +104,151 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
     for (int e = 0; e < E; ++e) x[e] = bad ? NAN : l2[e];
     return iters;
 }
+
+
+#if defined(__HIPCC__) // (the solver above also compiles for the host: tests/hostcore)
+// The loop of admm_fwd_diag from iteration it0 on, over state that already exists (admm_fwd_diag_respread's second
+// phase).  Returns through the state; `iters` is the number of iterations executed in total.
+template <int KIND, int E, class G>
+DQQ_D void admm_diag_resume(double (&M)[E], double (&Minv)[E], const double (&q)[E], double (&qp)[E], double (&l2)[E],
+                            double (&u)[E], const double* rad, double& rho, double& inv_rho, double& tau_inc,
+                            double& tau_dec, double& Mmin, int& rho_up, int& cpt, bool& bad, int& iters, int it0,
+                            int max_iter, double eps, double mu, int adaptive, bool valid)
+{
+    constexpr bool QP_LIKE = (KIND != 1);
+    static_assert(KIND < 2, "QP / QCQP");
+    const double *lo = nullptr, *hi = nullptr, *sg = nullptr;
+    (void)lo; (void)hi; (void)sg;
+    if (valid) {
+        for (int it = it0; it < max_iter; ++it) {
+#define DQQ_ADMM_ON_STOP break
+#include "admm_diag_body.inc"
+#undef DQQ_ADMM_ON_STOP
+        }
+    }
+}
+
+// admm_fwd_diag for N = 8 on TWO lanes per problem (E = 4) that re-spreads the tail of its tile: once at most
+// `respread_at` (<= 16) of the wave's 32 problems are still iterating, their state moves -- through `lds`, 256
+// wave-private doubles -- onto FOUR lanes per problem (E = 2, problem r of the survivors on lanes 4r..4r+3) and
+// the loop goes on with half the per-coordinate arithmetic per iteration: a launch lasts as long as its slowest
+// problems (8..38 iterations at the bench shape, median 17) and those spent the second half of their iterations
+// in a half-empty wave.
+// Results are bit-identical to the un-respread solve: the per-coordinate arithmetic is the same code, the group
+// maxima are exact, the reciprocals are taken pair by pair (rcp_all<4>) and |l|^2 is summed contact by contact
+// in the order of the lane tree -- so a problem's result does not depend on what else is in its tile.
+// A problem that moved (moved = true on its two phase-1 lanes) has its x and iteration count stored from here
+// (xout / itout point at the tile's first problem); the others return theirs as admm_fwd_diag does.
+template <int KIND>
+DQQ_D int admm_fwd_diag_respread(const double (&p)[4], const double (&q)[4], const double* rad, double eps, double mu,
+                                 int max_iter, int adaptive, bool valid, double (&x)[4], int respread_at, double* lds,
+                                 double* __restrict__ xout, int* __restrict__ itout, bool& moved)
+{
+    constexpr int E = 4;
+    using G = LaneGroup<2>;
+    constexpr bool QP_LIKE = (KIND != 1);
+    static_assert(KIND < 2, "QP / QCQP");
+    const double *lo = nullptr, *hi = nullptr, *sg = nullptr;
+    (void)lo; (void)hi; (void)sg;
+#include "admm_diag_prologue.inc"
+
+    int rho_up = 0, cpt = 0, iters = 0, it_next = 0;
+    bool more = false;
+    const int lanes_at = 2 * respread_at;
+    if (valid) {
+        for (int it = 0; it < max_iter; ++it) {
+#define DQQ_ADMM_ON_STOP break
+#include "admm_diag_body.inc"
+#undef DQQ_ADMM_ON_STOP
+            // lanes still in this loop = the execution mask
+            if (__popcll(__ballot(true)) <= lanes_at) {
+                more = it + 1 < max_iter;
+                it_next = it + 1;
+                break;
+            }
+        }
+    }
+    moved = more;
+    const unsigned long long mm = __ballot(more);
+    if (mm != 0) { // wave-uniform
+        constexpr int E2 = 2;
+        using G4 = LaneGroup<4>;
+        const int lane = threadIdx.x & 63, h = lane & 1;
+        const unsigned long long firsts = mm & 0x5555555555555555ull;       // one bit per moving problem
+        const int r = __popcll(firsts & ((1ull << (lane & ~1)) - 1));       // its rank among them
+        const int nmv = __popcll(firsts);
+        const bool valid2 = lane < 4 * nmv;
+        // four coordinates of lane (r, h) -> slots 8r+4h .. +3; lane 4r+s of the new layout owns slots 8r+2s, +1 = 2*lane, +1
+        double* mine = lds + 8 * r + 4 * h;
+        auto move = [&](const double (&a)[4], const double (&b)[4], double (&a2)[2], double (&b2)[2]) {
+            wave_lds_fence();
+            if (more) {
+                *reinterpret_cast<double2*>(mine) = make_double2(a[0], a[1]);
+                *reinterpret_cast<double2*>(mine + 2) = make_double2(a[2], a[3]);
+                *reinterpret_cast<double2*>(mine + 128) = make_double2(b[0], b[1]);
+                *reinterpret_cast<double2*>(mine + 130) = make_double2(b[2], b[3]);
+            }
+            wave_lds_fence();
+            const double2 ta = *reinterpret_cast<const double2*>(lds + 2 * lane);
+            const double2 tb = *reinterpret_cast<const double2*>(lds + 128 + 2 * lane);
+            a2[0] = ta.x; a2[1] = ta.y;
+            b2[0] = tb.x; b2[1] = tb.y;
+        };
+        double M2[E2], Minv2[E2], q2[E2], qp2[E2], l22[E2], u2[E2], rad2[1];
+        move(M, Minv, M2, Minv2);
+        move(q, qp, q2, qp2);
+        move(l2, u, l22, u2);
+        // per-problem scalars (identical on both lanes of a problem: lane h = 0 hands them over), the radii and
+        // the problem's position in the tile
+        wave_lds_fence();
+        int* ldsi = reinterpret_cast<int*>(lds + 128);
+        if (more) {
+            if (h == 0) {
+                lds[r] = rho;
+                lds[16 + r] = inv_rho;
+                lds[32 + r] = tau_inc;
+                lds[48 + r] = tau_dec;
+                ldsi[r] = rho_up;
+                ldsi[16 + r] = cpt;
+                ldsi[32 + r] = lane >> 1;
+                ldsi[48 + r] = bad ? 1 : 0;
+                ldsi[64] = it_next;  // the same on every lane that moves
+            }
+            lds[64 + 4 * r + 2 * h] = rad[0];
+            lds[64 + 4 * r + 2 * h + 1] = rad[1];
+        }
+        wave_lds_fence();
+        const int g = lane >> 2;
+        double rho2 = lds[g], inv_rho2 = lds[16 + g], tau_inc2 = lds[32 + g], tau_dec2 = lds[48 + g];
+        int rho_up2 = ldsi[g], cpt2 = ldsi[16 + g];
+        const int pl2 = ldsi[32 + g];
+        bool bad2 = ldsi[48 + g] != 0;
+        const int it0 = ldsi[64];
+        rad2[0] = lds[64 + lane];
+        wave_lds_fence();
+        if (!valid2) { // idle lanes: harmless numbers
+            rho2 = inv_rho2 = tau_inc2 = tau_dec2 = 1.0;
+            rad2[0] = 1.0;
+            bad2 = false;
+#pragma unroll
+            for (int e = 0; e < E2; ++e) { M2[e] = Minv2[e] = 1.0; q2[e] = qp2[e] = l22[e] = u2[e] = 0.0; }
+        }
+        double Mmin2 = fmin(M2[0], M2[1]);
+        int iters2 = it0;
+        admm_diag_resume<KIND, E2, G4>(M2, Minv2, q2, qp2, l22, u2, rad2, rho2, inv_rho2, tau_inc2, tau_dec2, Mmin2,
+                                       rho_up2, cpt2, bad2, iters2, it0, max_iter, eps, mu, adaptive, valid2);
+        bad2 = G4::max(bad2 ? 1.0 : 0.0) > 0.0;
+        if (valid2) {
+            *reinterpret_cast<double2*>(xout + pl2 * 8 + 2 * (lane & 3)) =
+                bad2 ? make_double2(NAN, NAN) : make_double2(l22[0], l22[1]);
+            if (itout != nullptr && (lane & 3) == 0) itout[pl2] = iters2;
+        }
+    }
+    bad = G::max(bad ? 1.0 : 0.0) > 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) x[e] = bad ? NAN : l2[e];
+    return iters;
+}
+#endif // __HIPCC__
 
 } // namespace dqq

@@ -9,6 +9,7 @@
 namespace dqq {
 extern std::atomic<int> g_dense_block;
 extern std::atomic<int> g_fwd_compact;
+extern std::atomic<int> g_fwd_respread;
 extern std::atomic<int> g_dense_wave64;
 extern std::atomic<int> g_lane_dense;
 extern std::atomic<int> g_dense_teams;
@@ -31,6 +32,7 @@ struct Option {
 Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback", &g_auto_fallback},
                       {"fuse_fallback", &g_fuse},
                       {"fwd_compact", &dqq::g_fwd_compact},
+                      {"fwd_respread", &dqq::g_fwd_respread},
                       {"dense_block", &dqq::g_dense_block},
                       {"dense_wave64", &dqq::g_dense_wave64},
                       {"lane_dense", &dqq::g_lane_dense},

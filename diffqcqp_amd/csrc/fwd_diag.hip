@@ -34,6 +34,12 @@ namespace dqq {
 #define DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE) \
     __attribute__((amdgpu_waves_per_eu(((FUSE) && (N) == 8 && (LPP) <= 2 && (KIND) < 2) ? 4 : 1, 8)))
 
+// Option "fwd_respread": once at most this many (0..16) of a wave's 32 problems are still iterating, they move onto
+// twice the lanes (admm_core.h admm_fwd_diag_respread; N = 8, two lanes per problem, QP / QCQP).  0 = never.
+// Results do not depend on it (bit-identical, tests/test_gpu_compaction.py).
+std::atomic<int> g_fwd_respread{16};
+constexpr bool fwd_diag_respreads(int kind, int n, int lpp) { return kind < 2 && n == 8 && lpp == 2; }
+
 // CMP: the tiles of a workgroup are repacked as their problems stop (admm_compact.h); a workgroup that meets a
 // non-diagonal tile runs the plain per-wave solve instead.
 template <int KIND, int N, int LPP, int WPB, bool FUSE, bool CMP = false>
@@ -46,7 +52,7 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
                                                             int adaptive, int layout, int* __restrict__ iters,
                                                             int* __restrict__ ws,
                                                             double* __restrict__ pdiag_out,
-                                                            unsigned char* __restrict__ flags_out)
+                                                            unsigned char* __restrict__ flags_out, int respread_at)
 {
     constexpr int E = N / LPP;       // coordinates per lane
     constexpr int PPW = 64 / LPP;    // problems per wave tile
@@ -194,9 +200,17 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
             }
         }
     }
-    if (!solved)
-        it = admm_fwd_diag<KIND, E, LaneGroup<LPP>>(p, qv, rad, N, eps, mu_prox, max_iter, adaptive, valid, xv, lo, hi,
-                                                    sg);
+    // N = 8 on two lanes per problem: the tail of the tile moves onto four lanes per problem (admm_core.h)
+    constexpr bool RSP = fwd_diag_respreads(KIND, N, LPP) && !CMP;
+    [[maybe_unused]] bool moved = false; // this lane's problem was finished (and stored) in the re-spread layout
+    if (!solved) {
+        if constexpr (RSP)
+            it = admm_fwd_diag_respread<KIND>(p, qv, rad, eps, mu_prox, max_iter, adaptive, valid, xv, respread_at,
+                                              s_diag[wave], x + first * N, iters ? iters + first : nullptr, moved);
+        else
+            it = admm_fwd_diag<KIND, E, LaneGroup<LPP>>(p, qv, rad, N, eps, mu_prox, max_iter, adaptive, valid, xv, lo,
+                                                        hi, sg);
+    }
 #ifdef DQQ_TIMELINE
     {
         int m = valid ? it : 0, s = valid ? it : 0;
@@ -207,10 +221,12 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
 #endif
 
     if (valid) {
-        double* xx = x + first * N + lane * E;
+        if (!moved) {
+            double* xx = x + first * N + lane * E;
 #pragma unroll
-        for (int e = 0; e < E; e += 2) *reinterpret_cast<double2*>(xx + e) = make_double2(xv[e], xv[e + 1]);
-        if (iters != nullptr && (lane % LPP) == 0) iters[first + pl] = it;
+            for (int e = 0; e < E; e += 2) *reinterpret_cast<double2*>(xx + e) = make_double2(xv[e], xv[e + 1]);
+            if (iters != nullptr && (lane % LPP) == 0) iters[first + pl] = it;
+        }
         // hand the verified diagonal to the backward of the same problems (it then skips the P stream)
         if (flags_out != nullptr && (lane % LPP) == 0 && !dense_tile) flags_out[first + pl] = 1;
         if (pdiag_out != nullptr && !dense_tile) {
@@ -231,7 +247,7 @@ static hipError_t launch_one(const FwdArgs& a, hipStream_t s)
     if (nblocks == 0) return hipSuccess;
     return launch((fwd_diag_kernel<KIND, N, LPP, WPB, FUSE, CMP>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q,
                        a.l_n, a.mu, a.v, a.x, a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.layout, a.iters, a.ws,
-                       a.pdiag_out, a.flags_out);
+                       a.pdiag_out, a.flags_out, std::min(16, std::max(0, g_fwd_respread.load())));
 }
 
 // Option "fwd_compact": 1 = repack the tiles of a workgroup as their problems stop (admm_compact.h).  OFF by

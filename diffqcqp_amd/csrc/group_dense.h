@@ -266,7 +266,7 @@ DQQ_D int group_dense_fwd(const double* __restrict__ Pg, const double (&q)[N / L
 #define DQQ_ADMM_SOLVE(l)                                                                                             \
     do {                                                                                                              \
         double rhs_[E];                                                                                               \
-        _Pragma("unroll") for (int e_ = 0; e_ < E; ++e_) rhs_[e_] = rho * l2[e_] - u[e_] - qp[e_];                    \
+        _Pragma("unroll") for (int e_ = 0; e_ < E; ++e_) rhs_[e_] = __builtin_fma(rho, l2[e_], -u[e_]) - qp[e_];                  \
         R::matvec(A, rhs_, l);                                                                                        \
     } while (0)
 #define DQQ_ADMM_REFACTOR(delta)                                                                                      \
