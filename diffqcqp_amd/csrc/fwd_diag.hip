@@ -287,25 +287,35 @@ static const int* lpp_choices(int N, int& count)
     }
 }
 
-// Built-in choice.  N <= 16: fewer lanes per problem = fewer VALU instructions per problem (the scalar
-// rho/tau/stop logic and the pow() prologue are replicated on every lane of a problem), but the
-// kernel is latency-bound with a single wave per SIMD, so take the smallest LPP that still puts
-// about two waves on each of the chip's 1024 SIMDs.  N >= 32: a wave first streams 32+ KiB of P per
-// problem, and the smaller its tile, the finer that stream interleaves with other waves' arithmetic
-// -- the most lanes per problem win at every batch size measured (N=32 QP forward, LPP 4 / 8 / 16:
-// B=32768 73 / 68 / 63 us, B=262144 478 / 458 / 442 us; QCQP B=32768 84 / 78 / 69 us; N=64 alike).
-int fwd_diag_default_lpp(int N, long B)
+// Built-in choice, from sweeps on MI355X (tools/probe_lpp_sweep.py; us per forward launch, QP / QCQP):
+//   N = 8    B = 49152: LPP 4 20.6 / 25.5, LPP 2 23.0 / 28.7;   65536: LPP 2 25.0 / 30.3, LPP 4 27.4 / 34.5;
+//            131072: LPP 2 39.9 / 48.0, LPP 4 47.3 / 55.5;      262144: LPP 1 66.1 / 93.2, LPP 2 69.8 / 81.7;
+//            524288: LPP 1 119.5 / 176.0, LPP 2 126.2 / 150.8
+//   N = 16   B = 32768: LPP 8 33.3 / 38.4, LPP 4 33.8 / 38.8;   65536: LPP 4 51.2 / 59.6, LPP 2 54.2 / 66.6;
+//            262144: LPP 4 150.3 / 169.1, LPP 2 153.6 / 194.4, LPP 8 166.1 / 184.4
+//   N = 4    LPP 2 below 131072 problems (32768: 12.6 / 15.6 against 16.4 / 22.2), LPP 1 from there on
+// Fewer lanes per problem = fewer instructions per problem (the scalar rho / tau / stop logic and the pow()
+// prologue are replicated on every lane of a problem), more lanes = more waves to hide the latency of a small
+// batch behind; four coordinates per lane is the sweet spot of a batch that fills the chip, and the QCQP at
+// N = 8 keeps it at every size because its tiles re-spread their tails (admm_fwd_diag_respread).
+// N >= 32: a wave first streams 32+ KiB of P per problem, and the smaller its tile, the finer that stream
+// interleaves with other waves' arithmetic -- the most lanes per problem win at every batch size measured
+// (N=32 QP forward, LPP 4 / 8 / 16: B=32768 73 / 68 / 63 us, B=262144 478 / 458 / 442 us; QCQP B=32768
+// 84 / 78 / 69 us; N=64 alike).
+int fwd_diag_default_lpp(int N, long B, int kind)
 {
     int count = 0;
     const int* c = lpp_choices(N, count);
     if (count == 0) return 0;
     if (N >= 32) return c[count - 1];
+    if (N == 16) return B <= 40960 ? 8 : 4;
+    if (N == 8) return B < 57344 ? 4 : (B < 262144 || kind == kKindQCQP) ? 2 : 1;
     for (int i = 0; i < count; ++i)
         if (B * c[i] / 64 >= 2048) return c[i];
     return c[count - 1];
 }
 
-bool fwd_diag_supported(int N) { return fwd_diag_default_lpp(N, 1) != 0; }
+bool fwd_diag_supported(int N) { return fwd_diag_default_lpp(N, 1, 0) != 0; }
 
 
 template <int KIND>
@@ -353,7 +363,7 @@ hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fus
     if (wpb != 1 && wpb != 4) wpb = 4;
     const bool fuse = fwd_diag_will_fuse(a.N, a.B, a.layout, fuse_opt);
     if (lpp <= 0) {
-        lpp = fwd_diag_default_lpp(a.N, a.B);
+        lpp = fwd_diag_default_lpp(a.N, a.B, kind);
         // a batch declared dense takes the general solve's own mapping (N/2 lanes per problem): one pass per tile
         if (a.layout == DQQ_P_DENSE && a.N <= 8) lpp = a.N / 2;
     }
@@ -369,7 +379,7 @@ hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fus
         }
     };
     bool found = dispatch(lpp);
-    if (!found) found = dispatch(fwd_diag_default_lpp(a.N, a.B));
+    if (!found) found = dispatch(fwd_diag_default_lpp(a.N, a.B, kind));
     return found ? e : hipErrorInvalidValue;
 }
 

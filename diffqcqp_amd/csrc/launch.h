@@ -147,7 +147,7 @@ constexpr int kKindQP = 0, kKindQCQP = 1, kKindBox = 2, kKindSignedBox = 3;
 bool fwd_diag_supported(int N);
 bool fwd_diag_fuses_fallback(int N, long B);
 bool bwd_diag_fuses_fallback(int N, long B);
-int fwd_diag_default_lpp(int N, long B);
+int fwd_diag_default_lpp(int N, long B, int kind);
 // fuse_opt: -1 built-in choice, 0 never, 1 whenever instantiated.  *needs_fallback: launch the dense kernel
 // in work-list mode behind this one.
 hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fuse_opt, hipStream_t s,
