@@ -289,15 +289,15 @@ static const int* lpp_choices(int N, int& count)
 
 // Built-in choice, from sweeps on MI355X (tools/probe_lpp_sweep.py; us per forward launch, QP / QCQP):
 //   N = 8    B = 49152: LPP 4 20.6 / 25.5, LPP 2 23.0 / 28.7;   65536: LPP 2 25.0 / 30.3, LPP 4 27.4 / 34.5;
-//            131072: LPP 2 39.9 / 48.0, LPP 4 47.3 / 55.5;      262144: LPP 1 66.1 / 93.2, LPP 2 69.8 / 81.7;
-//            524288: LPP 1 119.5 / 176.0, LPP 2 126.2 / 150.8
+//            131072: LPP 2 39.9 / 48.0, LPP 4 47.3 / 55.5;      262144: LPP 1 67 / 93, LPP 2 (fused kernel) 66 / 79;
+//            1048576: LPP 1 238 / 326, LPP 2 (fused kernel) 222 / 264
 //   N = 16   B = 32768: LPP 8 33.3 / 38.4, LPP 4 33.8 / 38.8;   65536: LPP 4 51.2 / 59.6, LPP 2 54.2 / 66.6;
 //            262144: LPP 4 150.3 / 169.1, LPP 2 153.6 / 194.4, LPP 8 166.1 / 184.4
 //   N = 4    LPP 2 below 131072 problems (32768: 12.6 / 15.6 against 16.4 / 22.2), LPP 1 from there on
 // Fewer lanes per problem = fewer instructions per problem (the scalar rho / tau / stop logic and the pow()
 // prologue are replicated on every lane of a problem), more lanes = more waves to hide the latency of a small
-// batch behind; four coordinates per lane is the sweet spot of a batch that fills the chip, and the QCQP at
-// N = 8 keeps it at every size because its tiles re-spread their tails (admm_fwd_diag_respread).
+// batch behind; four coordinates per lane is the sweet spot of a batch that fills the chip (at N = 8 also because
+// those tiles re-spread their tails, admm_fwd_diag_respread).
 // N >= 32: a wave first streams 32+ KiB of P per problem, and the smaller its tile, the finer that stream
 // interleaves with other waves' arithmetic -- the most lanes per problem win at every batch size measured
 // (N=32 QP forward, LPP 4 / 8 / 16: B=32768 73 / 68 / 63 us, B=262144 478 / 458 / 442 us; QCQP B=32768
@@ -309,7 +309,7 @@ int fwd_diag_default_lpp(int N, long B, int kind)
     if (count == 0) return 0;
     if (N >= 32) return c[count - 1];
     if (N == 16) return B <= 40960 ? 8 : 4;
-    if (N == 8) return B < 57344 ? 4 : (B < 262144 || kind == kKindQCQP) ? 2 : 1;
+    if (N == 8) return B < 57344 ? 4 : 2;
     for (int i = 0; i < count; ++i)
         if (B * c[i] / 64 >= 2048) return c[i];
     return c[count - 1];
@@ -333,13 +333,22 @@ static bool launch_kind(const FwdArgs& a, int lpp, int wpb, bool fuse, hipStream
     return false;
 }
 
-// The in-kernel dense fallback costs the fast path registers (occupancy), which only matters once the
-// batch is large enough to want more than two waves per SIMD; below that it saves the extra launch.  Only where
-// the fallback solves a whole tile at once (group_dense.h, N <= 8): the per-problem fallback of N = 16 makes a
-// dense batch 3-10x slower than the work-list route (4096 x 16: 735 vs 81 us), for 3 us saved on a diagonal one.
+// In-kernel solve of non-diagonal tiles (fused) against queueing them for the dense kernel launched behind (work-list),
+// forward, us per launch (tools/probe_fuse_n.py; diagonal batch QP / QCQP, then dense batch QP / QCQP):
+//   N = 2  B = 131072: fused 14 / 19, 34 / 25, work-list 17 / 21, 53 / 46;  1048576: fused 68 / 87, 154 / 106,
+//          work-list 74 / 92, 279 / 271                                      -> fused at every size
+//   N = 4  B = 65536: fused 16 / 22, 38 / 38, work-list 17 / 24, 45 / 48;   1048576: fused 122 / 157, 371 / 350,
+//          work-list 122 / 162, 321 / 344                                    -> fused up to 131072 problems
+//   N = 8  (two lanes per problem, 128 VGPRs either way) B = 131072: fused 40 / 48, 222 / 214, work-list 43 / 50,
+//          185 / 182;  1048576: fused 222 / 264, 1396 / 1338, work-list 236 / 278, 1308 / 1237
+//          -> fused at every size: the diagonal batch is what DQQ_P_AUTO is for (a batch known to be dense has
+//          DQQ_P_DENSE), and it saves the drain launch (2.5-5 us of a 56 us step at the bench shape)
+// Only where the fallback solves a whole tile at once (group_dense.h, N <= 8): the per-problem fallback of N = 16
+// makes a dense batch 3-10x slower than the work-list route (4096 x 16: 735 vs 81 us), for 3 us saved on a diagonal one.
 bool fwd_diag_fuses_fallback(int N, long B)
 {
-    return fwd_diag_supported(N) && fwd_diag_fuses(N) && N <= 8 && B <= 131072;
+    if (!(fwd_diag_supported(N) && fwd_diag_fuses(N) && N <= 8)) return false;
+    return N == 4 ? B <= 131072 : true;
 }
 
 // DQQ_P_DENSE batches the fused kernel's group solve (group_dense.h) takes from the lane-per-problem kernel:

@@ -135,8 +135,7 @@ struct BwdArgs {
 
 // Which N can solve their non-diagonal tiles inside the fast kernel (no fallback launch: an empty
 // work-list launch still costs ~4.6 us behind a 13-35 us kernel).  Chosen at launch from the batch size
-// (fwd/bwd_diag_fuses_fallback): the in-kernel general routine costs registers, which only pays while
-// the batch is too small to want more waves per SIMD anyway.
+// (fwd/bwd_diag_fuses_fallback, with the measurements behind the choice).
 constexpr bool fwd_diag_fuses(int N) { return N <= 16; }
 constexpr bool bwd_diag_fuses(int N) { return N <= 8; }
 

@@ -164,9 +164,12 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
  *   "wpb"            waves per workgroup of the diagonal kernels (1 or 4; 0 = built-in)
  *   "fuse_fallback"  DQQ_P_AUTO, N <= 16: solve non-diagonal tiles inside the fast kernel (1), queue them
  *                    for the dense kernel launched behind it (0), or decide from (N, B) (-1, default: the
- *                    forward inside for N <= 8 and B <= 131072, where it solves a whole tile at once on the fast
- *                    path's own lane mapping; the backward, whose in-kernel routine takes one problem per wave at
+ *                    forward inside for N = 2 and N = 8 at every batch size and for N = 4 up to 131072 problems,
+ *                    where it solves a whole tile at once on lanes of the fast path; the backward, whose in-kernel routine takes one problem per wave at
  *                    a time, never: its non-diagonal tiles are queued at every batch size)
+ *   "fwd_respread"   diagonal fast path, N = 8 on two lanes per problem: once at most this many (0..16, default
+ *                    16; 0 = never) of a wave's 32 problems are still iterating they move onto four lanes per
+ *                    problem and finish with half the arithmetic per lane.  Bit-identical results.
  *   "fwd_compact"    diagonal fast path, N = 8: repack the tiles of a workgroup as their problems stop (1), or
  *                    leave every tile to its wave (0, default: at the bench shape the barriers cost more than the
  *                    saved wave-iterations; it pays for heavy-tailed iteration counts).  Bit-identical results.
