@@ -61,16 +61,24 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : (KIND == 1 ? 4 :
     // The forward of these problems may have left their verified diagonal behind (pdiag, flags): a tile all
     // of whose problems are flagged diagonal skips the stream of P -- 512 of its 1280 bytes per problem at
     // N=8 -- and is handled exactly like the stream would have ended.
-    bool have_diag = false;
-    if (pdiag != nullptr && flags != nullptr && layout == DQQ_P_AUTO)
-        have_diag = __all(!valid || flags[first + pl] != 0);
+    // A tile all of whose problems the forward saw in non-diagonal tiles (flag 2) is queued without a look at P
+    // (for N >= 32 the forward's tiles are this kernel's, so that is the decision the stream would reach; below, a
+    // diagonal problem that lands in the general kernel this way gets the same bits: both follow the reference's order).
+    bool have_diag = false, known_dense = false;
+    if (pdiag != nullptr && flags != nullptr && layout == DQQ_P_AUTO) {
+        const int f = valid ? flags[first + pl] : -1;
+        have_diag = __all(f == 1 || f == -1);
+        known_dense = __all(f == 2 || f == -1);
+    }
     constexpr bool AGG = !FUSE && WPB > 1; // queue non-diagonal tiles with ONE atomic per workgroup (see launch.h)
     __shared__ int s_cnt[2];
     if (layout == DQQ_P_DIAG) {
         pv = valid ? *reinterpret_cast<const double2*>(P + first * N + 2 * lane) : make_double2(1.0, 1.0);
     } else {
-        bool tile_dense = false;
-        if (have_diag) {
+        bool tile_dense = known_dense;
+        if (known_dense) {
+            pv = make_double2(1.0, 1.0);
+        } else if (have_diag) {
             pv = valid ? *reinterpret_cast<const double2*>(pdiag + first * N + 2 * lane) : make_double2(1.0, 1.0);
         } else {
             const double* Pw = P + first * (long)(N * N);

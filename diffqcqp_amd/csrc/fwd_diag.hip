@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
                                             : stream_tile_diag<N, NCH, true>(Pw, limit, sd, lane);
         const bool tile_dense = __any(nz != 0); // wave-uniform
         if constexpr (CMP) wg_dense = __syncthreads_or(tile_dense) != 0;
-        if (tile_dense && flags_out != nullptr && valid && (lane % LPP) == 0) flags_out[first + pl] = 0;
+        if (tile_dense && flags_out != nullptr && valid && (lane % LPP) == 0) flags_out[first + pl] = 2; // seen, not diagonal
         if constexpr (GD) {
             dense_tile = tile_dense;
         } else if constexpr (FUSE) {

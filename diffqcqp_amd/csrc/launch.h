@@ -13,27 +13,42 @@
 namespace dqq {
 
 // Fallback work-list in the caller's workspace (ints).  [0] number of queued
-// problem indices, [1] exit ticket of the dense kernel (its last workgroup
-// re-zeroes both), entries from [kWsEntries].
+// problem indices, [1] exit ticket of the dense kernel (its last participant
+// re-zeroes the header), [2] next unclaimed entry (dynamic pick-up), then 32 sub-tickets one cache line apart,
+// entries from [kWsEntries].
 constexpr int kWsCount = 0;
 constexpr int kWsTicket = 1;
 constexpr int kWsNext = 2; // work-list mode with dynamic pick-up: next unclaimed entry
-constexpr int kWsEntries = 4;
+constexpr int kWsSubTickets = 32;   // first of 32 sub-tickets, kWsSubStride ints apart
+constexpr int kWsSubStride = 32;    // 128 bytes: one sub-ticket per cache line
+constexpr int kWsEntries = kWsSubTickets + 32 * kWsSubStride;
 
 
 #if defined(__HIPCC__)
 // Work-list mode of the general kernels: the last participant (wave or workgroup) out re-zeroes the
-// work-list header for the next call.  Call from ONE lane per participant; `participants` = how many call.
+// work-list header for the next call.  Call from ONE lane per participant; `participants` = how many call
+// (gridDim.x, or gridDim.x * waves per workgroup).
 // With an empty list nothing is touched: hundreds of same-address atomics would otherwise serialise into
-// ~13 us of an otherwise empty launch.
+// ~13 us of an otherwise empty launch.  With entries, the tickets are drawn in two levels -- participant i on
+// sub-ticket i mod 32, the last of each on the top ticket -- so that no address sees more than
+// participants / 32 atomics: 4096 tickets on ONE address took ~30 us of the 67 us backward of a dense 65536 x 8
+// batch through DQQ_P_AUTO (round 3).
 static DQQ_D void worklist_release(int* ws, long count, int participants)
 {
     if (count > 0) {
-        const int tk = atomicAdd(&ws[kWsTicket], 1);
-        if (tk == participants - 1) {
-            ws[kWsCount] = 0;
-            ws[kWsTicket] = 0;
-            ws[kWsNext] = 0;
+        const int id = (participants == (int)gridDim.x) ? (int)blockIdx.x
+                                                        : (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+        const int g = id & 31;
+        const int members = (participants - g + 31) >> 5;      // ids congruent to g below `participants`
+        int* sub = ws + kWsSubTickets + g * kWsSubStride;
+        if (atomicAdd(sub, 1) == members - 1) {
+            *sub = 0;
+            const int groups = participants < 32 ? participants : 32;
+            if (atomicAdd(&ws[kWsTicket], 1) == groups - 1) {
+                ws[kWsCount] = 0;
+                ws[kWsTicket] = 0;
+                ws[kWsNext] = 0;
+            }
         }
     }
 }

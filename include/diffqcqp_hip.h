@@ -84,8 +84,10 @@ int dqq_max_n(int kind);
  * pybindings.cpp:17-22 -> Solver::solveQP, Solver.cpp:61-123).
  * iters (B ints, ADMM iterations executed per problem) may be NULL.
  * pdiag_out (B,N doubles) / diag_flags_out (B bytes), both optional and DQQ_P_AUTO only: the forward leaves
- * the diagonal of every problem it verified to be diagonal (flag 1; flag 0 otherwise) for the backward of
- * the SAME P, which then skips re-reading P for those problems (see dqq_qp_bwd_f64). */
+ * the diagonal of every problem it verified to be diagonal (flag 1; flag 2: the problem sat in a tile with
+ * non-zero off-diagonals; flag 0: not examined) for the backward of the SAME P, which then does not read P again
+ * for tiles flagged 1 throughout (they take pdiag) or 2 throughout (they go to the general kernel); see
+ * dqq_qp_bwd_f64. */
 int dqq_qp_fwd_f64(const double* P, const double* q, double* x, int64_t B, int N, double eps, double mu_prox,
                    int max_iter, int adaptive_rho, int p_layout, int* iters, double* pdiag_out,
                    unsigned char* diag_flags_out, void* workspace, size_t workspace_bytes, void* stream);

@@ -250,7 +250,8 @@ def test_backward_with_the_forwards_diagonal_cache_is_identical(oracle, ops, kin
         assert torch.equal(u, v)
     flags = cache[1].cpu().numpy()
     offdiag = (d["P"] - torch.diag_embed(torch.diagonal(d["P"], dim1=1, dim2=2))).abs().amax((1, 2)).numpy() > 0
-    assert not flags[offdiag].any(), "a non-diagonal problem was flagged diagonal"
+    assert (flags[offdiag] == 2).all(), "a non-diagonal problem must be flagged 2 (seen, not diagonal)"
+    assert np.isin(flags, (1, 2)).all(), "the forward examines every problem"
     if structure == "diag":
         assert flags.all()
         assert torch.equal(cache[0], torch.diagonal(g["P"], dim1=1, dim2=2))
