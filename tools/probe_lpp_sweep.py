@@ -13,7 +13,7 @@ def t(fn, n=30):
     for _ in range(n): fn()
     b.record(); b.synchronize(); return a.elapsed_time(b) * 1e3 / n
 for kind in ("qp", "qcqp"):
-    for B in (8192, 16384, 32768, 49152, 65536, 98304, 131072, 262144, 524288):
+    for B in [b for b in (8192, 16384, 32768, 49152, 65536, 98304, 131072, 262144, 524288) if b * N * N * 8 <= (5 << 30)]:
         d = {k: v.cuda() for k, v in make_problem(kind, B, N, 11).items()}
         xo = torch.empty(B, N, 1, dtype=torch.float64, device="cuda")
         row = []
