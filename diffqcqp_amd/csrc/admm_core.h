@@ -42,23 +42,21 @@ namespace dqq {
 // signs (KIND 2, 3; may be null otherwise).
 // valid = false: the lane only keeps the wave's control flow company.
 // Returns the number of ADMM iterations executed (Solver.cpp:79 / :538 loop).
-// Reciprocals of E positive numbers from ONE reciprocal (of their product) and 3(E-1) multiplications: 14 instead
-// of 20 instructions at E = 4.  Each result carries ~3 roundings instead of 1.  A product that leaves the double
-// range (entries beyond ~1e75) or a non-positive factor falls back to one reciprocal per entry.
-// E = 4 (N = 8 on two lanes per problem, ...) goes two by two, so that its reciprocals are bit-identical to the ones
-// the same problem gets on twice the lanes with E = 2 (admm_fwd_diag_respread moves problems between the two).
+// Reciprocals of E positive numbers.  E >= 8: from ONE reciprocal (of their product) and 3(E-1) multiplications; each
+// result then carries ~3 roundings instead of 1, and a product that leaves the double range (entries beyond ~1e75) or
+// a non-positive factor falls back to one reciprocal per entry.  E <= 4: one reciprocal per entry -- with the range
+// test and its branch the shared reciprocal saved nothing there (11 against 10 VALU instructions per pair), and the
+// result must not depend on how a problem's coordinates are grouped into lanes (admm_fwd_diag_respread moves problems
+// from E = 4 to E = 2 in mid-solve).
 template <int E>
 DQQ_HD void rcp_all(const double (&m)[E], double (&inv)[E])
 {
-    if constexpr (E == 4) {
-        const double a[2] = {m[0], m[1]}, b[2] = {m[2], m[3]};
-        double ia[2], ib[2];
-        rcp_all<2>(a, ia);
-        rcp_all<2>(b, ib);
-        inv[0] = ia[0]; inv[1] = ia[1]; inv[2] = ib[0]; inv[3] = ib[1];
+    if constexpr (E <= 4) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) inv[e] = fast_rcp(m[e]);
         return;
     }
-    // (E != 4 from here on)
+    // (E >= 8 from here on)
     double pre[E];
     pre[0] = m[0];
 #pragma unroll
@@ -135,7 +133,7 @@ DQQ_D void admm_diag_resume(double (&M)[E], double (&Minv)[E], const double (&q)
 // problems (8..38 iterations at the bench shape, median 17) and those spent the second half of their iterations
 // in a half-empty wave.
 // Results are bit-identical to the un-respread solve: the per-coordinate arithmetic is the same code, the group
-// maxima are exact, the reciprocals are taken pair by pair (rcp_all<4>) and |l|^2 is summed contact by contact
+// maxima are exact, the reciprocals are taken entry by entry (rcp_all) and |l|^2 is summed contact by contact
 // in the order of the lane tree -- so a problem's result does not depend on what else is in its tile.
 // A problem that moved (moved = true on its two phase-1 lanes) has its x and iteration count stored from here
 // (xout / itout point at the tile's first problem); the others return theirs as admm_fwd_diag does.
