@@ -533,7 +533,55 @@ def test_auto_layout_mixed_batch_uses_fallback(oracle, ops, kind, N):
         else:
             check_backward_exact(grads, st, oracle_bwd(oracle, kind, d, xo), exact=False)
     for ws in ops._workspaces.values():
-        assert int(ws[:2].abs().sum()) == 0  # work-list count and exit ticket are left zeroed
+        assert int(ws[:WS_HEADER_INTS].abs().sum()) == 0  # work-list count, exit tickets, pick-up index: left zeroed
+
+
+WS_HEADER_INTS = 32 + 32 * 32  # csrc/launch.h kWsEntries: count, ticket, next, 32 sub-tickets a cache line apart
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("N,B", [(8, 20000), (8, 70001), (16, 9000), (32, 3000), (64, 700)])
+def test_worklist_header_is_rezeroed_by_large_drains(ops, kind, N, B):
+    """The participants of a drain launch draw exit tickets in two levels (32 sub-tickets, then one) and the last one
+    re-zeroes the header.  Dense batches through the work-list at sizes where every sub-ticket has several members,
+    three calls in a row on the same workspace, forward and backward: identical to the DQQ_P_DENSE results each
+    time, header zero afterwards; then a diagonal batch on the same workspaces finds an empty list."""
+    from diffqcqp_amd import _capi
+    g = dev(make_problem(kind, B, N, 4100 + N, "dense"))
+    xd, itd = hip_fwd(ops, kind, g, layout=1)
+    gd, std = hip_bwd(ops, kind, g, xd, layout=1)
+    _capi.set_option("fuse_fallback", 0)
+    try:
+        first = None
+        for _ in range(3):
+            xa, ita = hip_fwd(ops, kind, g)
+            ga, sta = hip_bwd(ops, kind, g, xd)
+            torch.cuda.synchronize()
+            for ws in ops._workspaces.values():
+                assert int(ws[:WS_HEADER_INTS].abs().sum()) == 0
+            if first is None:
+                first = (xa, ita, ga, sta)
+                # the general kernels behind the work-list may differ from the ones DQQ_P_DENSE picks for this size
+                assert float((ita == itd).double().mean()) >= 0.999
+                same = (ita == itd)
+                assert float((xa - xd)[same].abs().max()) < 1e-9
+                agree = (sta == std).reshape(sta.shape[0], -1).all(1)
+                assert float(agree.double().mean()) > 0.85
+                for u, v in zip(ga, gd):
+                    scale = float(v.abs().max()) + 1e-300
+                    assert float((u - v)[agree].abs().max()) / scale < 1e-6
+            else:       # the same launches again on the same workspace: the same bits
+                assert torch.equal(xa, first[0]) and torch.equal(ita, first[1]) and torch.equal(sta, first[3])
+                for u, v in zip(ga, first[2]):
+                    assert torch.equal(u, v)
+        gdiag = dev(make_problem(kind, B, N, 4200 + N))
+        x1, it1 = hip_fwd(ops, kind, gdiag)
+        assert torch.isfinite(x1).all() and int(it1.min()) >= 1
+        torch.cuda.synchronize()
+        for ws in ops._workspaces.values():
+            assert int(ws[:WS_HEADER_INTS].abs().sum()) == 0
+    finally:
+        _capi.set_option("fuse_fallback", -1)
 
 
 def test_single_nonzero_offdiagonal_is_detected(oracle, ops):
