@@ -321,16 +321,17 @@ DQQ_D void sweep16_spread_step(double (&a)[4], double (&e)[4], double& s, bool& 
     double m = col * -rd;
     unsigned long long saved;
     asm volatile("s_mov_b64 %[sv], exec\n\t"
-                 "s_mov_b64 exec, %[mk]\n\t"
+                 "s_and_b64 exec, %[mk], %[sv]\n\t" // (never more lanes than the caller had)
                  "v_mov_b64 %[m], 0\n\t"        // pivot row: stays as it is ...
                  "v_mov_b64 %[s], %[rd]\n\t"     // ... and carries the scale 1/d from now on
-                 "s_mov_b64 exec, %[mg]\n\t"
+                 "s_and_b64 exec, %[mg], %[sv]\n\t"
                  "v_mov_b64 %[acb], 0\n\t"      // column K: the pattern the update turns into a_nk / d
-                 "s_mov_b64 exec, %[mgk]\n\t"
+                 "s_and_b64 exec, %[mgk], %[sv]\n\t"
                  "v_mov_b64 %[acb], -1.0\n\t"
                  "s_mov_b64 exec, %[sv]"
                  : [m] "+v"(m), [s] "+v"(s), [acb] "+v"(a[CB]), [sv] "=&s"(saved)
-                 : [rd] "v"(rd), [mk] "s"(kRowK), [mg] "s"(kGroup), [mgk] "s"(kGroupK));
+                 : [rd] "v"(rd), [mk] "s"(kRowK), [mg] "s"(kGroup), [mgk] "s"(kGroupK)
+                 : "scc");
     // the later pivot columns of this block first (the next sweep reads one of them through DPP right away)
     if constexpr (GP < 1) DQQ_SPREAD_FMAC(e[1], K);
     if constexpr (GP < 2) DQQ_SPREAD_FMAC(e[2], K);
