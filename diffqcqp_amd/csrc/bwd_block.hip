@@ -56,10 +56,10 @@ __global__ __launch_bounds__(256, 1) void bwd_block_kernel(
     const int t = threadIdx.x;
     const bool has = t < M;
     const int me = has ? t : 0;
-    const long count = use_worklist ? (long)ws[kWsCount] : B;
+    const long count = use_worklist ? worklist_count(ws, N) : B;
 
     for (long w = blockIdx.x; w < count; w += gridDim.x) {
-        const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
+        const long prob = use_worklist ? worklist_entry(ws, N, B, w) : w;
         const double* Pg = P + prob * (long)(N * N);
         __syncthreads();
         if (t < N) vx[t] = x[prob * N + t];

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : (KIND == 1 ? 4 :
                 return;
             }
         } else if (layout == DQQ_P_AUTO) {
-            worklist_push<AGG>(ws, first, tile_dense ? nvalid : 0, lane, s_cnt);
+            worklist_push<AGG, worklist_segmented(N)>(ws, B, first, tile_dense ? nvalid : 0, lane, s_cnt);
             if (tile_dense) return;
         }
         if (!have_diag) {

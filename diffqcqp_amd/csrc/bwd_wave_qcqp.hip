@@ -31,19 +31,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 {
     constexpr int NT = 3;
     __shared__ __attribute__((aligned(16))) double s_trb[16 * kTrLd]; // tile transposes (one wave per workgroup)
-    const long count = use_worklist ? (long)ws[kWsCount] : B;
+    WorkClaim claim; // (launch.h: direct mode, or dynamic pick-up from the work-list)
+    claim.open(ws, use_worklist, N, B);
     const int nc = N / 2;
     for (long w = blockIdx.x;; w += gridDim.x) {
-        if (use_worklist) { // (an empty list is left untouched: nobody would reset the counter)
-            if (count == 0) break;
-            w = __builtin_amdgcn_readfirstlane(threadIdx.x == 0 ? atomicAdd(&ws[kWsNext], 1) : 0);
-        }
-        if (w >= count) break;
+        const long prob = claim.next(ws, B, w); // wave-uniform (SGPRs: P's addressing uses a scalar base)
+        if (prob < 0) break;
         int lane = threadIdx.x;
         asm volatile("" : "+v"(lane)); // nothing lane-derived is hoisted out of the problem loop (dense_wave64.hip)
         const int g = lane >> 4, n = lane & 15;
         const int xsrc = 4 * n + g;
-        const long prob = __builtin_amdgcn_readfirstlane(use_worklist ? ws[kWsEntries + w] : (int)w);
         const double* Pg = P + prob * (long)(N * N);
         // vectors: one entry per lane, lane = slot: 0..15 contacts, 16..47 coordinates
         const int ci = lane - 16;                        // coordinate of this lane
@@ -165,7 +162,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         if (ir_steps != nullptr && lane == 0) ir_steps[prob] = steps;
     }
-    if (use_worklist && threadIdx.x == 0) worklist_release(ws, count, (int)gridDim.x);
+    if (use_worklist && threadIdx.x == 0) worklist_release(ws, claim.count, (int)gridDim.x);
 }
 
 bool bwd_wave_qcqp_supported(int kind, int N) { return kind == kKindQCQP && N > 16 && N <= 32 && (N & 1) == 0; }

@@ -75,7 +75,8 @@ extern "C" {
 size_t dqq_workspace_bytes(int64_t B)
 {
     if (B < 0) B = 0;
-    size_t n = (size_t)dqq::kWsEntries + (size_t)B;
+    // header + the entry area: B slots of the plain list, or the 32 segments of the N >= 32 list (launch.h)
+    size_t n = (size_t)dqq::kWsEntries + (size_t)dqq::kWsEntryInts((long)B);
     n = (n + 63) & ~(size_t)63;
     return n * sizeof(int);
 }

@@ -31,10 +31,10 @@ __global__ __launch_bounds__(256) void fwd_dense_kernel(const double* __restrict
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     double* sw = smem + wave * lds_per_wave;
-    const long count = use_worklist ? (long)ws[kWsCount] : B;
+    const long count = use_worklist ? worklist_count(ws, n) : B;
     const long nwaves = (long)gridDim.x * wpb;
     for (long w = (long)blockIdx.x * wpb + wave; w < count; w += nwaves) {
-        const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
+        const long prob = use_worklist ? worklist_entry(ws, n, B, w) : w;
         dense_fwd_problem<KIND>(P, q, l_n, mu_c, v_sign, x, iters, prob, n, eps, mu, max_iter, adaptive, sw, lane);
     }
     if (use_worklist && lane == 0) worklist_release(ws, count, (int)nwaves);
@@ -54,10 +54,10 @@ __global__ __launch_bounds__(256) void bwd_dense_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int team = lane / T, tl = lane % T;
     double* sw = smem + (wave * TP + team) * lds_per_team;
-    const long count = use_worklist ? (long)ws[kWsCount] : B;
+    const long count = use_worklist ? worklist_count(ws, n) : B;
     const long nteams = (long)gridDim.x * wpb * TP;
     for (long w = ((long)blockIdx.x * wpb + wave) * TP + team; w < count; w += nteams) {
-        const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
+        const long prob = use_worklist ? worklist_entry(ws, n, B, w) : w;
         dense_bwd_problem<KIND, T>(P, q, l_n, mu_c, x, grad_x, grad_P, grad_q, grad_l_n, grad_mu, gamma_out, dgamma_out,
                                    ir_steps, prob, n, dual_eps, sw, tl);
     }

@@ -123,10 +123,10 @@ __global__ __launch_bounds__(256, N == 32 ? 3 : 2) void fwd_dense_block_kernel(c
     WR wr;
     wr.init(part, t);
     const int row = wr.row;
-    const long count = use_worklist ? (long)ws[kWsCount] : B;
+    const long count = use_worklist ? worklist_count(ws, N) : B;
 
     for (long w = blockIdx.x; w < count; w += gridDim.x) {
-        const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
+        const long prob = use_worklist ? worklist_entry(ws, N, B, w) : w;
         const double* Pg = P + prob * (long)(N * N);
         double m[CW]; // the wave's column block of P (power iteration), then of M^-1 (ADMM)
 #pragma unroll
@@ -300,10 +300,10 @@ __global__ __launch_bounds__(256, 2) void bwd_dense_block_qp_kernel(const double
     WR wr;
     wr.init(part, t);
     const int row = wr.row;
-    const long count = use_worklist ? (long)ws[kWsCount] : B;
+    const long count = use_worklist ? worklist_count(ws, N) : B;
 
     for (long w = blockIdx.x; w < count; w += gridDim.x) {
-        const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
+        const long prob = use_worklist ? worklist_entry(ws, N, B, w) : w;
         const double* Pg = P + prob * (long)(N * N);
         double m[CW]; // P[row][CW*wave ..]
 #pragma unroll

@@ -160,25 +160,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT == 4 ?
 {
     // KIND 2 / 3 (box / signed box QP): l_n = l_min, mu_c = l_max per coordinate.  PAD: N < 16 NT.
     constexpr bool QP_LIKE = (KIND != 1);
-    const long count = use_worklist ? (long)ws[kWsCount] : B;
+    WorkClaim claim; // (launch.h: direct mode, or dynamic pick-up from the work-list)
+    claim.open(ws, use_worklist, N, B);
     __shared__ __attribute__((aligned(16))) double s_lower[LowerLds<NT>::DOUBLES]; // one wave per workgroup
     __shared__ __attribute__((aligned(16))) double s_tr[16 * kTrLd];                // tile transposes of the sweep
 
     for (long w = blockIdx.x;; w += gridDim.x) {
-        // work-list mode: entries are claimed one at a time (iteration counts differ by 2x between problems; a fixed
-        // stride would leave the grid waiting for its unluckiest wave)
-        if (use_worklist) { // (an empty list is left untouched: nobody would reset the counter)
-            if (count == 0) break;
-            w = __builtin_amdgcn_readfirstlane(threadIdx.x == 0 ? atomicAdd(&ws[kWsNext], 1) : 0);
-        }
-        if (w >= count) break;
+        const long prob = claim.next(ws, B, w); // wave-uniform (SGPRs: P's addressing uses a scalar base)
+        if (prob < 0) break;
         // everything derived from the lane index is recomputed per problem: hoisted out of this loop (which runs
         // once per wave outside the work-list mode) those dozens of masks and offsets only occupy registers
         int lane = threadIdx.x;
         asm volatile("" : "+v"(lane));
         const int xsrc = 4 * (lane & 15) + (lane >> 4);
-        // wave-uniform by construction; readfirstlane tells the compiler so (P's addressing then uses an SGPR base)
-        const long prob = __builtin_amdgcn_readfirstlane(use_worklist ? ws[kWsEntries + w] : (int)w);
         const double* Pg = P + prob * (long)(N * N);
         // lanes >= N hold no coordinate (NT < 4) or a padded one (PAD): all their vector entries stay zero
         const bool live = (NT == 4 && !PAD) || lane < N;
@@ -276,7 +270,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT == 4 ?
         if (iters != nullptr && lane == 0) iters[prob] = it_done;
     }
     // last wave out re-zeroes the work-list header (nothing to do when the list was empty)
-    if (use_worklist && threadIdx.x == 0) worklist_release(ws, count, (int)gridDim.x);
+    if (use_worklist && threadIdx.x == 0) worklist_release(ws, claim.count, (int)gridDim.x);
 }
 
 template <int KIND, int NT, bool PAD>
@@ -338,20 +332,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT >= 3 ?
     const double* __restrict__ grad_x, double* __restrict__ grad_P, double* __restrict__ grad_q, long B, int N,
     double dual_eps, int* __restrict__ ir_steps, int* __restrict__ ws, int use_worklist)
 {
-    const long count = use_worklist ? (long)ws[kWsCount] : B;
+    WorkClaim claim; // (launch.h: direct mode, or dynamic pick-up from the work-list)
+    claim.open(ws, use_worklist, N, B);
     __shared__ __attribute__((aligned(16))) double s_trb[16 * kTrLd]; // tile transposes (one wave per workgroup)
     for (long w = blockIdx.x;; w += gridDim.x) {
-        if (use_worklist) { // (an empty list is left untouched: nobody would reset the counter)
-            if (count == 0) break;
-            w = __builtin_amdgcn_readfirstlane(threadIdx.x == 0 ? atomicAdd(&ws[kWsNext], 1) : 0);
-        }
-        if (w >= count) break;
+        const long prob = claim.next(ws, B, w); // wave-uniform (SGPRs: P's addressing uses a scalar base)
+        if (prob < 0) break;
         int lane = threadIdx.x;
         asm volatile("" : "+v"(lane)); // see the forward kernel: nothing lane-derived is hoisted out of the loop
         const int g = lane >> 4, n = lane & 15;
         const int xsrc = 4 * n + g;
-        // wave-uniform by construction; readfirstlane tells the compiler so (P's addressing then uses an SGPR base)
-        const long prob = __builtin_amdgcn_readfirstlane(use_worklist ? ws[kWsEntries + w] : (int)w);
         const double* Pg = P + prob * (long)(N * N);
         const bool live = (NT == 4 && !PAD) || lane < N;
         const double xi = live ? x[prob * N + lane] : 0.0, gi = live ? grad_x[prob * N + lane] : 0.0;
@@ -426,7 +416,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT >= 3 ?
         }
         if (ir_steps != nullptr && lane == 0) ir_steps[prob] = steps;
     }
-    if (use_worklist && threadIdx.x == 0) worklist_release(ws, count, (int)gridDim.x);
+    if (use_worklist && threadIdx.x == 0) worklist_release(ws, claim.count, (int)gridDim.x);
 }
 
 template <int NT, bool PAD>

@@ -139,8 +139,8 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
         const double* Pw = P + first * (long)(N * N);
         const int limit = nvalid * N * N; // doubles of P that belong to this tile
         double* sd = s_diag[wave];
-        const unsigned nz = (nvalid == PPW) ? stream_tile_diag<N, NCH, false>(Pw, limit, sd, lane)
-                                            : stream_tile_diag<N, NCH, true>(Pw, limit, sd, lane);
+        const unsigned nz = (nvalid == PPW) ? stream_tile_diag<N, NCH, false, true>(Pw, limit, sd, lane)
+                                            : stream_tile_diag<N, NCH, true, true>(Pw, limit, sd, lane);
         const bool tile_dense = __any(nz != 0); // wave-uniform
         if constexpr (CMP) wg_dense = __syncthreads_or(tile_dense) != 0;
         if (tile_dense && flags_out != nullptr && valid && (lane % LPP) == 0) flags_out[first + pl] = 2; // seen, not diagonal
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
                 return;
             }
         } else {
-            worklist_push<AGG>(ws, first, tile_dense ? nvalid : 0, lane, s_cnt);
+            worklist_push<AGG, worklist_segmented(N)>(ws, B, first, tile_dense ? nvalid : 0, lane, s_cnt);
             if (tile_dense) return;
         }
         wave_lds_fence();

@@ -27,9 +27,9 @@ __global__ __launch_bounds__(kAnyT) void fwd_any_kernel(const double* __restrict
     double* A = LDS ? smem : scr;
     double* Ainv = LDS ? smem + mat : scr + mat;
     double* vec = LDS ? scr : scr + 2 * mat;
-    const long count = use_worklist ? (long)ws[kWsCount] : B;
+    const long count = use_worklist ? worklist_count(ws, n) : B;
     for (long w = blockIdx.x; w < count; w += gridDim.x) {
-        const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
+        const long prob = use_worklist ? worklist_entry(ws, n, B, w) : w;
         any_fwd_problem<KIND>(P, q, l_n, mu_c, v_sign, x, iters, prob, n, eps, mu, max_iter, adaptive, A, Ainv, vec, red,
                               t);
     }
@@ -53,9 +53,9 @@ __global__ __launch_bounds__(kAnyT) void bwd_any_kernel(
     double* At = LDS ? smem : scr + mat;
     double* Kinv = LDS ? smem + mat : scr + 2 * mat;
     double* vec = LDS ? scr + mat : scr + 3 * mat;
-    const long count = use_worklist ? (long)ws[kWsCount] : B;
+    const long count = use_worklist ? worklist_count(ws, n) : B;
     for (long w = blockIdx.x; w < count; w += gridDim.x) {
-        const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
+        const long prob = use_worklist ? worklist_entry(ws, n, B, w) : w;
         any_bwd_problem<KIND>(P, q, l_n, mu_c, x, grad_x, grad_P, grad_q, grad_l_n, grad_mu, gamma_out, dgamma_out,
                               ir_steps, prob, n, dual_eps, At, K, Kinv, vec, t);
     }

@@ -21,7 +21,19 @@ constexpr int kWsTicket = 1;
 constexpr int kWsNext = 2; // work-list mode with dynamic pick-up: next unclaimed entry
 constexpr int kWsSubTickets = 32;   // first of 32 sub-tickets, kWsSubStride ints apart
 constexpr int kWsSubStride = 32;    // 128 bytes: one sub-ticket per cache line
-constexpr int kWsEntries = kWsSubTickets + 32 * kWsSubStride;
+// N >= 32 (one to sixteen problems per workgroup of the fast kernel: a dense batch through DQQ_P_AUTO queues from
+// thousands of workgroups within microseconds): the list is SEGMENTED -- workgroup i appends to segment i mod 32, each
+// with its own counter on its own cache line and kWsSegCap(B) slots in the entry area; ws[kWsCount] is a flag there
+// (1 = something is queued: an empty list is recognised with one load).  The
+// 8192 same-address atomics of a 65536 x 64 batch took 0.12 ms of its forward and 0.10 ms of its backward (round 3).
+constexpr int kWsSegCounts = kWsSubTickets + 32 * kWsSubStride; // entries queued on segment g: [kWsSegCounts + g * kWsSubStride]
+constexpr int kWsSegNext = kWsSegCounts + 32 * kWsSubStride;   // next unclaimed entry of segment g (dynamic pick-up)
+constexpr int kWsEntries = kWsSegNext + 32 * kWsSubStride;
+constexpr bool worklist_segmented(int N) { return N >= 32; }
+// slots per segment: the workgroups of one residue class hold at most B/32 + 2 * (problems per workgroup <= 256) problems
+DQQ_HD constexpr long kWsSegCap(long B) { return B / 32 + 512; }
+// ints behind the header that hold entries: B for the plain list, 32 segments otherwise
+DQQ_HD constexpr long kWsEntryInts(long B) { return 32 * kWsSegCap(B); }
 
 
 #if defined(__HIPCC__)
@@ -48,6 +60,10 @@ static DQQ_D void worklist_release(int* ws, long count, int participants)
                 ws[kWsCount] = 0;
                 ws[kWsTicket] = 0;
                 ws[kWsNext] = 0;
+                for (int h = 0; h < 32; ++h) {  // (segmented list, N >= 32)
+                    ws[kWsSegCounts + h * kWsSubStride] = 0;
+                    ws[kWsSegNext + h * kWsSubStride] = 0;
+                }
             }
         }
     }
@@ -80,15 +96,21 @@ static inline hipError_t launch(void (*kernel)(KArgs...), dim3 grid, dim3 block,
 // a dense batch through DQQ_P_AUTO otherwise serialises tens of thousands of same-address atomics (0.38 ms at
 // B=65536, N=64).  Every wave of the workgroup that has not returned yet must make the call (three workgroup
 // barriers; waves that already ended are not waited for).  s_cnt: two ints of LDS.
-template <bool AGG>
-static DQQ_D void worklist_push(int* __restrict__ ws, long first, int n, int lane, int* s_cnt)
+// SEG: the segmented list (see kWsSegCounts): the counter and the slots of segment blockIdx.x mod 32.
+template <bool AGG, bool SEG = false>
+static DQQ_D void worklist_push(int* __restrict__ ws, long B, long first, int n, int lane, int* s_cnt)
 {
+    int* counter = SEG ? ws + kWsSegCounts + (int)(blockIdx.x & 31u) * kWsSubStride : ws + kWsCount;
+    int* slots = SEG ? ws + kWsEntries + (long)(blockIdx.x & 31u) * kWsSegCap(B) : ws + kWsEntries;
     if constexpr (!AGG) {
         if (n > 0) {
             int base = 0;
-            if (lane == 0) base = atomicAdd(&ws[kWsCount], n);
+            if (lane == 0) {
+                base = atomicAdd(counter, n);
+                if (SEG) ws[kWsCount] = 1;
+            }
             base = __shfl(base, 0, 64);
-            if (lane < n) ws[kWsEntries + base + lane] = (int)(first + lane);
+            if (lane < n) slots[base + lane] = (int)(first + lane);
         }
     } else {
         if (threadIdx.x == 0) s_cnt[0] = 0;
@@ -96,14 +118,87 @@ static DQQ_D void worklist_push(int* __restrict__ ws, long first, int n, int lan
         int local = 0;
         if (lane == 0 && n > 0) local = atomicAdd(&s_cnt[0], n);
         __syncthreads();
-        if (threadIdx.x == 0 && s_cnt[0] > 0) s_cnt[1] = atomicAdd(&ws[kWsCount], s_cnt[0]);
+        if (threadIdx.x == 0 && s_cnt[0] > 0) {
+            s_cnt[1] = atomicAdd(counter, s_cnt[0]);
+            if (SEG) ws[kWsCount] = 1;
+        }
         __syncthreads();
         if (n > 0) {
             const int base = s_cnt[1] + __shfl(local, 0, 64);
-            if (lane < n) ws[kWsEntries + base + lane] = (int)(first + lane);
+            if (lane < n) slots[base + lane] = (int)(first + lane);
         }
     }
 }
+
+// Readers of the work-list for the kernels that drain it with a fixed stride (the kernels behind tuning options and
+// the global-memory kernels).  Plain list: the count word and entry w.  Segmented list (N >= 32): the 32 segment
+// counters are summed / scanned on every call (~6 us: these kernels spend 50 us to milliseconds per problem).  The
+// counters do not change while a drain kernel runs (the last participant out re-zeroes them, worklist_release).
+static DQQ_D long worklist_count(const int* __restrict__ ws, int N)
+{
+    if (!worklist_segmented(N) || ws[kWsCount] == 0) return ws[kWsCount];
+    long c = 0;
+#pragma unroll
+    for (int h = 0; h < 32; ++h) c += ws[kWsSegCounts + h * kWsSubStride];
+    return c;
+}
+// 0 <= w < worklist_count
+static DQQ_D long worklist_entry(const int* __restrict__ ws, int N, long B, long w)
+{
+    if (!worklist_segmented(N)) return ws[kWsEntries + w];
+    long base = 0, at = 0;     // entries before segment g; slot of entry w
+    int g = 0;
+#pragma unroll
+    for (int h = 0; h < 32; ++h) {
+        const long c = ws[kWsSegCounts + h * kWsSubStride];
+        if (w >= base && w < base + c) { g = h; at = w - base; }
+        base += c;
+    }
+    return ws[kWsEntries + g * kWsSegCap(B) + at];
+}
+
+// Dynamic pick-up for the wave-per-problem kernels (one wave per workgroup; iteration counts differ by 2x between
+// problems, a fixed stride would leave the grid waiting for its unluckiest wave).  Every value is wave-uniform.
+// Plain list: tickets on ws[kWsNext].  Segmented list: a wave starts on segment blockIdx.x mod 32, draws tickets on
+// THAT segment's pick-up word and moves on when it is exhausted; after 32 exhausted segments it is done -- no
+// prefix sums, and the tickets are spread over 32 addresses as the pushes were.
+struct WorkClaim {
+    long count;        // direct mode: B; plain list: entries; segmented list: non-zero iff anything is queued
+    int seg, left, c;  // segmented: current segment, segments not yet found exhausted, entries of the current one
+    bool listed, segd;
+    DQQ_D void open(const int* __restrict__ ws, int use_worklist, int N, long B)
+    {
+        listed = use_worklist != 0;
+        segd = listed && worklist_segmented(N);
+        count = listed ? (long)ws[kWsCount] : B;
+        seg = (int)(blockIdx.x & 31u);
+        left = 32;
+        c = -1;
+    }
+    // the next problem of this wave, -1 = none left.  w: the caller's strided counter (direct mode only).
+    // (An empty list is left untouched: nobody would reset its words.)
+    DQQ_D long next(int* __restrict__ ws, long B, long w)
+    {
+        if (!listed) return w < count ? w : -1;
+        if (count == 0) return -1;
+        if (!segd) {
+            const long t = __builtin_amdgcn_readfirstlane(threadIdx.x == 0 ? atomicAdd(&ws[kWsNext], 1) : 0);
+            return t < count ? (long)__builtin_amdgcn_readfirstlane(ws[kWsEntries + t]) : -1;
+        }
+        while (left > 0) {
+            if (c < 0) c = __builtin_amdgcn_readfirstlane(ws[kWsSegCounts + seg * kWsSubStride]);
+            if (c > 0) {
+                const int t = __builtin_amdgcn_readfirstlane(
+                    threadIdx.x == 0 ? atomicAdd(&ws[kWsSegNext + seg * kWsSubStride], 1) : 0);
+                if (t < c) return (long)__builtin_amdgcn_readfirstlane(ws[kWsEntries + seg * kWsSegCap(B) + t]);
+            }
+            seg = (seg + 1) & 31;
+            --left;
+            c = -1;
+        }
+        return -1;
+    }
+};
 #endif
 
 struct FwdArgs {

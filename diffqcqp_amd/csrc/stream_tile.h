@@ -6,35 +6,57 @@
 
 namespace dqq {
 
-// Streams NCH chunks of 128 doubles (16 B per lane, 1 KiB per wave instruction) of a tile of P,
-// writes the diagonal entries to sd[problem*N + row] and returns a non-zero word if any
-// off-diagonal entry is not +-0.  GUARD: the tile is ragged (last tile of the batch).
-// Large tiles (N >= 32: 64+ KiB) stop streaming at the first group of chunks that shows a non-zero off-diagonal
-// -- the tile is not going to take the fast path, and a dense batch would otherwise be read twice in full.
-template <int N, int NCH, bool GUARD>
+// One group of UU chunks of 128 doubles (16 B per lane, 1 KiB per wave instruction), all loads issued before the first
+// is looked at: diagonal entries to sd[problem*N + row], the bit patterns of the off-diagonal entries ORed into nz.
+template <int N, int UU, bool GUARD>
+static DQQ_D void stream_group_diag(const double* __restrict__ Pw, int limit, double* sd, int lane, int k0, unsigned& nz)
+{
+    double2 v[UU];
+#pragma unroll
+    for (int j = 0; j < UU; ++j) {
+        const int f = (k0 + j) * 128 + 2 * lane;
+        if (GUARD) v[j] = f < limit ? *reinterpret_cast<const double2*>(Pw + f) : make_double2(0.0, 0.0);
+        else v[j] = *reinterpret_cast<const double2*>(Pw + f);
+    }
+#pragma unroll
+    for (int j = 0; j < UU; ++j) {
+        const int f = (k0 + j) * 128 + 2 * lane;
+        const int row = f / N; // == problem*N + r
+        const int r = row % N, c = f % N; // c is even; (r,c) and (r,c+1) are this lane's entries
+        const unsigned b0 = nonzero_bits(v[j].x), b1 = nonzero_bits(v[j].y);
+        if (c == r) { sd[row] = v[j].x; nz |= b1; }
+        else if (c + 1 == r) { sd[row] = v[j].y; nz |= b0; }
+        else nz |= b0 | b1;
+    }
+}
+
+// Streams NCH chunks of a tile of P, writes the diagonal entries to sd[problem*N + row] and returns a non-zero word if
+// any off-diagonal entry is not +-0.  GUARD: the tile is ragged (last tile of the batch).
+// Large tiles (N >= 32: 32+ KiB) stop streaming at the first group of chunks that shows a non-zero off-diagonal -- the
+// tile is not going to take the fast path, and a dense batch would otherwise be read twice in full -- and their first
+// group can be a PROBE of two chunks (the first rows of the tile's first problem): the verifying pass over a dense
+// 65536 x 64 batch read 16 KiB per wave = 0.5 GB = 0.10 ms before it knew (round 3).  The forward probes (same box,
+// B=262144 N=32 diagonal: 430 us with, 436 without: the probe also staggers the waves' bursts); the backward does
+// not -- it rarely streams P at all (the forward's flags), and the extra code cost that kernel 3 % (404 -> 417 us).
+template <int N, int NCH, bool GUARD, bool PROBE = false>
 static DQQ_D unsigned stream_tile_diag(const double* __restrict__ Pw, int limit, double* sd, int lane)
 {
     unsigned nz = 0;
     constexpr int U = NCH < 16 ? (NCH < 8 ? NCH : 8) : 16;
-    for (int k0 = 0; k0 < NCH; k0 += U) {
-        double2 v[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const int f = (k0 + j) * 128 + 2 * lane;
-            if (GUARD) v[j] = f < limit ? *reinterpret_cast<const double2*>(Pw + f) : make_double2(0.0, 0.0);
-            else v[j] = *reinterpret_cast<const double2*>(Pw + f);
+    if constexpr (NCH >= 32 && PROBE) {
+        constexpr int U0 = 2;
+        stream_group_diag<N, U0, GUARD>(Pw, limit, sd, lane, 0, nz);
+        if (__any(nz != 0)) return nz; // wave-uniform
+        stream_group_diag<N, U - U0, GUARD>(Pw, limit, sd, lane, U0, nz);
+        for (int k0 = U; k0 < NCH; k0 += U) {
+            if (__any(nz != 0)) break;
+            stream_group_diag<N, U, GUARD>(Pw, limit, sd, lane, k0, nz);
         }
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const int f = (k0 + j) * 128 + 2 * lane;
-            const int row = f / N; // == problem*N + r
-            const int r = row % N, c = f % N; // c is even; (r,c) and (r,c+1) are this lane's entries
-            const unsigned b0 = nonzero_bits(v[j].x), b1 = nonzero_bits(v[j].y);
-            if (c == r) { sd[row] = v[j].x; nz |= b1; }
-            else if (c + 1 == r) { sd[row] = v[j].y; nz |= b0; }
-            else nz |= b0 | b1;
+    } else {
+        for (int k0 = 0; k0 < NCH; k0 += U) {
+            stream_group_diag<N, U, GUARD>(Pw, limit, sd, lane, k0, nz);
+            if (NCH > 32 && __any(nz != 0)) break;
         }
-        if (NCH > 32 && __any(nz != 0)) break; // wave-uniform
     }
     return nz;
 }

@@ -536,11 +536,13 @@ def test_auto_layout_mixed_batch_uses_fallback(oracle, ops, kind, N):
         assert int(ws[:WS_HEADER_INTS].abs().sum()) == 0  # work-list count, exit tickets, pick-up index: left zeroed
 
 
-WS_HEADER_INTS = 32 + 32 * 32  # csrc/launch.h kWsEntries: count, ticket, next, 32 sub-tickets a cache line apart
+# csrc/launch.h kWsEntries: count, ticket, next, 32 sub-tickets and the 32 segment counters of the N >= 32 list, a cache
+# line apart each
+WS_HEADER_INTS = 32 + 2 * 32 * 32
 
 
 @pytest.mark.parametrize("kind", ["qp", "qcqp"])
-@pytest.mark.parametrize("N,B", [(8, 20000), (8, 70001), (16, 9000), (32, 3000), (64, 700)])
+@pytest.mark.parametrize("N,B", [(8, 20000), (8, 70001), (16, 9000), (32, 3000), (64, 700), (32, 8195), (64, 2051)])
 def test_worklist_header_is_rezeroed_by_large_drains(ops, kind, N, B):
     """The participants of a drain launch draw exit tickets in two levels (32 sub-tickets, then one) and the last one
     re-zeroes the header.  Dense batches through the work-list at sizes where every sub-ticket has several members,
@@ -1107,6 +1109,56 @@ def test_full_size_b65536_n8_dense_p_through_auto(oracle, ops, kind, structure):
     assert np.array_equal(npy(sa)[idx], ref[-1])
     for a, b in zip(ga, ref[:-1]):
         assert np.allclose(npy(a)[idx], b, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(b).max()))
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("N,B,pattern", [(32, 6000, "sparse"), (64, 3001, "sparse"), (32, 4099, "one_segment"),
+                                         (64, 2500, "one_segment"), (64, 4097, "dense"), (32, 3, "dense")])
+def test_segmented_worklist_uneven_segments(ops, kind, N, B, pattern):
+    """N >= 32: the fast kernels queue non-diagonal tiles on a SEGMENTED list (workgroup i -> segment i mod 32, one
+    counter per segment, csrc/launch.h) that the general kernels read through a scan of the 32 counters.  Batches whose
+    dense problems leave the segments uneven, most of them empty ("one_segment": only workgroups of one residue class
+    see a dense problem) or all full; forward + backward through DQQ_P_AUTO, twice on the same workspace, against the
+    same batch declared DQQ_P_DENSE (the same general kernels without a list).  Both fast-kernel shapes: four waves
+    per workgroup (one aggregated push) and one (a push per wave)."""
+    from diffqcqp_amd import _capi
+    dd, dg = make_problem(kind, B, N, 6700 + N, "dense"), make_problem(kind, B, N, 6700 + N, "diag")
+    per_wg_fwd = (64 // (N // 2)) * 4           # problems per workgroup of the forward (LPP = N/2, four waves)
+    idx = torch.arange(B)
+    if pattern == "sparse":
+        sel = (idx * 2654435761 % 4294967296) % 23 == 0
+    elif pattern == "one_segment":
+        sel = ((idx // per_wg_fwd) % 32 == 5) & (idx % 3 == 0)
+    else:
+        sel = torch.ones(B, dtype=torch.bool)
+    d = dict(dd)
+    d["P"] = torch.where(sel.view(B, 1, 1), dd["P"], dg["P"]).contiguous()
+    g = dev(d)
+    xd, itd = hip_fwd(ops, kind, g, layout=1)
+    gd, sd = hip_bwd(ops, kind, g, xd, layout=1)
+    nd = sel.numpy()
+    try:
+        for wpb in (0, 1, 0):
+            _capi.set_option("wpb", wpb)
+            xa, ita = hip_fwd(ops, kind, g, layout=0)
+            ga, sa = hip_bwd(ops, kind, g, xd, layout=0)
+            torch.cuda.synchronize()
+            for ws in ops._workspaces.values():
+                assert int(ws[:WS_HEADER_INTS].abs().sum()) == 0
+            # queued problems: the very kernel DQQ_P_DENSE launches -> the same bits
+            assert np.array_equal(npy(xa)[nd], npy(xd)[nd]) and np.array_equal(npy(ita)[nd], npy(itd)[nd])
+            assert np.array_equal(npy(sa)[nd], npy(sd)[nd])
+            for a, b in zip(ga, gd):
+                assert np.array_equal(npy(a)[nd], npy(b)[nd])
+            # the rest took the diagonal arithmetic (or, as neighbours of a dense problem in its tile, the list)
+            assert np.abs(npy(xa) - npy(xd)).max() <= 1e-9 and (npy(ita) == npy(itd)).mean() >= 0.99
+            same = (npy(sa) == npy(sd)).reshape(B, -1).all(1)
+            assert same.mean() > 0.9
+            for a, b in zip(ga, gd):
+                a, b = npy(a), npy(b)
+                assert np.abs(a - b)[same].max() <= 1e-6 * max(1.0, np.abs(b).max())
+    finally:
+        _capi.set_option("wpb", 0)
 
 
 @pytest.mark.parametrize("N,B", [(18, 300), (20, 129), (24, 500), (26, 64), (30, 257), (32, 1024), (34, 96), (40, 200),
