@@ -37,6 +37,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (long w = blockIdx.x;; w += gridDim.x) {
         const long prob = claim.next(ws, B, w); // wave-uniform (SGPRs: P's addressing uses a scalar base)
         if (prob < 0) break;
+        claim.ahead_issue(ws); // (work-list: the ticket for this wave's next problem travels while this one is solved)
         int lane = threadIdx.x;
         asm volatile("" : "+v"(lane)); // nothing lane-derived is hoisted out of the problem loop (dense_wave64.hip)
         const int g = lane >> 4, n = lane & 15;
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
         }
         bool bad = false;
+        claim.ahead_entry(ws, B);
         C.factor(lane, bad);                                                  // :22
         C.invert_in_place(lane, s_trb);                                              // :23
         const double KinvAb = sym_upper_matvec<NT>(C.U, Ab, xsrc, lane, s_trb);      // :27
@@ -152,6 +154,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (gamma_out != nullptr) gamma_out[prob * nc + lane] = gamma;
             if (dgamma_out != nullptr) dgamma_out[prob * nc + lane] = dg;
         }
+        claim.ahead_done(ws, B);
         if (is_coord && grad_q != nullptr) grad_q[prob * N + ci] = -b;       // qcqp.py:176
         if (grad_P != nullptr) {                                              // qcqp.py:174: -(dl l^T)
             double* Gp = grad_P + prob * (long)(N * N);

@@ -168,6 +168,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT == 4 ?
     for (long w = blockIdx.x;; w += gridDim.x) {
         const long prob = claim.next(ws, B, w); // wave-uniform (SGPRs: P's addressing uses a scalar base)
         if (prob < 0) break;
+        // (no claim ahead here, unlike the backward kernels: forward problems differ 2x in iteration count, and a
+        // problem claimed at the start of a long one waits while other waves run dry -- measured: 3.79 -> 3.96 ms)
         // everything derived from the lane index is recomputed per problem: hoisted out of this loop (which runs
         // once per wave outside the work-list mode) those dozens of masks and offsets only occupy registers
         int lane = threadIdx.x;
@@ -277,9 +279,10 @@ template <int KIND, int NT, bool PAD>
 static hipError_t launch_wave64(const FwdArgs& a, bool use_worklist, hipStream_t s)
 {
     // one wave per problem, dispatched by the hardware as waves retire (iteration counts differ per problem);
-    // work-list mode: a fixed grid of 8 waves per CU claims the entries one at a time
+    // work-list mode: a fixed grid of as many waves as the chip holds claims the entries one at a time
     const long cap = 1L << 22;
-    const unsigned grid = (unsigned)(a.B < (use_worklist ? 2048L : cap) ? (a.B > 0 ? a.B : 1) : (use_worklist ? 2048L : cap));
+    const long wl = 1024L * (NT == 4 ? 2 : (NT == 3 ? 3 : 4)); // the waves the chip holds of this instantiation
+    const unsigned grid = (unsigned)(a.B < (use_worklist ? wl : cap) ? (a.B > 0 ? a.B : 1) : (use_worklist ? wl : cap));
     return launch(fwd_dense_wave64_kernel<KIND, NT, PAD>, dim3(grid), dim3(64), 0, s, a.P, a.q, a.l_n, a.mu, a.v, a.x, a.B,
                   a.N, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0);
 }
@@ -338,6 +341,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT >= 3 ?
     for (long w = blockIdx.x;; w += gridDim.x) {
         const long prob = claim.next(ws, B, w); // wave-uniform (SGPRs: P's addressing uses a scalar base)
         if (prob < 0) break;
+        claim.ahead_issue(ws); // (work-list: the ticket for this wave's next problem travels while this one is solved)
         int lane = threadIdx.x;
         asm volatile("" : "+v"(lane)); // see the forward kernel: nothing lane-derived is hoisted out of the loop
         const int g = lane >> 4, n = lane & 15;
@@ -390,6 +394,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT >= 3 ?
                     Kc[ta][tb] = acc;
                 }
         }
+        claim.ahead_entry(ws, B);
         bool bad = false;
         C.factor(lane, bad);                                                  // :22
         C.invert_in_place(lane, s_trb);                                              // :23; C.U = upper tiles of K^-1
@@ -405,6 +410,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT >= 3 ?
             const double res = sqrt(wave_sum64(d * d));                       // :31
             if (ctl.update(res)) break;                                       // :32-41
         }
+        claim.ahead_done(ws, B);
         const double dl = bad ? NAN : (is_act ? 0.0 : xs);                    // :187-191
         if (live && grad_q != nullptr) grad_q[prob * N + lane] = -dl;        // qcqp.py:49
         if (grad_P != nullptr) {                                              // qcqp.py:48: -(dl l^T)
@@ -423,7 +429,8 @@ template <int NT, bool PAD>
 static hipError_t launch_bwd_chol(const BwdArgs& a, bool use_worklist, hipStream_t s)
 {
     const long cap = 1L << 22;
-    const unsigned grid = (unsigned)(a.B < (use_worklist ? 2048L : cap) ? (a.B > 0 ? a.B : 1) : (use_worklist ? 2048L : cap));
+    const long wl = 1024L * (NT >= 3 ? 2 : 3); // the waves the chip holds of this instantiation
+    const unsigned grid = (unsigned)(a.B < (use_worklist ? wl : cap) ? (a.B > 0 ? a.B : 1) : (use_worklist ? wl : cap));
     return launch(bwd_dense_chol_qp_kernel<NT, PAD>, dim3(grid), dim3(64), 0, s, a.P, a.q, a.x, a.grad_x, a.grad_P, a.grad_q,
                   a.B, a.N, a.epsilon, a.ir_steps, a.ws, use_worklist ? 1 : 0);
 }

@@ -162,10 +162,20 @@ static DQQ_D long worklist_entry(const int* __restrict__ ws, int N, long B, long
 // Plain list: tickets on ws[kWsNext].  Segmented list: a wave starts on segment blockIdx.x mod 32, draws tickets on
 // THAT segment's pick-up word and moves on when it is exhausted; after 32 exhausted segments it is done -- no
 // prefix sums, and the tickets are spread over 32 addresses as the pushes were.
+// The segmented pick-up can be pipelined (the backward kernels do; without the three ahead_* calls next() claims on
+// the spot): while a wave works on a problem its ticket for the next one is in flight
+// (ahead_issue right after next(), ahead_entry once the problem's own loads have landed, ahead_done at its end).  A
+// ticket and the entry behind it are two dependent round trips to memory, ~3 us that the wave otherwise spends idle
+// before every problem -- 7 % of a 42 us backward at N = 64.
 struct WorkClaim {
     long count;        // direct mode: B; plain list: entries; segmented list: non-zero iff anything is queued
     int seg, left, c;  // segmented: current segment, segments not yet found exhausted, entries of the current one
     bool listed, segd;
+    bool primed;       // segmented: `ahead` holds the wave's next problem (-1: none left)
+    bool pipelined;    // ahead_done ran after the last next()
+    long ahead;
+    int flight;        // per lane: the ticket (stage 1) / the entry (stage 2) in flight
+    int stage;         // 0 nothing in flight, 1 ticket, 2 entry
     DQQ_D void open(const int* __restrict__ ws, int use_worklist, int N, long B)
     {
         listed = use_worklist != 0;
@@ -174,17 +184,14 @@ struct WorkClaim {
         seg = (int)(blockIdx.x & 31u);
         left = 32;
         c = -1;
+        primed = false;
+        pipelined = false;
+        ahead = -1;
+        flight = 0;
+        stage = 0;
     }
-    // the next problem of this wave, -1 = none left.  w: the caller's strided counter (direct mode only).
-    // (An empty list is left untouched: nobody would reset its words.)
-    DQQ_D long next(int* __restrict__ ws, long B, long w)
+    DQQ_D long claim_segmented(int* __restrict__ ws, long B)
     {
-        if (!listed) return w < count ? w : -1;
-        if (count == 0) return -1;
-        if (!segd) {
-            const long t = __builtin_amdgcn_readfirstlane(threadIdx.x == 0 ? atomicAdd(&ws[kWsNext], 1) : 0);
-            return t < count ? (long)__builtin_amdgcn_readfirstlane(ws[kWsEntries + t]) : -1;
-        }
         while (left > 0) {
             if (c < 0) c = __builtin_amdgcn_readfirstlane(ws[kWsSegCounts + seg * kWsSubStride]);
             if (c > 0) {
@@ -197,6 +204,53 @@ struct WorkClaim {
             c = -1;
         }
         return -1;
+    }
+    // the next problem of this wave, -1 = none left.  w: the caller's strided counter (direct mode only).
+    // (An empty list is left untouched: nobody would reset its words.)
+    DQQ_D long next(int* __restrict__ ws, long B, long w)
+    {
+        if (!listed) return w < count ? w : -1;
+        if (count == 0) return -1;
+        if (!segd) {
+            const long t = __builtin_amdgcn_readfirstlane(threadIdx.x == 0 ? atomicAdd(&ws[kWsNext], 1) : 0);
+            return t < count ? (long)__builtin_amdgcn_readfirstlane(ws[kWsEntries + t]) : -1;
+        }
+        if (!primed || !pipelined) { // the first problem, or a kernel that does not claim ahead
+            ahead = claim_segmented(ws, B);
+            primed = true;
+        }
+        return ahead;
+    }
+    // the three stages of the claim ahead; no-ops outside the segmented mode.  Call each once per problem, in order.
+    DQQ_D void ahead_issue(int* __restrict__ ws)
+    {
+        stage = 0;
+        if (segd && left > 0 && c > 0) {
+            flight = threadIdx.x == 0 ? atomicAdd(&ws[kWsSegNext + seg * kWsSubStride], 1) : 0;
+            stage = 1;
+        }
+    }
+    DQQ_D void ahead_entry(const int* __restrict__ ws, long B)
+    {
+        if (stage == 1) {
+            const int t = __builtin_amdgcn_readfirstlane(flight);
+            if (t < c) {
+                flight = ws[kWsEntries + seg * kWsSegCap(B) + t];
+                stage = 2;
+            } else { // this segment is exhausted: ahead_done walks on
+                seg = (seg + 1) & 31;
+                --left;
+                c = -1;
+                stage = 0;
+            }
+        }
+    }
+    DQQ_D void ahead_done(int* __restrict__ ws, long B)
+    {
+        if (!segd) return;
+        ahead = (stage == 2) ? (long)__builtin_amdgcn_readfirstlane(flight) : claim_segmented(ws, B);
+        stage = 0;
+        pipelined = true;
     }
 };
 #endif
