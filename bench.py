@@ -540,6 +540,65 @@ def dense_p_record(args, ctx):
     return rec
 
 
+def survey_extras_record(args, ctx):
+    """The side lines SURVEY.md 8(d) asks for next to the headline: the iteration-count distribution of each headline
+    family (a wave runs as long as its slowest problem), the long-tailed stress variant p ~ U(0,1) of config 2, and the
+    compact diagonal layout (DQQ_P_DIAG, P as (B,N): 192 algorithmic bytes per QP forward at N=8) -- extension lines,
+    never the headline."""
+    from diffqcqp_amd import ops
+    dev = ctx["dev"]
+    B, N = 65536, 8
+    g = torch.Generator(device=dev).manual_seed(1002)
+    r = lambda *s: torch.rand(*s, generator=g, dtype=F64, device=dev)
+
+    def stats(it):
+        it = it.double()
+        q = torch.quantile(it, torch.tensor([0.5, 0.99], dtype=F64, device=dev))
+        tile = it.view(-1, 32).max(dim=1).values          # a wave tile of the bench shape holds 32 problems
+        return {"mean": float(it.mean()), "p50": float(q[0]), "p99": float(q[1]), "max": float(it.max()),
+                "mean_of_tile_max_32": float(tile.mean())}
+
+    def timed(fn, reps=30):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / reps)
+        return sorted(ts)[1]
+
+    p, q = r(B, N) + 0.1, 2 * r(B, N, 1) - 1
+    l_n, mu = r(B, N // 2, 1), r(B, N // 2, 1)
+    P = torch.diag_embed(p).contiguous()
+    rec = {"workload": "B=65536 N=8, eps=1e-7, max_iter=1000; one stream, median of 3 x 30 forward calls through the "
+                       "Python ops layer into a preallocated x"}
+    _, it_qp = ops.qp_forward(P, q, EPS, MAX_ITER, return_iters=True)
+    _, it_qc = ops.qcqp_forward(P, q, l_n, mu, EPS, MAX_ITER, return_iters=True)
+    rec["iterations"] = {"qp_p_u(0.1,1.1)": stats(it_qp), "qcqp_p_u(0.1,1.1)": stats(it_qc)}
+    # stress variant of config 2: p ~ U(0,1) (SURVEY 8d): nearly singular coordinates, long-tailed iteration counts
+    ps = r(B, N)
+    Ps = torch.diag_embed(ps).contiguous()
+    _, it_s = ops.qp_forward(Ps, q, EPS, MAX_ITER, return_iters=True)
+    xb = torch.empty(B, N, 1, dtype=F64, device=dev)
+    t = timed(lambda: ops.qp_forward(Ps, q, EPS, MAX_ITER, out=xb))
+    rec["stress_p_u(0,1)_qp_fwd"] = {"ms_per_call": t * 1e3, "solves_per_s": B / t, "iterations": stats(it_s)}
+    t0 = timed(lambda: ops.qp_forward(P, q, EPS, MAX_ITER, out=xb))
+    rec["same_call_p_u(0.1,1.1)_qp_fwd"] = {"ms_per_call": t0 * 1e3, "solves_per_s": B / t0}
+    # compact diagonal layout: P handed over as (B,N)
+    tc = timed(lambda: ops.qp_forward(p, q, EPS, MAX_ITER, layout=2, out=xb))
+    xc = ops.qp_forward(p, q, EPS, MAX_ITER, layout=2)
+    xd = ops.qp_forward(P, q, EPS, MAX_ITER)
+    rec["compact_diag_layout_qp_fwd"] = {"ms_per_call": tc * 1e3, "solves_per_s": B / tc,
+                                         "algo_bytes_per_problem": 3 * N * 8,
+                                         "algo_GBps": 3 * N * 8 * B / tc / 1e9,
+                                         "bit_identical_to_dense_layout": bool(torch.equal(xc, xd))}
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -616,6 +675,7 @@ def main():
                                      "kernel durations, roofline fractions, CPU baseline on a bounded sample; config_4 is " \
                                      "the whole B=262144 batch on this one GPU"
             out["dense_p_n8"] = dense_p_record(args, ctx)
+            out["survey_8d_extras"] = survey_extras_record(args, ctx)
     if rank == 0:
         out["environment"] = gpu_environment()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
