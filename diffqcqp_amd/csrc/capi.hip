@@ -12,6 +12,7 @@ extern std::atomic<int> g_fwd_compact;
 extern std::atomic<int> g_fwd_respread;
 extern std::atomic<int> g_dense_wave64;
 extern std::atomic<int> g_lane_dense;
+extern std::atomic<int> g_lane_defer;
 extern std::atomic<int> g_dense_teams;
 extern std::atomic<int> g_small_bwd;
 extern std::atomic<int> g_small_fwd;
@@ -36,6 +37,7 @@ Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback"
                       {"dense_block", &dqq::g_dense_block},
                       {"dense_wave64", &dqq::g_dense_wave64},
                       {"lane_dense", &dqq::g_lane_dense},
+                      {"lane_defer", &dqq::g_lane_defer},
                       {"dense_teams", &dqq::g_dense_teams},
                       {"small_bwd", &dqq::g_small_bwd},
                       {"small_fwd", &dqq::g_small_fwd},

@@ -14,13 +14,29 @@
 // diagonal fast path: FMA contraction, reciprocal-multiply instead of divide (1-ulp rcp / rsqrt).
 // The rho-update branch (refactorisation, ~700 instructions) runs under the exec mask of the lanes
 // that fire in that iteration.
+#include <algorithm>
+#include <atomic>
+
 #include "admm_core.h"
 #include "launch.h"
 
 namespace dqq {
 
+// Option "lane_defer": the lane-per-problem kernel runs the refactorisation of the lanes that changed rho every this
+// many trips of its loop (1 = in the trip of the change, as rounds 1-2 did).  Results do not depend on it.
+// Dense 8 x 8 (P = S S^T/8 + 0.1 I), QP / QCQP forward, us (tools/probe_lane_defer.py):
+//   B = 65536    1: 76.7 / 89.2   2: 65.2 / 80.6   3: 61.0 / 79.6   4: 61.3 / 76.8   6: 58.2 / 78.6   8: 61.0 / 78.4   12: 65.9 / 86.7
+//   B = 262144   1: 255 / 275     2: 211 / 246     3: 193 / 236     4: 194 / 234     6: 185 / 247     8: 190 / 248     12: 202 / 270
+// (N = 4: 40.7 / 36.1 -> 38.6 / 34.9).  A model of the wave -- 190 instructions per trip, 440 per refactorisation, the
+// firing pattern of the reference's rho schedule -- predicts 0.66 / 0.73 of the loop's cost at 4.
+std::atomic<int> g_lane_defer{4};
+
 // Explicit inverse of the symmetric matrix whose strict lower triangle is Plow and whose diagonal is
-// d: lower Cholesky (left-looking, as Eigen's unblocked LLT), then per column L y = e_c, L^T x = y.
+// d: lower Cholesky (left-looking, as Eigen's unblocked LLT), the lower triangular L^-1 by forward substitution
+// (column c: L y = e_c, rows >= c), then M^-1 = L^-T L^-1 on its lower half, mirrored (the compiler keeps ONE register
+// per symmetric pair).  Round 2 ran a backward substitution per column instead: 408 instead of 240 multiply-adds
+// at N = 8 -- and this routine is what a wave of 64 problems executes, under a partial mask, whenever ANY of its
+// lanes changes rho: ~25 times per wave on the dense 8 x 8 family of the bench, 60 % of the kernel's instructions.
 template <int N>
 DQQ_D void lane_chol_inverse(const double (&Plow)[N][N], const double (&d)[N], double (&Minv)[N][N], bool& bad)
 {
@@ -43,26 +59,27 @@ DQQ_D void lane_chol_inverse(const double (&Plow)[N][N], const double (&d)[N], d
             L[i][k] = (Plow[i][k] - t) * rs;
         }
     }
+    double Li[N][N]; // L^-1, lower triangle
 #pragma unroll
     for (int c = 0; c < N; ++c) {
-        double y[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            if (i < c) { y[i] = 0.0; continue; }
+        for (int i = c; i < N; ++i) {
             double t = (i == c) ? 1.0 : 0.0;
 #pragma unroll
-            for (int j = c; j < i; ++j) t -= L[i][j] * y[j];
-            y[i] = t * rinv[i];
+            for (int j = c; j < i; ++j) t -= L[i][j] * Li[j][c];
+            Li[i][c] = t * rinv[i];
         }
+    }
 #pragma unroll
-        for (int i = N - 1; i >= 0; --i) {
-            double t = y[i];
+    for (int c = 0; c < N; ++c) {
 #pragma unroll
-            for (int j = i + 1; j < N; ++j) t -= L[j][i] * y[j];
-            y[i] = t * rinv[i];
+        for (int i = c; i < N; ++i) {
+            double t = Li[i][i] * Li[i][c];
+#pragma unroll
+            for (int k = i + 1; k < N; ++k) t += Li[k][i] * Li[k][c];
+            Minv[i][c] = t;
+            Minv[c][i] = t;
         }
-#pragma unroll
-        for (int i = 0; i < N; ++i) Minv[i][c] = y[i];
     }
 }
 
@@ -77,7 +94,7 @@ __global__ __launch_bounds__(64, 1) void fwd_lane_dense_kernel(const double* __r
                                                                const double* __restrict__ v_sign, double* __restrict__ x,
                                                                long B, double eps, double mu, int max_iter,
                                                                int adaptive, int* __restrict__ iters,
-                                                               int* __restrict__ ws, int use_worklist)
+                                                               int* __restrict__ ws, int use_worklist, int defer)
 {
     // KIND 2 / 3 (box / signed box QP, Solver.cpp:198-261 / 374-439): l_n = l_min, mu_c = l_max per coordinate
     static_assert(N % 2 == 0, "even N");
@@ -247,10 +264,16 @@ __global__ __launch_bounds__(64, 1) void fwd_lane_dense_kernel(const double* __r
 #pragma unroll
     for (int i = 0; i < N; ++i) { qp[i] = qv[i]; l2[i] = 0.0; u[i] = 0.0; }
 
+    // The refactorisation after a rho update is DEFERRED: a lane that changes rho (rho, 1/rho and the shifted diagonal
+    // are updated on the spot) sits out until the wave next runs the refactorisation -- every `defer`-th trip, or as
+    // soon as no lane has anything else to do -- so that one pass of those ~450 instructions serves the lanes that fired
+    // over several trips (a trip of the loop costs the wave the same ~190 instructions whether 64 lanes take part or 6).
+    // On the dense 8 x 8 family of the bench a wave ran the refactorisation on 25 of its 47 trips (QP; QCQP 18 of 36).
+    // A lane's own arithmetic, and so its result, does not depend on `defer`.
     int it_done = 0;
-    bool done = !valid;
-    for (int it = 0; it < max_iter; ++it) {
-        if (!done) {
+    bool done = !valid || max_iter <= 0, pend = false;
+    for (int trip = 0;; ++trip) {
+        if (!done && !pend) {
             double rhs[N], w[N], z[N];
             double rd = 0.0, rp = 0.0, nl = 0.0;
 #pragma unroll
@@ -303,24 +326,28 @@ __global__ __launch_bounds__(64, 1) void fwd_lane_dense_kernel(const double* __r
                 l2[i] = z[i];
             }
             const double res_dual = rho * rd, res_prim = rp;
-            it_done = it + 1;
+            it_done += 1;
             bool stop = res_dual < eps;                                           // :88
             if (KIND == 1) {
                 if (stop) stop = res_prim < eps + kEpsRel * sqrt(nl);             // :548
             }
-            done = stop;
-            if (!stop && adaptive) {
+            done = stop || it_done >= max_iter;
+            if (!done && adaptive) {
                 double delta;
                 if (sched.template update<QP_LIKE, true>(res_prim, res_dual, delta)) { // Solver.cpp:90-120 / 550-580
                     rho = sched.rho;
                     inv_rho = fast_rcp(rho);
 #pragma unroll
                     for (int i = 0; i < N; ++i) md[i] += delta;
-                    lane_chol_inverse<N>(Pm, md, Minv, bad);                      // llt() + solveInPlace(Identity)
+                    pend = true;
                 }
             }
         }
         if (__all(done)) break;
+        if (__any(pend) && ((trip + 1) % defer == 0 || !__any(!done && !pend))) {
+            if (pend) lane_chol_inverse<N>(Pm, md, Minv, bad);                    // llt() + solveInPlace(Identity)
+            pend = false;
+        }
     }
 
     if (valid) {
@@ -339,7 +366,8 @@ static hipError_t launch_lane(const FwdArgs& a, bool use_worklist, hipStream_t s
     const long nw = (a.B + 63) / 64;
     if (nw == 0) return hipSuccess;
     return launch((fwd_lane_dense_kernel<KIND, N>), dim3((unsigned)nw), dim3(64), 0, s, a.P, a.q, a.l_n, a.mu, a.v, a.x,
-                       a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0);
+                       a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0,
+                       std::min(64, std::max(1, g_lane_defer.load())));
 }
 
 bool fwd_lane_dense_supported(int N) { return N == 2 || N == 4 || N == 6 || N == 8; }

@@ -218,3 +218,43 @@ def test_qcqp_refinement_exit_flips_are_the_reference_at_the_other_exit(oracle, 
         e_hip = np.abs(npy(grads[1])[i, :, 0] - ex).max() / scale
         e_one = np.abs(forced[1][1][k, :, 0] - ex).max() / scale
         assert e_hip <= e_one * (1 + 1e-6) + 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["qp", "qcqp", "box", "sbox"])
+@pytest.mark.parametrize("N", [2, 4, 6, 8])
+def test_lane_kernel_deferred_refactorisation_is_bit_identical(oracle, ops, kind, N):
+    """The lane-per-problem forward (dense P, N <= 8) defers the refactorisation after a rho update so that one pass
+    serves the lanes that fired over several trips of the wave's loop (option lane_defer, csrc/fwd_lane_dense.hip).
+    A lane only sits out meanwhile: x and the iteration counts must not depend on the deferral -- every setting, at
+    the reference's default budget, at budgets that run out mid-solve (max_iter exhaustion, Solver.cpp:79 / :538) and
+    at eps = 1e-10; checked against the oracle once."""
+    from diffqcqp_amd import _capi
+    B = 3001
+    d = make_problem(kind, B, N, 9100 + N, "dense")
+    g = dev(d)
+
+    def fwd(eps, max_iter):
+        if kind in ("box", "sbox"):
+            return ops.boxqp_forward(g["P"], g["q"], g["l_min"], g["l_max"], eps, max_iter, v=g.get("v"), layout=1,
+                                     return_iters=True)
+        return hip_fwd(ops, kind, g, layout=1, eps=eps, max_iter=max_iter)
+
+    _capi.set_option("fuse_fallback", 0)   # (N = 8, small B: DQQ_P_DENSE would otherwise take the group solve)
+    try:
+        for eps, max_iter in ((1e-7, 1000), (1e-10, 1000), (1e-7, 23), (1e-7, 7), (1e-7, 1)):
+            _capi.set_option("lane_defer", 1)
+            x1, it1 = fwd(eps, max_iter)
+            for defer in (2, 3, 4, 7, 64):
+                _capi.set_option("lane_defer", defer)
+                xd, itd = fwd(eps, max_iter)
+                assert torch.equal(it1, itd), (eps, max_iter, defer)
+                assert torch.equal(torch.nan_to_num(x1, nan=12345.0), torch.nan_to_num(xd, nan=12345.0)), (eps, max_iter, defer)
+            if max_iter == 1000 and eps == 1e-7 and kind in ("qp", "qcqp"):
+                xo, ito = oracle_fwd(oracle, kind, d)
+                check_forward(xd, itd, xo, ito, min_match=0.99)
+            if max_iter < 1000:
+                assert int(it1.max()) <= max_iter
+    finally:
+        _capi.set_option("lane_defer", 4)
+        _capi.set_option("fuse_fallback", -1)
