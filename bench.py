@@ -17,7 +17,8 @@ Workloads (`--config k` = k-th entry of BASELINE.json `configs`, 1-based as in B
   2         B=65536 N=8 diagonal-P QP, forward only                                   (one launch per step)
   3         B=65536 N=8 QCQP forward+backward
   4         B=262144 N=32 QP forward+backward, the batch SPLIT over the ranks (strong scaling); `value` includes the
-            RCCL all-gather of x after every step, the rate without it is reported alongside
+            RCCL all-gather of x in every step (behind the forward, beside the backward), the rates without it and
+            with it serialised behind the backward are reported alongside
   5         B=65536 N=64 dense-P QP forward+backward (P = S S^T/64 + 0.1 I), through DQQ_P_AUTO as QPFn2 calls it
 Timing: W warm-up steps, then R regions of EXACTLY K steps, each bracketed by barrier + torch.cuda.synchronize()
 on both sides and reduced with MAX over the ranks; `ms_per_step` / `value` are the MEDIAN region (min / max in
@@ -299,10 +300,25 @@ def measure(cfg, args, ctx, light=False):
             el = float(tm.item())
         return el
 
-    def step_and_gather():
+    def step_and_gather_serial():
         nonlocal x_all
         step()
         x_all = parallel.gather_batch(chains[0].sets[0]["x"], B_total) if use_dist else chains[0].sets[0]["x"]
+
+    def step_and_gather():
+        """The path's one exchange step where it belongs: x is complete after the FORWARD, so its all-gather (RCCL's own
+        stream, ordered behind the forward) travels over xGMI while the backward of the same problems runs -- the
+        backward needs this rank's x only.  The step ends when both are done (the launch stream waits for the
+        collective)."""
+        nonlocal x_all
+        if not use_dist:
+            return step_and_gather_serial()
+        chains[0].launch(0, sh)
+        x_all, work = parallel.gather_batch(chains[0].sets[0]["x"], B_total, async_op=True)
+        for w in range(1, len(chains[0].names)):
+            chains[0].launch(w, sh)
+        if work is not None:
+            work.wait()
 
     timed = step_and_gather if gather else step
 
@@ -316,6 +332,12 @@ def measure(cfg, args, ctx, light=False):
     if gather and use_dist:
         assert x_all.shape[0] == B_total
     extra = {}
+    if gather and use_dist:   # the same regions with the gather behind the whole step instead of beside the backward
+        tg = sorted(region(step_and_gather_serial, steps) for _ in range(max(repeats // 2, 1)))
+        extra["gather_after_backward"] = {"ms_per_step": tg[len(tg) // 2] / steps * 1e3,
+                                          "value": B_total * steps / tg[len(tg) // 2],
+                                          "note": "forward, backward, then the all-gather of x (serialised); the headline "
+                                                  "value overlaps the all-gather with the backward"}
     if gather:   # the same regions without the exchange step
         tn = sorted(region(step, steps) for _ in range(max(repeats // 2, 1)))
         extra["without_gather"] = {"ms_per_step": tn[len(tn) // 2] / steps * 1e3,
@@ -453,7 +475,7 @@ def measure(cfg, args, ctx, light=False):
             "B_this_rank": [c.B for c in chains], "N": [c.N for c in chains],
             "p_layout": "auto (off-diagonals verified in-kernel; non-diagonal tiles go to the general kernel)",
             "launch": "eager, one C-ABI call per pass" + (", the two families on two streams" if side is not None else ""),
-            "sharding": ("batch split over the ranks, no data-path collective; RCCL all-gather of x per step"
+            "sharding": ("batch split over the ranks, no data-path collective; RCCL all-gather of x per step, issued after the forward and overlapped with the backward"
                          if gather else ("batch shards, no collective" if world > 1 else "single GPU")),
             "rccl_world": dist.get_world_size() if use_dist else 1,
         },
@@ -506,7 +528,7 @@ def condensed(rec):
         out["roofline"]["fp64_TFLOPs"] = rl["fp64"]["achieved"]
     if "fp64_valu_issue" in rl:
         out["roofline"]["fp64_valu_issue_frac"] = rl["fp64_valu_issue"]["frac"]
-    for k in ("without_gather", "cpu_baseline", "parity_max_abs_err_vs_oracle_sample", "gpu_over_cpu_all_cores"):
+    for k in ("without_gather", "gather_after_backward", "cpu_baseline", "parity_max_abs_err_vs_oracle_sample", "gpu_over_cpu_all_cores"):
         if k in rec:
             out[k] = rec[k]
     return out
