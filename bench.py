@@ -699,6 +699,11 @@ def main():
             out["dense_p_n8"] = dense_p_record(args, ctx)
             out["survey_8d_extras"] = survey_extras_record(args, ctx)
     if rank == 0:
+        out["scaling_note"] = ("two curves can be read across the driver's N = 1, 2, 4, 8 lines: STRONG scaling of configs[3] "
+                               "(B=262144 N=32 split over the ranks) = `per_config.config_4` of the N=1 line, then `value` of "
+                               "the N>1 lines; WEAK scaling of the headline step = `value` of the N=1 line, then "
+                               "`weak_headline.value` of the N>1 lines.  `value` itself changes workload between N=1 "
+                               "(headline) and N>1 (configs[3]), as BASELINE.json names them")
         out["environment"] = gpu_environment()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
