@@ -38,6 +38,7 @@ namespace dqq {
 // twice the lanes (admm_core.h admm_fwd_diag_respread; N = 8, two lanes per problem, QP / QCQP).  0 = never.
 // Results do not depend on it (bit-identical, tests/test_gpu_compaction.py).
 std::atomic<int> g_fwd_respread{16};
+int lane_defer_for(int kind); // fwd_lane_dense.hip: the general routines' deferred refactorisation (option lane_defer)
 constexpr bool fwd_diag_respreads(int kind, int n, int lpp) { return kind < 2 && n == 8 && lpp == 2; }
 
 // CMP: the tiles of a workgroup are repacked as their problems stop (admm_compact.h); a workgroup that meets a
@@ -52,7 +53,8 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
                                                             int adaptive, int layout, int* __restrict__ iters,
                                                             int* __restrict__ ws,
                                                             double* __restrict__ pdiag_out,
-                                                            unsigned char* __restrict__ flags_out, int respread_at)
+                                                            unsigned char* __restrict__ flags_out, int respread_at,
+                                                            int gdefer)
 {
     constexpr int E = N / LPP;       // coordinates per lane
     constexpr int PPW = 64 / LPP;    // problems per wave tile
@@ -190,11 +192,11 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
         if (dense_tile) {
             if constexpr (LD == LPP) {
                 it = group_dense_fwd<KIND, N, LPP>(P + (first + pl) * (long)(N * N), qv, rad, eps, mu_prox, max_iter,
-                                                   adaptive, valid, xv, lo, hi, sg);
+                                                   adaptive, valid, xv, lo, hi, sg, gdefer);
                 solved = true;
             } else {
                 group_dense_tile<KIND, N, LD, PPW>(P, q, l_n, mu_c, v_sign, x, iters, first, nvalid, eps, mu_prox, max_iter,
-                                                   adaptive, lane);
+                                                   adaptive, lane, gdefer);
                 DQQ_TL(5);
                 return; // x / iters written in the general solve's own mapping; no barrier follows
             }
@@ -247,7 +249,8 @@ static hipError_t launch_one(const FwdArgs& a, hipStream_t s)
     if (nblocks == 0) return hipSuccess;
     return launch((fwd_diag_kernel<KIND, N, LPP, WPB, FUSE, CMP>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q,
                        a.l_n, a.mu, a.v, a.x, a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.layout, a.iters, a.ws,
-                       a.pdiag_out, a.flags_out, std::min(16, std::max(0, g_fwd_respread.load())));
+                       a.pdiag_out, a.flags_out, std::min(16, std::max(0, g_fwd_respread.load())),
+                       lane_defer_for(KIND));
 }
 
 // Option "fwd_compact": 1 = repack the tiles of a workgroup as their problems stop (admm_compact.h).  OFF by

@@ -23,13 +23,20 @@
 namespace dqq {
 
 // Option "lane_defer": the lane-per-problem kernel runs the refactorisation of the lanes that changed rho every this
-// many trips of its loop (1 = in the trip of the change, as rounds 1-2 did).  Results do not depend on it.
+// many trips of its loop (1 = in the trip of the change, as rounds 1-2 did; 0 = built-in choice per kind).  Results do
+// not depend on it.  The group solve of the fused forward (group_dense.h) takes the same option.
 // Dense 8 x 8 (P = S S^T/8 + 0.1 I), QP / QCQP forward, us (tools/probe_lane_defer.py):
 //   B = 65536    1: 76.7 / 89.2   2: 65.2 / 80.6   3: 61.0 / 79.6   4: 61.3 / 76.8   6: 58.2 / 78.6   8: 61.0 / 78.4   12: 65.9 / 86.7
 //   B = 262144   1: 255 / 275     2: 211 / 246     3: 193 / 236     4: 194 / 234     6: 185 / 247     8: 190 / 248     12: 202 / 270
 // (N = 4: 40.7 / 36.1 -> 38.6 / 34.9).  A model of the wave -- 190 instructions per trip, 440 per refactorisation, the
 // firing pattern of the reference's rho schedule -- predicts 0.66 / 0.73 of the loop's cost at 4.
-std::atomic<int> g_lane_defer{4};
+std::atomic<int> g_lane_defer{0};
+// 0 = built-in: 4 for the QCQP, 6 for the QP-like kinds (sweeps above and in tools/probe_group_defer.py)
+int lane_defer_for(int kind)
+{
+    const int v = g_lane_defer.load();
+    return v > 0 ? (v < 64 ? v : 64) : (kind == kKindQCQP ? 4 : 6);
+}
 
 // Explicit inverse of the symmetric matrix whose strict lower triangle is Plow and whose diagonal is
 // d: lower Cholesky (left-looking, as Eigen's unblocked LLT), the lower triangular L^-1 by forward substitution
@@ -367,7 +374,7 @@ static hipError_t launch_lane(const FwdArgs& a, bool use_worklist, hipStream_t s
     if (nw == 0) return hipSuccess;
     return launch((fwd_lane_dense_kernel<KIND, N>), dim3((unsigned)nw), dim3(64), 0, s, a.P, a.q, a.l_n, a.mu, a.v, a.x,
                        a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0,
-                       std::min(64, std::max(1, g_lane_defer.load())));
+                       lane_defer_for(KIND));
 }
 
 bool fwd_lane_dense_supported(int N) { return N == 2 || N == 4 || N == 6 || N == 8; }

@@ -138,7 +138,8 @@ struct GroupRows {
 template <int KIND, int N, int LPP>
 DQQ_D int group_dense_fwd(const double* __restrict__ Pg, const double (&q)[N / LPP], const double* rad, double eps,
                           double mu, int max_iter, int adaptive, bool valid, double (&x)[N / LPP],
-                          const double* lo = nullptr, const double* hi = nullptr, const double* sg = nullptr)
+                          const double* lo = nullptr, const double* hi = nullptr, const double* sg = nullptr,
+                          int defer = 4)
 {
     constexpr int E = N / LPP;
     constexpr bool QP_LIKE = (KIND != 1);
@@ -269,18 +270,36 @@ DQQ_D int group_dense_fwd(const double* __restrict__ Pg, const double (&q)[N / L
         _Pragma("unroll") for (int e_ = 0; e_ < E; ++e_) rhs_[e_] = __builtin_fma(rho, l2[e_], -u[e_]) - qp[e_];                  \
         R::matvec(A, rhs_, l);                                                                                        \
     } while (0)
+    // The refactorisation after a rho update is DEFERRED (as in fwd_lane_dense.hip; option "lane_defer"): the group
+    // updates rho, 1/rho and the shifted diagonal on the spot and sits out until the wave next runs the sweep -- every
+    // `defer`-th trip of the loop, or as soon as no group has anything else to do.  One sweep (~590 instructions, a
+    // trip of the iteration is ~150) then serves every group that changed rho since the last one; with 16 problems
+    // per wave some group fires on most trips otherwise.  A problem's own arithmetic does not depend on `defer`.
 #define DQQ_ADMM_REFACTOR(delta)                                                                                      \
     do {                                                                                                              \
         _Pragma("unroll") for (int e_ = 0; e_ < E; ++e_) md[e_] += (delta);                                           \
-        R::load_lower_symmetric(Pg, s, md, A);                                                                        \
-        R::invert(A, s, bad);                                                                                         \
+        pend = true;                                                                                                  \
     } while (0)
     int rho_up = 0, cpt = 0, iters = 0;
-    if (valid) {
-        for (int it = 0; it < max_iter; ++it) {
-#define DQQ_ADMM_ON_STOP break
+    bool run = valid && max_iter > 0, pend = false;
+    int it = 0;
+    for (int trip = 0;; ++trip) {
+        if (run && !pend) {
+            do {
+#define DQQ_ADMM_ON_STOP { run = false; break; }
 #include "admm_diag_body.inc"
 #undef DQQ_ADMM_ON_STOP
+            } while (0);
+            ++it;
+            if (it >= max_iter) run = false;
+        }
+        if (!__any(run)) break;
+        if (__any(pend) && ((trip + 1) % defer == 0 || !__any(run && !pend))) {
+            if (pend) {
+                R::load_lower_symmetric(Pg, s, md, A);
+                R::invert(A, s, bad);                                   // llt() + solveInPlace(Identity), :100-101
+            }
+            pend = false;
         }
     }
 #undef DQQ_ADMM_REFACTOR
@@ -304,7 +323,7 @@ template <int KIND, int N, int LD, int TILE>
 DQQ_D void group_dense_tile(const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ l_n,
                             const double* __restrict__ mu_c, const double* __restrict__ v_sign, double* __restrict__ x,
                             int* __restrict__ iters, long first, int nvalid, double eps, double mu, int max_iter,
-                            int adaptive, int lane)
+                            int adaptive, int lane, int defer = 4)
 {
     constexpr int E = N / LD, PPP = 64 / LD; // coordinates per lane, problems per pass
     static_assert(E >= 2 && E % 2 == 0 && TILE % PPP == 0, "whole contacts per lane, whole passes per tile");
@@ -338,7 +357,7 @@ DQQ_D void group_dense_tile(const double* __restrict__ P, const double* __restri
             }
         }
         const int it = group_dense_fwd<KIND, N, LD>(P + prob * (long)(N * N), qv, rad, eps, mu, max_iter, adaptive, valid,
-                                                    xv, lo, hi, sg);
+                                                    xv, lo, hi, sg, defer);
         if (valid) {
 #pragma unroll
             for (int e = 0; e < E; e += 2)

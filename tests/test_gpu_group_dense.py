@@ -89,3 +89,36 @@ def test_dense_layout_small_batches_take_the_group_kernel(oracle, ops):
             xo, ito = oracle_fwd(oracle, kind, dn)
             xh, ith = hip_fwd(ops, kind, dev(d), layout=_capi.P_DENSE)
             check_forward(xh[:n], ith[:n], xo, ito, min_match=0.99)
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp", "box", "sbox"])
+@pytest.mark.parametrize("N,lpp", [(2, 1), (4, 2), (8, 2), (8, 4)])
+def test_group_solve_deferred_refactorisation_is_bit_identical(ops, fused, kind, N, lpp):
+    """The group solve defers the Gauss-Jordan sweep after a rho update so that one sweep serves every problem of the
+    wave that changed rho over several trips (option lane_defer, csrc/group_dense.h).  A problem only sits out
+    meanwhile: x and the iteration counts must not depend on the setting -- through DQQ_P_AUTO (tiles of a mixed batch
+    met by the fused kernel, the two-pass narrow mapping at N = 8 on two lanes per problem) and through DQQ_P_DENSE
+    (the solve's own mapping), budgets that run out mid-solve included."""
+    fused.set_option("fwd_lpp", lpp)
+    B = 1500
+    g = dev(make_problem(kind, B, N, 9300 + N, "mixed"))
+    gd = dev(make_problem(kind, B, N, 9400 + N, "dense"))
+
+    def fwd(gg, layout, eps, max_iter):
+        if kind in ("box", "sbox"):
+            return ops.boxqp_forward(gg["P"], gg["q"], gg["l_min"], gg["l_max"], eps, max_iter, v=gg.get("v"), layout=layout,
+                                     return_iters=True)
+        return hip_fwd(ops, kind, gg, layout=layout, eps=eps, max_iter=max_iter)
+
+    try:
+        for gg, layout in ((g, 0), (gd, 0), (gd, 1)):
+            for eps, max_iter in ((1e-7, 1000), (1e-10, 1000), (1e-7, 9), (1e-7, 1)):
+                fused.set_option("lane_defer", 1)
+                x1, it1 = fwd(gg, layout, eps, max_iter)
+                for defer in (0, 2, 4, 6, 64):
+                    fused.set_option("lane_defer", defer)
+                    xd, itd = fwd(gg, layout, eps, max_iter)
+                    assert torch.equal(it1, itd), (layout, eps, max_iter, defer)
+                    assert torch.equal(torch.nan_to_num(x1, nan=12345.0), torch.nan_to_num(xd, nan=12345.0))
+    finally:
+        fused.set_option("lane_defer", 0)
