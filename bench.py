@@ -51,6 +51,10 @@ import time
 # serialise (measured, one rank: 80.6 us per step instead of 59.5).  Eight queues keep the chains concurrent.
 # Must be in the environment before the runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Kernel arguments in device memory (the runtime's default on this image: unset and "1" measure alike, 56.7 us per
+# headline step; "0" -- arguments fetched from host memory at every launch -- 64.2 us: six launches per step).  Pinned
+# here so that a box whose runtime defaults differently measures the same thing; an explicit setting is respected.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -214,7 +218,8 @@ def gpu_environment():
     """Clocks, power cap and queue setting of this box (boxes of the pool differ by up to ~9 %).
     Best effort: rocm-smi may be missing or slow; nothing here is required for the measurement."""
     import subprocess
-    env = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "device": torch.cuda.get_device_name(0)}
+    env = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+           "HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG"), "device": torch.cuda.get_device_name(0)}
     try:
         p = torch.cuda.get_device_properties(0)
         env.update({"compute_units": p.multi_processor_count, "clock_rate_khz_reported": getattr(p, "clock_rate", None)})
