@@ -19,6 +19,8 @@
 
 namespace dqq {
 
+int lane_defer_for(int kind); // fwd_lane_dense.hip (option lane_defer)
+
 template <int N>
 struct SmallFwd {
     static constexpr int T = 16;                       // team width (8 < N <= 16)
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256, N >= 14 ? 1 : 2) void fwd_small_kernel(const d
                                                         const double* __restrict__ mu_c,
                                                         const double* __restrict__ v_sign, double* __restrict__ x,
                                                         long B, double eps, double mu, int max_iter, int adaptive,
-                                                        int* __restrict__ iters, int* __restrict__ ws, int use_worklist)
+                                                        int* __restrict__ iters, int* __restrict__ ws, int use_worklist, int defer)
 {
     using S = SmallFwd<N>;
     using G = LaneGroup<S::T>;
@@ -183,10 +185,13 @@ __global__ __launch_bounds__(256, N >= 14 ? 1 : 2) void fwd_small_kernel(const d
     ts.chol_inverse(Prow, md, Minv, bad);
 
     double qp = qi, l2 = 0.0, u = 0.0;
+    // The refactorisation after a rho update is deferred as in fwd_lane_dense.hip (option lane_defer): the team updates
+    // rho, 1/rho and its shifted diagonal entry on the spot and sits out until the wave next runs chol_inverse -- every
+    // `defer`-th trip, or as soon as no team has anything else to do.  A problem's arithmetic does not depend on it.
     int it_done = 0;
-    bool done = !valid;
-    for (int it = 0; it < max_iter; ++it) {
-        if (!done) {
+    bool done = !valid || max_iter <= 0, pend = false;
+    for (int trip = 0;; ++trip) {
+        if (!done && !pend) {
             const double rhs = actn ? rho * l2 - u - qp : 0.0;
             const double l = ts.matvec(Minv, rhs);                                  // :80 / :539
             qp = qi - mu * l;                                                     // :81 / :540
@@ -215,24 +220,28 @@ __global__ __launch_bounds__(256, N >= 14 ? 1 : 2) void fwd_small_kernel(const d
             const double rp = G::max(actn ? fabs(z - w) : 0.0);
             l2 = z;
             const double res_dual = rho * rd, res_prim = rp;
-            it_done = it + 1;
+            it_done += 1;
             bool stop = res_dual < eps;                                           // :88
             if (KIND == 1) {
                 const double nl = G::sum(actn ? l * l : 0.0);
                 if (stop) stop = res_prim < eps + kEpsRel * sqrt(nl);             // :548
             }
-            done = stop;
-            if (!stop && adaptive) {
+            done = stop || it_done >= max_iter;
+            if (!done && adaptive) {
                 double delta;
                 if (sched.template update<QP_LIKE, true>(res_prim, res_dual, delta)) { // Solver.cpp:90-120 / 550-580
                     rho = sched.rho;
                     inv_rho = fast_rcp(rho);
                     md += delta;
-                    ts.chol_inverse(Prow, md, Minv, bad);                         // llt() + solveInPlace(Identity)
+                    pend = true;
                 }
             }
         }
         if (__all(done)) break;
+        if (__any(pend) && ((trip + 1) % defer == 0 || !__any(!done && !pend))) {
+            if (pend) ts.chol_inverse(Prow, md, Minv, bad);                       // llt() + solveInPlace(Identity)
+            pend = false;
+        }
     }
 
     bad = G::max(bad ? 1.0 : 0.0) > 0.0;
@@ -253,7 +262,8 @@ static hipError_t launch_small_fwd(const FwdArgs& a, bool use_worklist, hipStrea
     const long nb = (a.B + per_block - 1) / per_block;
     if (nb == 0) return hipSuccess;
     return launch((fwd_small_kernel<KIND, N>), dim3((unsigned)nb), dim3(64 * WPB), lds_bytes, s, a.P, a.q, a.l_n, a.mu,
-                       a.v, a.x, a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0);
+                       a.v, a.x, a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.iters, a.ws, use_worklist ? 1 : 0,
+                       lane_defer_for(KIND));
 }
 
 bool fwd_small_supported(int N) { return N == 10 || N == 12 || N == 14 || N == 16; }

@@ -222,9 +222,10 @@ def test_qcqp_refinement_exit_flips_are_the_reference_at_the_other_exit(oracle, 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["qp", "qcqp", "box", "sbox"])
-@pytest.mark.parametrize("N", [2, 4, 6, 8])
+@pytest.mark.parametrize("N", [2, 4, 6, 8, 10, 12, 16])
 def test_lane_kernel_deferred_refactorisation_is_bit_identical(oracle, ops, kind, N):
-    """The lane-per-problem forward (dense P, N <= 8) defers the refactorisation after a rho update so that one pass
+    """The lane-per-problem forward (dense P, N <= 8; N = 10 .. 16: the team-per-problem forward, csrc/fwd_small.hip,
+    with the same deferral) defers the refactorisation after a rho update so that one pass
     serves the lanes that fired over several trips of the wave's loop (option lane_defer, csrc/fwd_lane_dense.hip).
     A lane only sits out meanwhile: x and the iteration counts must not depend on the deferral -- every setting, at
     the reference's default budget, at budgets that run out mid-solve (max_iter exhaustion, Solver.cpp:79 / :538) and
