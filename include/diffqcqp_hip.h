@@ -186,8 +186,8 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
  *                    wave / team kernel with run-time sizes (0)
  *   "lane_dense"     general path, N = 2..8 forward: lane-per-problem kernel (1, default) or the
  *                    wave-per-problem kernel (0)
- *   "lane_defer"     general forward for N <= 8 (lane-per-problem kernel and the group solve inside the fused fast
- *                    kernel): the refactorisation after a rho update runs every this many trips of the wave's loop,
+ *   "lane_defer"     general forward for N <= 16 (lane-per-problem kernel, the group solve inside the fused fast
+ *                    kernel, team-per-problem kernel): the refactorisation after a rho update runs every this many trips of the wave's loop,
  *                    for all problems that changed rho since the last one (0, default: 4 for the QCQP, 6 for the other
  *                    kinds; 1 = in the trip of the update).  Bit-identical results.
  *   "dense_wave64"   general path, 16 < N <= 64 forward and QP backward: register-resident
