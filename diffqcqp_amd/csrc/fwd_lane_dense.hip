@@ -31,7 +31,8 @@ namespace dqq {
 // (N = 4: 40.7 / 36.1 -> 38.6 / 34.9).  A model of the wave -- 190 instructions per trip, 440 per refactorisation, the
 // firing pattern of the reference's rho schedule -- predicts 0.66 / 0.73 of the loop's cost at 4.
 std::atomic<int> g_lane_defer{0};
-// 0 = built-in: 4 for the QCQP, 6 for the QP-like kinds (sweeps above and in tools/probe_group_defer.py)
+// 0 = built-in: 4 for the QCQP, 6 for the QP-like kinds (sweeps above and in tools/probe_group_defer.py; box / signed box
+// QP, dense 8 x 8, B = 65536: 1: 79.7 / 80.5   2: 70.7 / 73.4   4: 69.0 / 71.2   6: 65.6 / 68.1   8: 68.0 / 69.9 us)
 int lane_defer_for(int kind)
 {
     const int v = g_lane_defer.load();
