@@ -97,6 +97,7 @@ class Chain:
         self.sets = [self._make_set(seed + 104729 * s) for s in range(nsets)]
         self.names = [kind + "_fwd"] + ([kind + "_bwd"] if backward else [])
         self.ws = {}
+        self.calls = {}
         self.ops = ops
         self.handoff = structure == "diag" and layout == 0
 
@@ -128,23 +129,31 @@ class Chain:
             self.ws[stream] = self.ops._workspace(self.dev, self.B, stream)
         return self.ws[stream]
 
-    def launch(self, which, stream, s=0):
+    def _call(self, which, stream, s):
+        """(C-ABI function, full argument tuple) of one launch -- every pointer resolved ONCE (the host
+        side of a 56 us step must not re-resolve 16 data_ptr() per call)."""
         t, L, p = self.sets[s], self.lib, (lambda a: a.data_ptr())
         ws = self.workspace(stream)
         wsb, B, N = ws.numel() * 4, self.B, self.N
         if which == 0 and self.kind == "qp":
-            rc = L.dqq_qp_fwd_f64(p(t["P"]), p(t["q"]), p(t["x"]), B, N, EPS, MU_PROX, MAX_ITER, 1, self.layout, None,
-                                  p(t["pdiag"]), p(t["flags"]), p(ws), wsb, stream)
-        elif which == 0:
-            rc = L.dqq_qcqp_fwd_f64(p(t["P"]), p(t["q"]), p(t["l_n"]), p(t["mu"]), p(t["x"]), B, N, EPS, MU_PROX, MAX_ITER,
-                                    1, self.layout, None, p(t["pdiag"]), p(t["flags"]), p(ws), wsb, stream)
-        elif self.kind == "qp":
-            rc = L.dqq_qp_bwd_f64(p(t["P"]), p(t["q"]), p(t["x"]), p(t["g"]), p(t["gP"]), p(t["gq"]), B, N, 1e-10,
-                                  self.layout, None, p(t["pdiag"]), p(t["flags"]), p(ws), wsb, stream)
-        else:
-            rc = L.dqq_qcqp_bwd_f64(p(t["P"]), p(t["q"]), p(t["l_n"]), p(t["mu"]), p(t["x"]), p(t["g"]), p(t["gP"]),
+            return L.dqq_qp_fwd_f64, (p(t["P"]), p(t["q"]), p(t["x"]), B, N, EPS, MU_PROX, MAX_ITER, 1, self.layout, None,
+                                      p(t["pdiag"]), p(t["flags"]), p(ws), wsb, stream)
+        if which == 0:
+            return L.dqq_qcqp_fwd_f64, (p(t["P"]), p(t["q"]), p(t["l_n"]), p(t["mu"]), p(t["x"]), B, N, EPS, MU_PROX,
+                                        MAX_ITER, 1, self.layout, None, p(t["pdiag"]), p(t["flags"]), p(ws), wsb, stream)
+        if self.kind == "qp":
+            return L.dqq_qp_bwd_f64, (p(t["P"]), p(t["q"]), p(t["x"]), p(t["g"]), p(t["gP"]), p(t["gq"]), B, N, 1e-10,
+                                      self.layout, None, p(t["pdiag"]), p(t["flags"]), p(ws), wsb, stream)
+        return L.dqq_qcqp_bwd_f64, (p(t["P"]), p(t["q"]), p(t["l_n"]), p(t["mu"]), p(t["x"]), p(t["g"]), p(t["gP"]),
                                     p(t["gq"]), p(t["gl"]), p(t["gm"]), None, None, B, N, 1e-10, self.layout, None,
                                     p(t["pdiag"]), p(t["flags"]), p(ws), wsb, stream)
+
+    def launch(self, which, stream, s=0):
+        key = (which, stream, s)
+        c = self.calls.get(key)
+        if c is None:
+            c = self.calls[key] = self._call(which, stream, s)
+        rc = c[0](*c[1])
         if rc != 0:
             raise RuntimeError("launch %s failed with %d" % (self.names[which], rc))
 
@@ -211,6 +220,11 @@ WORKLOADS = {
         "all-gather of x after every step", [("qp", 32, "diag", True)], 262144, "strong", 16384),
     5: ("BASELINE configs[4]: B=65536 N=64 dense-P QP (P = S S^T/64 + 0.1 I) forward+backward",
         [("qp", 64, "dense", True)], 65536, "weak", 2048),
+    # not a BASELINE config: what a real contact problem presents -- a dense 8x8 Delassus matrix (P = S S^T/8 + 0.1 I)
+    6: ("dense-P B=65536 N=8 QCQP forward+backward through DQQ_P_AUTO (what QCQPFn2 passes)",
+        [("qcqp", 8, "dense", True, 0)], 65536, "weak", 16384),
+    7: ("dense-P B=65536 N=8 QCQP forward+backward, P declared dense (DQQ_P_DENSE)",
+        [("qcqp", 8, "dense", True, 1)], 65536, "weak", 16384),
 }
 
 
@@ -255,15 +269,19 @@ def measure(cfg, args, ctx, light=False):
     if cfg == 4 and args.steps == 100:
         steps = 20
     if light:
-        steps, repeats, warmup = {2: 50, 3: 50, 4: 10, 5: 3, 0: 50, 6: 20}[cfg], 3, 3
+        steps, repeats, warmup = {2: 50, 3: 50, 4: 10, 5: 3, 0: 50, 6: 10, 7: 10}[cfg], 3, 3
 
-    chains = [Chain(k, B_rank, n, st, bw, dev, 1000 + 17 * cfg + 7919 * rank + 31 * i)
-              for i, (k, n, st, bw) in enumerate(families)]
+    chains = [Chain(f[0], B_rank, f[1], f[2], f[3], dev, 1000 + 17 * min(cfg, 6) + 7919 * rank + 31 * i,
+                    layout=(f[4] if len(f) > 4 else 0)) for i, f in enumerate(families)]
     main_stream = torch.cuda.current_stream()
     sh = main_stream.cuda_stream
     side = ctx["side"] if (len(chains) == 2 and args.streams == 2) else None
     streams = [sh, side.cuda_stream if side is not None else sh]
-    x_all = None
+    x_all = gather_scratch = None
+    if gather and use_dist:   # the exchange step's buffers are the caller's: nothing is allocated inside a timed step
+        x_all = torch.empty((B_total, families[0][1], 1), dtype=F64, device=dev)
+        rows = parallel.gather_scratch_rows(B_total, world)
+        gather_scratch = torch.empty((rows, families[0][1], 1), dtype=F64, device=dev) if rows else None
 
     def step(s=0):
         """One pass of the hot path over this rank's batch (all chains; set s of each)."""
@@ -286,6 +304,8 @@ def measure(cfg, args, ctx, light=False):
             dist.barrier()
         torch.cuda.synchronize()
 
+    enq, enq_log = [0.0], []
+
     def region(fn, k):
         """Exactly k calls of fn between two barrier+synchronize brackets; MAX over the ranks, seconds.  The clock
         stops when this rank's work has completed (synchronize); the closing barrier follows and the MAX over the
@@ -295,6 +315,7 @@ def measure(cfg, args, ctx, light=False):
         t0 = time.perf_counter()
         for _ in range(k):
             fn()
+        enq[0] = time.perf_counter() - t0   # the host is done enqueueing here (no synchronise yet): host-bound iff ~ el
         drain()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
@@ -303,12 +324,16 @@ def measure(cfg, args, ctx, light=False):
             tm = torch.tensor([el], dtype=F64, device=dev)
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             el = float(tm.item())
+        enq_log.append((el, enq[0], k))
         return el
 
     def step_and_gather_serial():
         nonlocal x_all
         step()
-        x_all = parallel.gather_batch(chains[0].sets[0]["x"], B_total) if use_dist else chains[0].sets[0]["x"]
+        if use_dist:
+            parallel.gather_batch(chains[0].sets[0]["x"], B_total, out=x_all, scratch=gather_scratch)
+        else:
+            x_all = chains[0].sets[0]["x"]
 
     def step_and_gather():
         """The path's one exchange step where it belongs: x is complete after the FORWARD, so its all-gather (RCCL's own
@@ -319,11 +344,10 @@ def measure(cfg, args, ctx, light=False):
         if not use_dist:
             return step_and_gather_serial()
         chains[0].launch(0, sh)
-        x_all, work = parallel.gather_batch(chains[0].sets[0]["x"], B_total, async_op=True)
+        _, work = parallel.gather_batch(chains[0].sets[0]["x"], B_total, async_op=True, out=x_all, scratch=gather_scratch)
         for w in range(1, len(chains[0].names)):
             chains[0].launch(w, sh)
-        if work is not None:
-            work.wait()
+        work.wait()
 
     timed = step_and_gather if gather else step
 
@@ -334,15 +358,27 @@ def measure(cfg, args, ctx, light=False):
     # ---- timed regions: R times EXACTLY K steps
     times = sorted(region(timed, steps) for _ in range(repeats))
     elapsed = times[len(times) // 2]
+    host_enqueue_us = sorted(e / k for _, e, k in enq_log)[len(enq_log) // 2] * 1e6
+    # How much of a K-step region is fill / drain / synchronise latency rather than steady state?  The same step in
+    # regions of 5K steps: T(K) = F + s K from the two medians (the driver times --steps 20, the
+    # builder's profiles used to time --steps 100; the fixed ~90 us of a region are 8 % of the former, 1.6 % of the latter)
+    region_fit = None
+    if not light and not gather:
+        kl = 5 * steps
+        tl = sorted(region(timed, kl) for _ in range(3))[1]
+        s_fit = (tl - elapsed) / (kl - steps)
+        region_fit = {"long_region_steps": kl, "ms_per_step_long_region": tl / kl * 1e3,
+                      "us_per_step_steady_state": s_fit * 1e6, "region_fixed_us": (elapsed - steps * s_fit) * 1e6}
     if gather and use_dist:
-        assert x_all.shape[0] == B_total
+        torch.cuda.synchronize()
+        lo_r, hi_r = parallel.shard_bounds(B_total, rank, world)
+        assert x_all.shape[0] == B_total and torch.equal(x_all[lo_r:hi_r], chains[0].sets[0]["x"]), "all-gather of x"
     extra = {}
     if gather and use_dist:   # the same regions with the gather behind the whole step instead of beside the backward
         tg = sorted(region(step_and_gather_serial, steps) for _ in range(max(repeats // 2, 1)))
         extra["gather_after_backward"] = {"ms_per_step": tg[len(tg) // 2] / steps * 1e3,
                                           "value": B_total * steps / tg[len(tg) // 2],
-                                          "note": "forward, backward, then the all-gather of x (serialised); the headline "
-                                                  "value overlaps the all-gather with the backward"}
+                                          "note": "all-gather of x serialised behind the backward"}
     if gather:   # the same regions without the exchange step
         tn = sorted(region(step, steps) for _ in range(max(repeats // 2, 1)))
         extra["without_gather"] = {"ms_per_step": tn[len(tn) // 2] / steps * 1e3,
@@ -355,8 +391,7 @@ def measure(cfg, args, ctx, light=False):
         side = save
         extra["single_stream"] = {"ms_per_step": t1[1] / steps * 1e3,
                                   "value_this_rank": sum(c.B for c in chains) * steps / t1[1],
-                                  "note": "all launches of a step on one stream (what one problem family alone sees); "
-                                          "the figure to compare across boxes and rounds next to the two-stream one"}
+                                  "note": "all launches of a step on one stream"}
 
     # ---- cold variant: rotate input AND output sets so that a step never finds its data in the 256 MiB Infinity Cache
     if cfg in (0, 2, 3) and not args.no_cold and world == 1 and not light:
@@ -377,28 +412,46 @@ def measure(cfg, args, ctx, light=False):
         chains = hot
         extra["cold"] = {"sets": nsets, "bytes_per_set": per_set, "ms_per_step": tc[len(tc) // 2] / steps * 1e3,
                          "value": sum(c.B for c in chains) * steps / tc[len(tc) // 2],
-                         "note": "same step, inputs and outputs rotating over `sets` distinct buffers (> 256 MiB in "
-                                 "total): nothing is served from the Infinity Cache"}
+                         "note": "inputs and outputs rotate over `sets` distinct buffers (> 256 MiB in total)"}
         del cold
         torch.cuda.empty_cache()
 
     # ---- roofline pass: HIP events around every launch of the step, on the launch stream.  The work-list launch
     # behind an all-diagonal DQQ_P_AUTO batch is switched off here so that each bracket holds exactly one kernel.
     all_diag = all(c.structure == "diag" for c in chains)
-    if all_diag:
-        _capi.set_option("auto_fallback", 0)
     nrep = 5 if cfg == 5 else (20 if cfg == 4 else (30 if light else 100))
     launches = [(c, w) for c in chains for w in range(len(c.names))]
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in launches]
           for _ in range(nrep)]
     torch.cuda.synchronize()
-    for r in range(nrep):
-        for j, (c, w) in enumerate(launches):
-            ev[r][j][0].record(main_stream)
-            c.launch(w, sh)
-            ev[r][j][1].record(main_stream)
-    torch.cuda.synchronize()
-    _capi.set_option("auto_fallback", 1)
+    try:
+        if all_diag:
+            _capi.set_option("auto_fallback", 0)   # process-wide: restored whatever happens below
+        for r in range(nrep):
+            for j, (c, w) in enumerate(launches):
+                ev[r][j][0].record(main_stream)
+                c.launch(w, sh)
+                ev[r][j][1].record(main_stream)
+        torch.cuda.synchronize()
+    finally:
+        _capi.set_option("auto_fallback", 1)
+    # the empty work-list launch behind every DQQ_P_AUTO backward of a diagonal batch, bracketed on its own: with and
+    # without it, per backward launch (rocprofv3 read 5.5 us where DESIGN said 2.5)
+    drain_us = None
+    if all_diag and any(c.backward for c in chains) and not light:
+        drain_us = {}
+        for c in chains:
+            if not c.backward:
+                continue
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c.launch(1, sh)
+            torch.cuda.synchronize()
+            e0.record(main_stream)
+            for _ in range(50):
+                c.launch(1, sh)
+            e1.record(main_stream)
+            torch.cuda.synchronize()
+            drain_us[c.names[1]] = e0.elapsed_time(e1) / 50 * 1e3
     kernels = {}
     for j, (c, w) in enumerate(launches):
         ts = sorted(ev[r][j][0].elapsed_time(ev[r][j][1]) for r in range(nrep))
@@ -410,18 +463,35 @@ def measure(cfg, args, ctx, light=False):
                                "moved_bytes_per_launch": mb, "moved_GBps": mb / (mean_ms * 1e-3) / 1e9}
     dom = max(kernels, key=lambda k: kernels[k]["mean_us"])
     step_algo = sum(k["algo_bytes_per_launch"] for k in kernels.values())
+    step_moved = sum(k["moved_bytes_per_launch"] for k in kernels.values())
+    step_s = elapsed / steps
     roofline = {
         "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["algo_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": kernels[dom]["algo_GBps"] / HBM_PEAK_GBS, "traffic": None,
-        "moved_GBps": kernels[dom]["moved_GBps"], "frac_vs_measured_copy_bw_6290": kernels[dom]["algo_GBps"] / 6290.0,
+        "moved_GBps": kernels[dom]["moved_GBps"], "moved_frac": kernels[dom]["moved_GBps"] / HBM_PEAK_GBS,
+        "frac_vs_measured_copy_bw_6290": kernels[dom]["algo_GBps"] / 6290.0,
         "step_algo_GBps_kernels_alone": step_algo / (sum(k["mean_us"] for k in kernels.values()) * 1e-6) / 1e9,
-        "step_algo_GBps_as_timed": step_algo / (elapsed / steps) / 1e9,
-        "step_frac_as_timed": step_algo / (elapsed / steps) / 1e9 / HBM_PEAK_GBS,
+        "step_algo_GBps_as_timed": step_algo / step_s / 1e9,
+        "step_frac_as_timed": step_algo / step_s / 1e9 / HBM_PEAK_GBS,
+        # the same with the bytes that really move (the backward takes the forward's verified diagonal instead of P):
+        # the physical figure -- the algorithmic one can exceed 1
+        "step_moved_GBps_as_timed": step_moved / step_s / 1e9,
+        "step_moved_frac": step_moved / step_s / 1e9 / HBM_PEAK_GBS,
         "timing": "HIP events on the launch stream around each launch, mean of %d" % nrep,
+        # flat scalars: the driver's record keeps the scalar entries of `roofline` and `config`
+        "host_enqueue_us_per_step": host_enqueue_us,
+        "kernels_sum_us": sum(k["mean_us"] for k in kernels.values()),
     }
+    for k, v in kernels.items():
+        roofline["kernel_us_" + k] = v["mean_us"]
+    if drain_us:
+        for k, v in drain_us.items():
+            roofline["kernel_us_" + k + "_with_empty_drain"] = v
+    if region_fit:
+        roofline.update(region_fit)
     # HBM traffic and VALU instruction counts are PMC measurements of a separate rocprofv3 run (tools/profile.sh):
     # quoted from the committed summary of the same workload, with its provenance, never measured by this run
-    tag = {0: "", 2: "_cfg2", 3: "_cfg3", 4: "_cfg4", 5: "_cfg5", 6: "_cfg6"}[cfg]
+    tag = {0: "", 2: "_cfg2", 3: "_cfg3", 4: "_cfg4", 5: "_cfg5", 6: "_cfg6", 7: "_cfg7"}[cfg]
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest%s.json" % tag)
     if os.path.exists(pmc_path):
         try:
@@ -438,8 +508,13 @@ def measure(cfg, args, ctx, light=False):
                     "bound": "fp64_valu_issue", "valu_insts_per_launch": pmc["SQ_INSTS_VALU"],
                     "issue_floor_ns_per_wave_inst": 2.08, "floor_us": floor_us,
                     "frac": floor_us / kernels[dom]["mean_us"], "source": roofline["traffic_source"]}
+                roofline["fp64_valu_issue_floor_us"] = floor_us
+                roofline["fp64_valu_issue_frac"] = floor_us / kernels[dom]["mean_us"]
                 if floor_us / kernels[dom]["mean_us"] > roofline["frac"]:
                     roofline["binding"] = "fp64_valu_issue"
+            for k in ("valu_lane_utilisation", "SQ_WAIT_INST_ANY_frac", "SQ_WAIT_ANY_frac"):
+                if k in pmc:
+                    roofline["pmc_" + k] = pmc[k]
         except Exception:
             pass
     if cfg == 5:
@@ -460,6 +535,12 @@ def measure(cfg, args, ctx, light=False):
             "note": "this config is FP64-compute-bound (SURVEY.md 8(d)): the HBM fraction above is capped at ~30-55 %",
         }
         roofline["binding"] = "fp64"
+        roofline["fp64_frac"] = roofline["fp64"]["frac"]
+        roofline["fp64_TFLOPs"] = roofline["fp64"]["achieved"][dom]
+    if "single_stream" in extra:
+        roofline["single_stream_ms_per_step"] = extra["single_stream"]["ms_per_step"]
+    if "cold" in extra:
+        roofline["cold_ms_per_step"] = extra["cold"]["ms_per_step"]
 
     if rank != 0:
         del chains
@@ -478,7 +559,8 @@ def measure(cfg, args, ctx, light=False):
             "baseline_config": cfg if cfg else "2'+3 (headline)",
             "B_total": B_total if scaling == "strong" else sum(c.B for c in chains) * world,
             "B_this_rank": [c.B for c in chains], "N": [c.N for c in chains],
-            "p_layout": "auto (off-diagonals verified in-kernel; non-diagonal tiles go to the general kernel)",
+            "p_layout": ("dense (declared)" if chains[0].layout == 1 else
+                         "auto (off-diagonals verified in-kernel; non-diagonal tiles go to the general kernel)"),
             "launch": "eager, one C-ABI call per pass" + (", the two families on two streams" if side is not None else ""),
             "sharding": ("batch split over the ranks, no data-path collective; RCCL all-gather of x per step, issued after the forward and overlapped with the backward"
                          if gather else ("batch shards, no collective" if world > 1 else "single GPU")),
@@ -486,8 +568,7 @@ def measure(cfg, args, ctx, light=False):
         },
         "repeats": {"R": len(times), "ms_per_step_median": elapsed / steps * 1e3, "ms_per_step_min": times[0] / steps * 1e3,
                     "ms_per_step_max": times[-1] / steps * 1e3,
-                    "note": "R regions of exactly `steps` steps, barrier + synchronize on both sides, MAX over ranks; "
-                            "value / ms_per_step are the median region"},
+                    "note": "R regions of exactly `steps` steps; value / ms_per_step are the median region"},
         "roofline": roofline,
         "kernels": kernels,
         "per_gpu_value": units_per_step * steps / elapsed / world,
@@ -519,51 +600,50 @@ def measure(cfg, args, ctx, light=False):
 
 
 def condensed(rec):
-    """A per_config sub-record: what VERDICT r2 #4 asks to be driver-measured for every BASELINE config."""
+    """A per_config sub-record: what VERDICT r2 #4 / r3 #7 ask to be driver-measured for every BASELINE config."""
     rl = rec["roofline"]
-    out = {"workload": rec["config"]["workload"], "ms_per_step": rec["ms_per_step"], "value": rec["value"],
-           "unit": rec["unit"], "steps": rec["steps"], "regions": rec["repeats"]["R"],
+    out = {"workload": rec["config"]["workload"][:90], "ms_per_step": rec["ms_per_step"], "value": rec["value"],
+           "steps": rec["steps"], "regions": rec["repeats"]["R"],
            "ms_per_step_min_max": [rec["repeats"]["ms_per_step_min"], rec["repeats"]["ms_per_step_max"]],
-           "dominant_kernel": rl["kernel"], "dominant_kernel_us": rec["kernels"][rl["kernel"]]["mean_us"],
-           "kernels_us": {k: v["mean_us"] for k, v in rec["kernels"].items()},
+           "dominant_kernel": rl["kernel"],
+           "kernels_us": {k: round(v["mean_us"], 2) for k, v in rec["kernels"].items()},
+           "host_enqueue_us_per_step": rl["host_enqueue_us_per_step"],
            "roofline": {"bound": rl.get("binding", "hbm"), "hbm_frac": rl["frac"], "hbm_achieved_GBps": rl["achieved"],
-                        "step_hbm_frac_as_timed": rl["step_frac_as_timed"], "traffic": rl.get("traffic")}}
-    if "fp64" in rl:
-        out["roofline"]["fp64_frac"] = rl["fp64"]["frac"]
-        out["roofline"]["fp64_TFLOPs"] = rl["fp64"]["achieved"]
-    if "fp64_valu_issue" in rl:
-        out["roofline"]["fp64_valu_issue_frac"] = rl["fp64_valu_issue"]["frac"]
-    for k in ("without_gather", "gather_after_backward", "cpu_baseline", "parity_max_abs_err_vs_oracle_sample", "gpu_over_cpu_all_cores"):
+                        "moved_GBps": rl["moved_GBps"], "moved_frac": rl["moved_frac"],
+                        "step_hbm_frac_as_timed": rl["step_frac_as_timed"], "step_moved_frac": rl["step_moved_frac"],
+                        "traffic": rl.get("traffic")}}
+    for k in ("fp64_frac", "fp64_TFLOPs", "fp64_valu_issue_frac", "pmc_valu_lane_utilisation"):
+        if k in rl:
+            out["roofline"][k] = rl[k]
+    for k in ("without_gather", "gather_after_backward", "parity_max_abs_err_vs_oracle_sample", "gpu_over_cpu_all_cores"):
         if k in rec:
             out[k] = rec[k]
+    if "cpu_baseline" in rec:
+        out["cpu_baseline"] = {k: rec["cpu_baseline"][k] for k in ("value", "cores", "kind", "single_thread_value")}
+    return out
+
+
+def flat_summary(prefix, rec):
+    """Scalar entries for `config` (the driver's record keeps the scalars of `config` and `roofline`)."""
+    rl = rec["roofline"]
+    out = {prefix + "_ms_per_step": rec["ms_per_step"], prefix + "_hbm_frac": rl["hbm_frac"],
+           prefix + "_moved_frac": rl["moved_frac"], prefix + "_step_moved_frac": rl["step_moved_frac"]}
+    for k, v in rec["kernels_us"].items():
+        out[prefix + "_us_" + k] = v
+    if "fp64_frac" in rl:
+        out[prefix + "_fp64_frac"] = rl["fp64_frac"]
+    if "cpu_baseline" in rec:
+        out[prefix + "_cpu_solves_per_s"] = rec["cpu_baseline"]["value"]
     return out
 
 
 def dense_p_record(args, ctx):
     """Dense 8x8 P (what a real contact problem presents) at the bench's batch size, QCQP forward + backward through
-    DQQ_P_AUTO (what QCQPFn2 passes) against DQQ_P_DENSE (the cliff must not come back)."""
-    dev = ctx["dev"]
-    sh = torch.cuda.current_stream().cuda_stream
-    rec = {}
-    for name, layout in (("auto", 0), ("dense", 1)):
-        c = Chain("qcqp", 65536, 8, "dense", True, dev, 4242, layout=layout)
-        for _ in range(3):
-            c.run(sh)
-        torch.cuda.synchronize()
-        ts = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            for _ in range(10):
-                c.run(sh)
-            torch.cuda.synchronize()
-            ts.append((time.perf_counter() - t0) / 10)
-        rec[name + "_ms_per_fwd_bwd"] = sorted(ts)[1] * 1e3
-        if layout == 0 and not args.no_check:
-            rec["parity_max_abs_err_vs_oracle_sample"] = c.check(1024)
-        del c
-        torch.cuda.empty_cache()
+    DQQ_P_AUTO (what QCQPFn2 passes) and DQQ_P_DENSE: full sub-records (per-launch durations, roofline, CPU baseline;
+    VERDICT r3 #4), and their ratio (the cliff must not come back)."""
+    rec = {"auto": condensed(measure(6, args, ctx, light=True)), "dense": condensed(measure(7, args, ctx, light=True))}
+    rec["auto_ms_per_fwd_bwd"], rec["dense_ms_per_fwd_bwd"] = rec["auto"]["ms_per_step"], rec["dense"]["ms_per_step"]
     rec["auto_over_dense"] = rec["auto_ms_per_fwd_bwd"] / rec["dense_ms_per_fwd_bwd"]
-    rec["workload"] = "B=65536 N=8 QCQP, P = S S^T/8 + 0.1 I (dense), forward+backward, one stream, median of 3 x 10 passes"
     return rec
 
 
@@ -615,6 +695,18 @@ def survey_extras_record(args, ctx):
     rec["stress_p_u(0,1)_qp_fwd"] = {"ms_per_call": t * 1e3, "solves_per_s": B / t, "iterations": stats(it_s)}
     t0 = timed(lambda: ops.qp_forward(P, q, EPS, MAX_ITER, out=xb))
     rec["same_call_p_u(0.1,1.1)_qp_fwd"] = {"ms_per_call": t0 * 1e3, "solves_per_s": B / t0}
+    # the workload of the reference's only published figure (test_script.py:91-123): P = diag(exp(U(-10,10))), q ~
+    # U(-1,1), l_n, mu ~ U(0,1), eps 1e-10, max_iter 1e6 -- heavy-tailed iteration counts; here at B = 65536
+    pf = torch.exp(r(B, N) * 20 - 10)
+    Pf = torch.diag_embed(pf).contiguous()
+    _, it_fq = ops.qp_forward(Pf, q, 1e-10, 1000000, return_iters=True)
+    _, it_fc = ops.qcqp_forward(Pf, q, l_n, mu, 1e-10, 1000000, return_iters=True)
+    tq = timed(lambda: ops.qp_forward(Pf, q, 1e-10, 1000000, out=xb), reps=5)
+    tcq = timed(lambda: ops.qcqp_forward(Pf, q, l_n, mu, 1e-10, 1000000, out=xb), reps=5)
+    rec["reference_figure_workload"] = {"qp_fwd_ms": tq * 1e3, "qcqp_fwd_ms": tcq * 1e3, "qp_iterations": stats(it_fq),
+                                        "qcqp_iterations": stats(it_fc),
+                                        "note": "P = diag(exp(U(-10,10))), eps 1e-10 (reference test_script.py:91-123), B=65536"}
+    del Pf
     # compact diagonal layout: P handed over as (B,N)
     tc = timed(lambda: ops.qp_forward(p, q, EPS, MAX_ITER, layout=2, out=xb))
     xc = ops.qp_forward(p, q, EPS, MAX_ITER, layout=2)
@@ -631,7 +723,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, default=None, choices=(0, 2, 3, 4, 5),
+    ap.add_argument("--config", type=int, default=None, choices=(0, 2, 3, 4, 5, 6, 7),
                     help="BASELINE.json configs entry (1-based); 0 = the headline step (configs 2'+3).  Default: the "
                          "headline on one GPU; with WORLD_SIZE > 1, configs[3] (the batch split over the ranks + RCCL "
                          "all-gather) with the weak-scaling headline as a sub-record")
@@ -697,18 +789,21 @@ def main():
             per = {}
             for cfg in (2, 3, 4, 5):
                 per["config_%d" % cfg] = condensed(measure(cfg, args, ctx, light=True))
+                out["config"].update(flat_summary("cfg%d" % cfg, per["config_%d" % cfg]))
             out["per_config"] = per
-            out["per_config_note"] = "BASELINE.json configs 2-5 (1-based) measured by THIS run: 3 regions each, HIP-event " \
-                                     "kernel durations, roofline fractions, CPU baseline on a bounded sample; config_4 is " \
-                                     "the whole B=262144 batch on this one GPU"
+            out["per_config_note"] = "BASELINE.json configs 2-5 (1-based) measured by THIS run, 3 regions each; config_4 " \
+                                     "is the whole B=262144 batch on this one GPU"
             out["dense_p_n8"] = dense_p_record(args, ctx)
+            out["config"].update(flat_summary("dense8_auto", out["dense_p_n8"]["auto"]))
+            out["config"].update(flat_summary("dense8_dense", out["dense_p_n8"]["dense"]))
             out["survey_8d_extras"] = survey_extras_record(args, ctx)
+            ex = out["survey_8d_extras"]
+            out["config"].update({"stress_p_u01_qp_fwd_ms": ex["stress_p_u(0,1)_qp_fwd"]["ms_per_call"],
+                                  "ref_figure_qp_fwd_ms": ex["reference_figure_workload"]["qp_fwd_ms"],
+                                  "ref_figure_qcqp_fwd_ms": ex["reference_figure_workload"]["qcqp_fwd_ms"]})
     if rank == 0:
-        out["scaling_note"] = ("two curves can be read across the driver's N = 1, 2, 4, 8 lines: STRONG scaling of configs[3] "
-                               "(B=262144 N=32 split over the ranks) = `per_config.config_4` of the N=1 line, then `value` of "
-                               "the N>1 lines; WEAK scaling of the headline step = `value` of the N=1 line, then "
-                               "`weak_headline.value` of the N>1 lines.  `value` itself changes workload between N=1 "
-                               "(headline) and N>1 (configs[3]), as BASELINE.json names them")
+        out["scaling_note"] = ("N=1: `value` = headline (weak), strong scaling of configs[3] = per_config.config_4; N>1: `value` = "
+                               "configs[3] split over the ranks (strong), weak headline = weak_headline.value")
         out["environment"] = gpu_environment()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:

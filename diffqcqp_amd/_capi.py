@@ -111,6 +111,10 @@ def check(rc, what):
 
 def set_option(name, value):
     check(lib().dqq_set_option(name.encode(), int(value)), "dqq_set_option(%s)" % name)
+    import sys
+    ops = sys.modules.get(__package__ + ".ops")
+    if ops is not None:
+        ops._need_cache.clear()   # dqq_scratch_bytes follows the knobs (include/diffqcqp_hip.h)
 
 
 def get_option(name):

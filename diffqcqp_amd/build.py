@@ -27,11 +27,9 @@ UNITS = {
     "dense.hip": ["-ffp-contract=off"],
     "general_any.hip": ["-ffp-contract=off"],
     "bwd_small.hip": ["-ffp-contract=off"],
-    "dense_block.hip": ["-ffp-contract=fast"],
     "dense_wave64.hip": ["-ffp-contract=fast"],
     "bwd_wave_qcqp.hip": ["-ffp-contract=off"],
     "bwd_wave_qcqp_big.hip": ["-ffp-contract=off"],
-    "bwd_block.hip": ["-ffp-contract=off"],
     "fwd_lane_dense.hip": ["-ffp-contract=fast"],
     "fwd_small.hip": ["-ffp-contract=fast"],
     "capi.hip": ["-ffp-contract=off", "-fvisibility=default"],
@@ -58,16 +56,42 @@ def _flag_stamp():
     return " ".join(COMMON) + " | " + os.environ.get("DQQ_EXTRA_FLAGS", "")
 
 
-def needs_build():
-    if not os.path.exists(LIB) or not os.path.exists(PYMOD):
-        return True
+def _read_stamp():
+    """(flag line, pybind line) of the last build; the second line records whether the pybind11 module was built
+    ("pybind11: ok") or why not -- a host without pybind11 must not rebuild the HIP units on every call."""
     try:
-        if open(STAMP).read() != _flag_stamp():
-            return True   # built with other flags (e.g. an experiment's -D...): never reuse it silently
+        lines = open(STAMP).read().split("\n")
     except OSError:
+        return None, None
+    return lines[0], (lines[1] if len(lines) > 1 else None)
+
+
+def needs_build():
+    """Does the C-ABI LIBRARY have to be rebuilt?  (The pybind11 module is optional and has its own test,
+    `_pybind_stale`: its absence alone never recompiles the HIP units.)"""
+    if not os.path.exists(LIB):
         return True
+    flags, _ = _read_stamp()
+    if flags != _flag_stamp():
+        return True   # built with other flags (e.g. an experiment's -D...): never reuse it silently
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(p) > t for p in _sources() + [os.path.abspath(__file__)])
+
+
+def _pybind_stale():
+    """The module must be (re)built when it is older than what it binds: its source, the header, the library.  A
+    recorded failure ("pybind11: unavailable ...") is not retried until one of those changes."""
+    deps = [os.path.join(CSRC, "pybind_module.cpp"), os.path.join(INCLUDE, "diffqcqp_hip.h"), LIB]
+    newest = max(os.path.getmtime(p) for p in deps)
+    if os.path.exists(PYMOD):
+        return os.path.getmtime(PYMOD) < newest
+    _, note = _read_stamp()
+    if note is not None and note.startswith("pybind11: unavailable"):
+        try:
+            return os.path.getmtime(STAMP) < newest
+        except OSError:
+            return True
+    return True
 
 
 def _compile(unit, flags, objdir, verbose):
@@ -83,6 +107,8 @@ def _compile(unit, flags, objdir, verbose):
 def build(force=False, verbose=False):
     """Compile and link; returns the library path."""
     if not force and not needs_build():
+        if _pybind_stale():
+            _write_stamp(_build_pybind(verbose))
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
@@ -93,20 +119,29 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    _build_pybind(verbose)
-    with open(STAMP, "w") as f:
-        f.write(_flag_stamp())
+    _write_stamp(_build_pybind(verbose))
     return LIB
+
+
+def _write_stamp(pybind_note):
+    with open(STAMP, "w") as f:
+        f.write(_flag_stamp() + "\n" + pybind_note)
 
 
 def _build_pybind(verbose=False):
     """The pybind11 module `_dqq` (host-only C++, g++): every C-ABI function under its own name.  Optional: without
-    pybind11 headers `_capi.py` binds the same symbols with ctypes."""
+    pybind11 headers `_capi.py` binds the same symbols with ctypes.  Returns the line for the stamp file.  The old
+    module is deleted BEFORE the attempt: after a C-ABI change a failed rebuild must fall back to ctypes, never to a
+    stale module with another argument order."""
+    try:
+        os.remove(PYMOD)
+    except OSError:
+        pass
     try:
         import pybind11
         import sysconfig
     except ImportError:
-        return None
+        return "pybind11: unavailable (no pybind11 headers); _capi.py binds the C ABI with ctypes"
     cxx = os.environ.get("CXX", "g++")
     cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-I", INCLUDE, "-I", pybind11.get_include(),
            "-I", sysconfig.get_paths()["include"], os.path.join(CSRC, "pybind_module.cpp"), "-o", PYMOD,
@@ -115,9 +150,13 @@ def _build_pybind(verbose=False):
         print(" ".join(cmd), flush=True)
     try:
         subprocess.check_call(cmd)
-    except (OSError, subprocess.CalledProcessError):
-        return None
-    return PYMOD
+    except (OSError, subprocess.CalledProcessError) as e:
+        try:
+            os.remove(PYMOD)
+        except OSError:
+            pass
+        return "pybind11: unavailable (%s failed: %s); _capi.py binds the C ABI with ctypes" % (cxx, type(e).__name__)
+    return "pybind11: ok"
 
 
 if __name__ == "__main__":

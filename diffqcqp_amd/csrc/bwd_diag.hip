@@ -72,6 +72,8 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : (KIND == 1 ? 4 :
     }
     constexpr bool AGG = !FUSE && WPB > 1; // queue non-diagonal tiles with ONE atomic per workgroup (see launch.h)
     __shared__ int s_cnt[2];
+    // (capacity of the segmented work-list: one tile per wave, grid = ceil(tiles / WPB), <= 256 problems per workgroup)
+    static_assert(!worklist_segmented(N) || T * WPB <= 256, "segmented work-list: at most 256 problems per workgroup");
     if (layout == DQQ_P_DIAG) {
         pv = valid ? *reinterpret_cast<const double2*>(P + first * N + 2 * lane) : make_double2(1.0, 1.0);
     } else {

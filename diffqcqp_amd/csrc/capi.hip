@@ -7,7 +7,6 @@
 #include "launch.h"
 
 namespace dqq {
-extern std::atomic<int> g_dense_block;
 extern std::atomic<int> g_fwd_compact;
 extern std::atomic<int> g_fwd_respread;
 extern std::atomic<int> g_dense_wave64;
@@ -16,7 +15,7 @@ extern std::atomic<int> g_lane_defer;
 extern std::atomic<int> g_dense_teams;
 extern std::atomic<int> g_small_bwd;
 extern std::atomic<int> g_small_fwd;
-extern std::atomic<int> g_block_bwd;
+extern std::atomic<int> g_wave_qcqp_bwd;
 }
 
 namespace {
@@ -34,14 +33,13 @@ Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback"
                       {"fuse_fallback", &g_fuse},
                       {"fwd_compact", &dqq::g_fwd_compact},
                       {"fwd_respread", &dqq::g_fwd_respread},
-                      {"dense_block", &dqq::g_dense_block},
                       {"dense_wave64", &dqq::g_dense_wave64},
                       {"lane_dense", &dqq::g_lane_dense},
                       {"lane_defer", &dqq::g_lane_defer},
                       {"dense_teams", &dqq::g_dense_teams},
                       {"small_bwd", &dqq::g_small_bwd},
                       {"small_fwd", &dqq::g_small_fwd},
-                      {"block_bwd", &dqq::g_block_bwd}};
+                      {"wave_qcqp_bwd", &dqq::g_wave_qcqp_bwd}};
 
 int check_common(int64_t B, int N, int p_layout, bool qcqp)
 {
@@ -91,7 +89,7 @@ size_t dqq_scratch_bytes(int kind, int pass, int N, int64_t B)
     return dqq::bwd_needs_any(kind, N) ? dqq::any_scratch_bytes(kind, true, N, (long)B) : 0;
 }
 
-int dqq_max_n(int kind) { return dqq::dense_max_n(kind); }
+int dqq_max_n(int kind) { return dqq::public_max_n(kind); }
 
 const char* dqq_version(void) { return "diffqcqp_hip 0.1.0 gfx950"; }
 

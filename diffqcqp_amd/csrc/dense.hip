@@ -8,12 +8,11 @@
 
 namespace dqq {
 
-std::atomic<int> g_dense_block{1}; // 0: always the wave-per-problem kernel (option "dense_block")
-std::atomic<int> g_dense_wave64{1}; // 0: never the register-resident wave-per-problem forward of N = 64 (option "dense_wave64")
+std::atomic<int> g_dense_wave64{1}; // 0: never the register-resident wave-per-problem forward / QP backward of 16 < N <= 64 (option "dense_wave64")
+std::atomic<int> g_wave_qcqp_bwd{1}; // 0: never the register-resident QCQP backward of 16 < N <= 64 (option "wave_qcqp_bwd")
 std::atomic<int> g_lane_dense{1};  // 0: never the lane-per-problem kernel of N <= 8 (option "lane_dense")
 std::atomic<int> g_dense_teams{1}; // 0: backward always one problem per wave (option "dense_teams")
 std::atomic<int> g_small_fwd{1};   // 0: never the team-per-problem forward of N = 10..16 (option "small_fwd")
-std::atomic<int> g_block_bwd{0};   // 1: workgroup QCQP / box backward also where the wave kernel would do (option "block_bwd")
 std::atomic<int> g_small_bwd{1};   // 0: never the statically sized team backward of N <= 8 (option "small_bwd")
 
 
@@ -72,7 +71,21 @@ int dense_max_n(int kind)
     return kDenseMaxRows;
 }
 
-// what the general path can take at all (include/diffqcqp_hip.h: dqq_max_n)
+// Does a backward of this size reach the global-memory kernels, as routed NOW?  (QCQP 42 < N <= 64 only with the
+// register-resident kernels switched off.)  dqq_scratch_bytes / dqq_max_n report exactly this, so that the scratch a call
+// demands is the scratch the kernels it launches use (the default route of QCQP 42 < N <= 64 demanded 46 MB it
+// never touched).
+bool bwd_uses_any(int kind, int N)
+{
+    if (kind == kKindQCQP && N > 16 && N <= 64 && g_wave_qcqp_bwd.load() != 0) return false;
+    return N > dense_max_n(kind == kKindQP ? 0 : (kind == kKindBox ? 3 : 2));
+}
+int public_max_n(int kind)
+{
+    if (kind == 2 && g_wave_qcqp_bwd.load() != 0) return 64;
+    return dense_max_n(kind);
+}
+
 // what the general path can take at all: everything (beyond dqq_max_n: the global-memory kernels of general_any.hip)
 bool fwd_dense_supported(int kind, int N) { return N >= 1 && !(kind == kKindQCQP && (N & 1)); }
 bool bwd_dense_supported(int kind, int N) { return N >= 1 && !(kind == kKindQCQP && (N & 1)); }
@@ -122,14 +135,12 @@ static hipError_t launch_fwd_wave(const FwdArgs& a, bool use_worklist, hipStream
 hipError_t launch_fwd_dense(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
-    if (a.N > dense_max_n(kind == kKindQCQP ? 1 : 0)) return launch_fwd_any(kind, a, use_worklist, s);
+    if (fwd_needs_any(kind, a.N)) return launch_fwd_any(kind, a, use_worklist, s);
     if (fwd_lane_dense_supported(a.N) && g_lane_dense.load() != 0)
         return launch_fwd_lane_dense(kind, a, use_worklist, s);
     if (fwd_small_supported(a.N) && g_small_fwd.load() != 0) return launch_fwd_small(kind, a, use_worklist, s);
     if (fwd_dense_wave64_supported(a.N) && g_dense_wave64.load() != 0)
         return launch_fwd_dense_wave64(kind, a, use_worklist, s);
-    if (fwd_dense_block_supported(a.N) && g_dense_block.load() != 0)
-        return launch_fwd_dense_block(kind, a, use_worklist, s);
     switch (kind) {
     case 0: return launch_fwd_wave<0>(a, use_worklist, s);
     case 1: return launch_fwd_wave<1>(a, use_worklist, s);
@@ -178,18 +189,16 @@ hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipSt
     if (bwd_small_supported(kind, a.N) && g_small_bwd.load() != 0) return launch_bwd_small(kind, a, use_worklist, s);
     if (bwd_dense_wave64_supported(kind, a.N) && g_dense_wave64.load() != 0)
         return launch_bwd_dense_wave64(kind, a, use_worklist, s);
-    if (bwd_wave_qcqp_supported(kind, a.N) && g_dense_wave64.load() != 0) return launch_bwd_wave_qcqp(a, use_worklist, s);
-    if (bwd_wave_qcqp_big_supported(kind, a.N) && g_dense_wave64.load() != 0)
+    // QCQP, 16 < N <= 64: the register-resident block-Cholesky kernels re-associate the sums of these Tikhonov systems
+    // (cond(K) ~ 1e9: gradients within 5e-7 / 8e-6 of the reference-order evaluation, the evaluation-order noise of the
+    // reference's own formulas); option "wave_qcqp_bwd" = 0 selects the reference-order kernels instead
+    // (LDS wave kernel up to N = 42, global-memory kernel beyond: 1e-9, 10-30x slower).
+    if (bwd_wave_qcqp_supported(kind, a.N) && g_wave_qcqp_bwd.load() != 0) return launch_bwd_wave_qcqp(a, use_worklist, s);
+    if (bwd_wave_qcqp_big_supported(kind, a.N) && g_wave_qcqp_bwd.load() != 0)
         return launch_bwd_wave_qcqp_big(a, use_worklist, s);
-    if (bwd_dense_block_supported(kind, a.N) && g_dense_block.load() != 0)
-        return launch_bwd_dense_block(kind, a, use_worklist, s);
     // Systems beyond the wave kernel's 64 rows (QP N > 64, QCQP N > 42, box N > 21): the global-memory kernel in the
-    // reference's summation order.  The workgroup kernel on the matrix cores (QCQP N <= 64, box N <= 32) is several
-    // times faster but associates the sums of these Tikhonov systems differently -- cond(K) ~ 1e9 turns that into up
-    // to 1e-5 relative on a few problems -- so it is the opt-in (option "block_bwd" = 1), also where the wave
-    // kernel would do (QCQP 22 <= N <= 42, box 11 <= N <= 21).
-    if (bwd_block_sys_supported(kind, a.N) && g_block_bwd.load() != 0) return launch_bwd_block_sys(kind, a, use_worklist, s);
-    if (a.N > dense_max_n(kind == kKindQP ? 0 : (kind == kKindBox ? 3 : 2))) return launch_bwd_any(kind, a, use_worklist, s);
+    // reference's summation order.
+    if (bwd_uses_any(kind, a.N)) return launch_bwd_any(kind, a, use_worklist, s);
     if (kind == kKindBox) return launch_bwd_kind<2>(a, use_worklist, s);
     return kind == 0 ? launch_bwd_kind<0>(a, use_worklist, s) : launch_bwd_kind<1>(a, use_worklist, s);
 }

@@ -67,6 +67,9 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
     __shared__ __attribute__((aligned(16))) double s_diag[WPB][SMEM];
     constexpr bool AGG = !FUSE && WPB > 1; // queue non-diagonal tiles with ONE atomic per workgroup (see launch.h)
     __shared__ int s_cnt[2];
+    // the segmented work-list's capacity, kWsSegCap(B) = B/32 + 512 slots per segment, rests on: one tile per wave, the
+    // grid exactly ceil(tiles / WPB), at most 256 problems per workgroup
+    static_assert(!worklist_segmented(N) || PPW * WPB <= 256, "segmented work-list: at most 256 problems per workgroup");
     static_assert(!CMP || (WPB > 1 && KIND < 2), "compaction: QP / QCQP, several waves per workgroup");
     [[maybe_unused]] __shared__ typename std::conditional<CMP, CompactLds<(KIND == 1) ? 1 : 0, N / LPP>, int>::type s_cmp;
     [[maybe_unused]] bool wg_dense = false;

@@ -93,10 +93,10 @@ size_t any_scratch_bytes(int kind, bool backward, int N, long B)
     return sizeof(double) * (size_t)stride * any_grid(B, stride);
 }
 
-// The sizes beyond the register / LDS kernels of the general path (dqq_max_n): independent of the tuning knobs, so that
-// dqq_scratch_bytes is a function of (kind, pass, N, B) alone.
+// The sizes beyond the register / LDS kernels of the general path (dqq_max_n).  The backward's answer follows the route
+// (dense.hip: bwd_uses_any): the scratch a call demands is the scratch its kernels use.
 bool fwd_needs_any(int kind, int N) { return N > dense_max_n(kind == kKindQCQP ? 1 : 0); }
-bool bwd_needs_any(int kind, int N) { return N > dense_max_n(kind == kKindQP ? 0 : (kind == kKindBox ? 3 : 2)); }
+bool bwd_needs_any(int kind, int N) { return bwd_uses_any(kind, N); }
 
 template <typename Kern, typename... Args>
 static hipError_t launch_any(Kern kernel, size_t lds_bytes, long stride, long B, double* scratch, hipStream_t s,

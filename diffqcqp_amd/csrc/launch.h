@@ -30,7 +30,10 @@ constexpr int kWsSegCounts = kWsSubTickets + 32 * kWsSubStride; // entries queue
 constexpr int kWsSegNext = kWsSegCounts + 32 * kWsSubStride;   // next unclaimed entry of segment g (dynamic pick-up)
 constexpr int kWsEntries = kWsSegNext + 32 * kWsSubStride;
 constexpr bool worklist_segmented(int N) { return N >= 32; }
-// slots per segment: the workgroups of one residue class hold at most B/32 + 2 * (problems per workgroup <= 256) problems
+// slots per segment: the workgroups of one residue class hold at most B/32 + 2 * (problems per workgroup <= 256) problems.
+// The invariant behind it -- one tile per wave, a grid of exactly ceil(tiles / waves per workgroup) workgroups, at most
+// 256 problems per workgroup -- is static_assert'ed where the fast kernels push (fwd_diag.hip, bwd_diag.hip); a
+// persistent or grid-stride fast kernel would need another capacity.
 DQQ_HD constexpr long kWsSegCap(long B) { return B / 32 + 512; }
 // ints behind the header that hold entries: B for the plain list, 32 segments otherwise
 DQQ_HD constexpr long kWsEntryInts(long B) { return 32 * kWsSegCap(B); }
@@ -338,23 +341,19 @@ hipError_t launch_fwd_small(int kind, const FwdArgs& a, bool use_worklist, hipSt
 // wave-per-problem, register-resident forward for N = 64 (dense_wave64.hip); launch_fwd_dense routes to it
 bool fwd_dense_wave64_supported(int N);
 hipError_t launch_fwd_dense_wave64(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s);
-// workgroup-per-problem forward for N = 32, 64 (dense_block.hip); launch_fwd_dense routes to it
-bool fwd_dense_block_supported(int N);
-hipError_t launch_fwd_dense_block(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s);
 hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);
 // workgroup-per-problem kernels with the matrices in global memory: any N (general_any.hip)
 // bytes of scratch those kernels need for (kind, N, B): a slice per workgroup of a grid that depends on (N, B) only
 size_t any_scratch_bytes(int kind, bool backward, int N, long B);
-bool fwd_needs_any(int kind, int N); // does a call of this size reach them (whatever the tuning knobs say)
-bool bwd_needs_any(int kind, int N);
+bool fwd_needs_any(int kind, int N); // does a call of this size reach them
+bool bwd_needs_any(int kind, int N); // (as routed now: QCQP 42 < N <= 64 only with "wave_qcqp_bwd" = 0)
+bool bwd_uses_any(int kind, int N);
+int public_max_n(int kind);           // dqq_max_n
 hipError_t launch_fwd_any(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s);
 hipError_t launch_bwd_any(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);
 // statically sized team backward for even N <= 16, QP / QCQP (bwd_small.hip); launch_bwd_dense routes to it
 bool bwd_small_supported(int kind, int N);
 hipError_t launch_bwd_small(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);
-// workgroup-per-problem QCQP (N = 32, 64) / box QP (N = 16, 32) backward (bwd_block.hip)
-bool bwd_block_sys_supported(int kind, int N);
-hipError_t launch_bwd_block_sys(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);
 // wave-per-problem, register-resident QP backward for N = 64 (dense_wave64.hip); launch_bwd_dense routes to it
 bool bwd_dense_wave64_supported(int kind, int N);
 hipError_t launch_bwd_dense_wave64(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);
@@ -364,8 +363,5 @@ hipError_t launch_bwd_wave_qcqp(const BwdArgs& a, bool use_worklist, hipStream_t
 // the same for 32 < N <= 64 with the system matrix streamed (bwd_wave_qcqp_big.hip)
 bool bwd_wave_qcqp_big_supported(int kind, int N);
 hipError_t launch_bwd_wave_qcqp_big(const BwdArgs& a, bool use_worklist, hipStream_t s);
-// workgroup-per-problem QP backward for N = 32, 64 (dense_block.hip); launch_bwd_dense routes to it
-bool bwd_dense_block_supported(int kind, int N);
-hipError_t launch_bwd_dense_block(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);
 
 } // namespace dqq

@@ -15,10 +15,20 @@
 // Vectors live one element per lane (lane l = element l).
 #pragma once
 
-#include "block_core.h" // v4d, lane_bcast
 #include "common.h"
 
 namespace dqq {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// value held by lane `src` (wave-uniform) of the calling wave
+DQQ_D double lane_bcast(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
 
 // one tile-row T[0..3] streamed from memory: acc[tj] += T[tj][R] * (lane BC of the 16-lane row of x0)
 #define DQQ_FMAC_BCAST_TROW(T, R, BC)                                                                          \

@@ -3,6 +3,10 @@
 Inputs are float64 CUDA (ROCm) tensors in the reference's layouts -- P (B,N,N),
 q (B,N,1), l_n / mu (B,N/2,1) -- and every call runs on torch's current stream.
 torch is used here for device memory and streams only.
+
+Workspace: every op takes `workspace=` (ops.make_workspace); without it a per-(device, stream) cache is used.  HIP-graph
+capture: warm the capture stream up with one eager call first (or pass workspace=); a cached workspace that was live
+during a capture is never replaced or freed afterwards, so a replayed graph cannot write into recycled memory.
 """
 import torch
 
@@ -34,28 +38,71 @@ class _device_guard:
 
 
 _MAX_WORKSPACES = 16   # cached (device, stream) pairs; the least recently used one is dropped beyond that
+_pinned = []           # workspaces handed out while a stream capture was going on: a captured graph has their address
+                       # baked in, so they are never replaced, evicted or freed
+_need_cache = {}       # (kind, pas, N, B) -> bytes, cleared by set_option (dqq_scratch_bytes follows the tuning knobs)
 
 
-def _workspace(device, B, stream=None, kind=0, pas=0, N=8):
-    """Zero-initialised fallback work-list (+ the scratch of the global-memory kernels behind it, when (kind, pas, N)
-    needs any), cached per (device, stream); the kernels leave the work-list empty again
-    (include/diffqcqp_hip.h: dqq_workspace_bytes, dqq_scratch_bytes)."""
+def _capturing():
+    try:
+        return torch.cuda.is_current_stream_capturing()
+    except Exception:  # pragma: no cover
+        return False
+
+
+def workspace_bytes(B, kind=0, pas=0, N=8):
+    """Bytes of `workspace` a call needs: the work-list + whatever scratch the kernels of (kind, pas, N, B) use -- asked
+    of the library (dqq_workspace_bytes + dqq_scratch_bytes), never guessed here."""
+    key = (int(kind), int(pas), int(N), int(B))
+    need = _need_cache.get(key)
+    if need is None:
+        lib = _capi.lib()
+        need = lib.dqq_workspace_bytes(int(B)) + lib.dqq_scratch_bytes(*key)
+        _need_cache[key] = need
+    return need
+
+
+def make_workspace(device, B, kind=0, pas=0, N=8):
+    """A caller-owned workspace for the `workspace=` argument of the ops below (int32, zero-initialised work-list header,
+    uninitialised scratch behind it).  A caller that captures ops calls into a HIP graph should own one per stream and
+    keep it alive as long as the graph: the captured launches hold its address."""
+    lib = _capi.lib()
+    head = lib.dqq_workspace_bytes(int(B))
+    need = max(workspace_bytes(B, kind, pas, N), 4096)
+    ws = torch.empty((need + 3) // 4, dtype=torch.int32, device=device)
+    ws[: (head + 3) // 4].zero_()     # only the work-list must start zeroed; the scratch needs no initialisation
+    return ws
+
+
+def _workspace(device, B, stream=None, kind=0, pas=0, N=8, given=None):
+    """The work-list (+ the scratch of the global-memory kernels behind it, when (kind, pas, N) needs any): the
+    caller's (`given`, checked for size) or one cached per (device, stream); the kernels leave the work-list empty again
+    (include/diffqcqp_hip.h: dqq_workspace_bytes, dqq_scratch_bytes).
+    Lifetime rule of the cache: an entry is replaced when a larger call arrives and evicted beyond 16 streams -- except
+    entries that were handed out during a stream capture, which stay alive for the life of the process."""
+    need = workspace_bytes(B, kind, pas, N)
+    if given is not None:
+        if not (given.is_cuda and given.dtype is torch.int32 and given.is_contiguous() and given.numel() * 4 >= need):
+            raise ValueError("workspace must be a contiguous int32 GPU tensor of at least %d bytes (ops.make_workspace)" % need)
+        return given
     if stream is None:
         stream = _raw_stream(device.index)
     key = (device.index, stream)
-    lib = _capi.lib()
-    need = lib.dqq_workspace_bytes(int(B))
-    if N > 21:  # dqq_max_n: nothing below needs scratch
-        need += lib.dqq_scratch_bytes(int(kind), int(pas), int(N), int(B))
     ws = _workspaces.get(key)
+    cap = _capturing()
     if ws is None or ws.numel() * 4 < need:
-        ws = torch.zeros(max((need + 3) // 4, 1024), dtype=torch.int32, device=device)
+        if cap and ws is None:
+            raise RuntimeError("diffqcqp_amd.ops: first call on this stream inside a stream capture -- the workspace would "
+                               "be allocated and zero-filled inside the capture; warm the stream up first or pass workspace=")
+        ws = make_workspace(device, B, kind, pas, N)
         _workspaces.pop(key, None)
         _workspaces[key] = ws
         while len(_workspaces) > _MAX_WORKSPACES:
-            _workspaces.pop(next(iter(_workspaces)))
+            _workspaces.pop(next(iter(_workspaces)))   # (pinned ones stay referenced by _pinned)
     elif len(_workspaces) > 1:
         _workspaces[key] = _workspaces.pop(key)  # most recently used last
+    if cap and not any(w is ws for w in _pinned):
+        _pinned.append(ws)
     return ws
 
 
@@ -100,7 +147,7 @@ def diag_cache(q):
 
 
 def qp_forward(P, q, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, layout=_capi.P_AUTO, return_iters=False,
-               out=None, cache=None):
+               out=None, cache=None, workspace=None):
     """Batched QP solve min 1/2 x'Px + q'x, x >= 0 (reference qcqp.py:24-33). -> x (B,N,1).
     cache: optional `diag_cache(q)` buffers; pass the same pair to qp_backward (P must be unchanged)."""
     B, N, pshape = _dims(P, q, layout)
@@ -108,7 +155,7 @@ def qp_forward(P, q, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, layout=_cap
     x = _out(out, (B, N, 1), "out") if out is not None else torch.empty((B, N, 1), dtype=torch.float64, device=q.device)
     iters = torch.empty(B, dtype=torch.int32, device=q.device) if return_iters else None
     stream = _raw_stream(q.device.index)
-    ws = _workspace(q.device, B, stream, 0, 0, N)
+    ws = _workspace(q.device, B, stream, 0, 0, N, workspace)
     with _device_guard(q.device):
         pd, fl = cache if cache is not None else (None, None)
         rc = _capi.lib().dqq_qp_fwd_f64(_ptr(P), _ptr(q), _ptr(x), B, N, float(eps), float(mu_prox), int(max_iter),
@@ -119,7 +166,7 @@ def qp_forward(P, q, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, layout=_cap
 
 
 def qcqp_forward(P, q, l_n, mu, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, layout=_capi.P_AUTO,
-                 return_iters=False, out=None, cache=None):
+                 return_iters=False, out=None, cache=None, workspace=None):
     """Batched QCQP solve, ||x_(i)|| <= mu_i*l_n_i per contact (reference qcqp.py:144-153)."""
     B, N, pshape = _dims(P, q, layout)
     P, q = _prep(P, "P", pshape), _prep(q, "q", (B, N, 1))
@@ -127,7 +174,7 @@ def qcqp_forward(P, q, l_n, mu, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, 
     x = _out(out, (B, N, 1), "out") if out is not None else torch.empty((B, N, 1), dtype=torch.float64, device=q.device)
     iters = torch.empty(B, dtype=torch.int32, device=q.device) if return_iters else None
     stream = _raw_stream(q.device.index)
-    ws = _workspace(q.device, B, stream, 1, 0, N)
+    ws = _workspace(q.device, B, stream, 1, 0, N, workspace)
     with _device_guard(q.device):
         pd, fl = cache if cache is not None else (None, None)
         rc = _capi.lib().dqq_qcqp_fwd_f64(_ptr(P), _ptr(q), _ptr(l_n), _ptr(mu), _ptr(x), B, N, float(eps),
@@ -138,7 +185,7 @@ def qcqp_forward(P, q, l_n, mu, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, 
 
 
 def boxqp_forward(P, q, l_min, l_max, eps, max_iter, v=None, mu_prox=1e-7, adaptive_rho=True, layout=_capi.P_AUTO,
-                  return_iters=False, out=None, cache=None):
+                  return_iters=False, out=None, cache=None, workspace=None):
     """Batched box QP solve, l_min <= x <= l_max (reference qcqp.py:56-65); with `v` the signed box QP,
     additionally sign(v_i) x_i <= 0 (reference qcqp.py:99-108)."""
     B, N, pshape = _dims(P, q, layout)
@@ -147,7 +194,7 @@ def boxqp_forward(P, q, l_min, l_max, eps, max_iter, v=None, mu_prox=1e-7, adapt
     x = _out(out, (B, N, 1), "out") if out is not None else torch.empty((B, N, 1), dtype=torch.float64, device=q.device)
     iters = torch.empty(B, dtype=torch.int32, device=q.device) if return_iters else None
     stream = _raw_stream(q.device.index)
-    ws = _workspace(q.device, B, stream, 2 if v is None else 3, 0, N)
+    ws = _workspace(q.device, B, stream, 2 if v is None else 3, 0, N, workspace)
     with _device_guard(q.device):
         pd, fl = cache if cache is not None else (None, None)
         tail = (B, N, float(eps), float(mu_prox), int(max_iter), int(bool(adaptive_rho)), layout, _ptr(iters), _ptr(pd),
@@ -164,7 +211,7 @@ def boxqp_forward(P, q, l_min, l_max, eps, max_iter, v=None, mu_prox=1e-7, adapt
 
 
 def qp_backward(P, q, x, grad_x, need_P=True, need_q=True, layout=_capi.P_AUTO, return_steps=False, out=None,
-                epsilon=1e-10, cache=None):
+                epsilon=1e-10, cache=None, workspace=None):
     """Implicit-function backward of the QP (reference qcqp.py:36-52). -> (grad_P|None, grad_q|None)"""
     B, N, pshape = _dims(P, q, layout)
     P, q = _prep(P, "P", pshape), _prep(q, "q", (B, N, 1))
@@ -177,7 +224,7 @@ def qp_backward(P, q, x, grad_x, need_P=True, need_q=True, layout=_capi.P_AUTO, 
         gq = torch.empty((B, N, 1), dtype=torch.float64, device=dev) if need_q else None
     steps = torch.empty(B, dtype=torch.int32, device=dev) if return_steps else None
     stream = _raw_stream(dev.index)
-    ws = _workspace(dev, B, stream, 0, 1, N)
+    ws = _workspace(dev, B, stream, 0, 1, N, workspace)
     with _device_guard(dev):
         pd, fl = cache if cache is not None else (None, None)
         rc = _capi.lib().dqq_qp_bwd_f64(_ptr(P), _ptr(q), _ptr(x), _ptr(grad_x), _ptr(gP), _ptr(gq), B, N,
@@ -188,7 +235,7 @@ def qp_backward(P, q, x, grad_x, need_P=True, need_q=True, layout=_capi.P_AUTO, 
 
 
 def qcqp_backward(P, q, l_n, mu, x, grad_x, need=(True, True, True, True), layout=_capi.P_AUTO, return_steps=False,
-                  out=None, epsilon=1e-10, duals=None, cache=None):
+                  out=None, epsilon=1e-10, duals=None, cache=None, workspace=None):
     """Implicit-function backward of the QCQP (reference qcqp.py:156-181).
     -> (grad_P, grad_q, grad_l_n, grad_mu), None where not needed.  duals: optional pair of (B,N/2,1)
     tensors that receive the contact duals gamma and their derivative terms dgamma."""
@@ -207,7 +254,7 @@ def qcqp_backward(P, q, l_n, mu, x, grad_x, need=(True, True, True, True), layou
         gm = torch.empty((B, N // 2, 1), dtype=torch.float64, device=dev) if need[3] else None
     steps = torch.empty(B, dtype=torch.int32, device=dev) if return_steps else None
     stream = _raw_stream(dev.index)
-    ws = _workspace(dev, B, stream, 1, 1, N)
+    ws = _workspace(dev, B, stream, 1, 1, N, workspace)
     with _device_guard(dev):
         gam, dgam = duals if duals is not None else (None, None)
         pd, fl = cache if cache is not None else (None, None)
@@ -219,7 +266,7 @@ def qcqp_backward(P, q, l_n, mu, x, grad_x, need=(True, True, True, True), layou
 
 
 def boxqp_backward(P, q, l_min, l_max, x, grad_x, need=(True, True, True, True), layout=_capi.P_AUTO,
-                   return_steps=False, out=None, duals=None, epsilon=1e-10, cache=None):
+                   return_steps=False, out=None, duals=None, epsilon=1e-10, cache=None, workspace=None):
     """Implicit-function backward of the box QP: what BoxQPFn2.backward (reference qcqp.py:67-94) spells out,
     with the signs finite differences confirm.  -> (grad_P, grad_q, grad_l_min, grad_l_max), None where not
     needed.  duals: optional pair of (B,2N) tensors that receive gamma and dgamma ([lower | upper]).
@@ -239,7 +286,7 @@ def boxqp_backward(P, q, l_min, l_max, x, grad_x, need=(True, True, True, True),
         ghi = torch.empty((B, N, 1), dtype=torch.float64, device=dev) if need[3] else None
     steps = torch.empty((B, 2), dtype=torch.int32, device=dev) if return_steps else None
     stream = _raw_stream(dev.index)
-    ws = _workspace(dev, B, stream, 2, 1, N)
+    ws = _workspace(dev, B, stream, 2, 1, N, workspace)
     with _device_guard(dev):
         gam, dgam = duals if duals is not None else (None, None)
         pd, fl = cache if cache is not None else (None, None)

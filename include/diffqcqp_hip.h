@@ -68,15 +68,16 @@ size_t dqq_workspace_bytes(int64_t B);
  * kernels of the general path (N > dqq_max_n(..), below) a workgroup-per-problem kernel works out of global memory and
  * needs this many bytes of scratch IN ADDITION to dqq_workspace_bytes(B), in the same `workspace` buffer (the work-list
  * first, the scratch behind it; no initialisation needed).  kind: 0 QP, 1 QCQP, 2 box QP, 3 signed box QP; pass: 0
- * forward, 1 backward.  A function of its arguments alone; 0 for every size the register / LDS kernels hold (all
- * BASELINE configs).  A call whose workspace is smaller than dqq_workspace_bytes(B) + dqq_scratch_bytes(..) returns
+ * forward, 1 backward.  A function of its arguments and of the tuning knobs as they stand (it reports what the kernels
+ * a call launches NOW use: QCQP backward 42 < N <= 64 needs scratch only with "wave_qcqp_bwd" = 0); 0 for every size
+ * the register / LDS kernels hold (all BASELINE configs).  A call whose workspace is smaller than dqq_workspace_bytes(B) + dqq_scratch_bytes(..) returns
  * DQQ_E_WORKSPACE -- with DQQ_P_DENSE too, which otherwise needs no workspace at all.  Since nothing is allocated
  * or freed, a forward + backward pair can be captured into a HIP graph (tests/test_gpu_graph_capture.py). */
 size_t dqq_scratch_bytes(int kind, int pass, int N, int64_t B);
 
 /* There is no size limit (the reference has none, Solver.cpp:61): this returns the largest N the register / LDS
  * kernels of the general path hold -- kind 0 = QP forward/backward and the box forwards (64), 1 = QCQP forward (64),
- * 2 = QCQP backward (42), 3 = box QP backward (21).  Beyond it a workgroup-per-problem kernel works out of global
+ * 2 = QCQP backward (64; 42 with "wave_qcqp_bwd" = 0), 3 = box QP backward (21).  Beyond it a workgroup-per-problem kernel works out of global
  * memory, in the reference's operation order, on the caller's scratch (dqq_scratch_bytes). */
 int dqq_max_n(int kind);
 
@@ -177,9 +178,6 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
  *                    saved wave-iterations; it pays for heavy-tailed iteration counts).  Bit-identical results.
  *   "dense_teams"    general path, backward: pack 64/T problems per wave for small N (1, default) or one
  *                    problem per wave (0)
- *   "block_bwd"      general path, QCQP 22 <= N <= 64 / box QP 11 <= N <= 32 backward: workgroup kernel on the
- *                    matrix cores (1: several times faster, sums associated differently -- up to 1e-5 relative on
- *                    ill-conditioned problems) or the kernels in the reference's summation order (0, default)
  *   "small_fwd"      general path, N = 10..16 forward: team-per-problem kernel (1, default) or the
  *                    wave-per-problem kernel (0)
  *   "small_bwd"      general path, even N <= 16 backward (QP, QCQP): statically sized team kernel (1, default) or the
@@ -190,10 +188,14 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
  *                    kernel, team-per-problem kernel): the refactorisation after a rho update runs every this many trips of the wave's loop,
  *                    for all problems that changed rho since the last one (0, default: 4 for the QCQP, 6 for the other
  *                    kinds; 1 = in the trip of the update).  Bit-identical results.
- *   "dense_wave64"   general path, 16 < N <= 64 forward and QP backward: register-resident
- *                    wave-per-problem kernels (1, default); 0 falls through to "dense_block" / the LDS wave kernel
- *   "dense_block"    general path, N = 32 / 64 forward: workgroup-per-problem kernel (1, default) or the
- *                    wave-per-problem kernel (0)
+ *   "dense_wave64"   general path, 16 < N <= 64 forward and QP backward: register-resident wave-per-problem kernels
+ *                    on the f64 matrix cores (1, default) or the LDS wave kernel in the reference's summation order (0)
+ *   "wave_qcqp_bwd"  general path, QCQP backward, 16 < N <= 64: register-resident block-Cholesky kernels (1, default;
+ *                    they re-associate the sums of the cond ~1e9 Tikhonov systems: gradients within 5e-7 (grad_P,
+ *                    grad_q) / 8e-6 (grad_l_n, grad_mu) relative of the reference-order evaluation, which is the
+ *                    evaluation-order noise of the reference's own formulas) or the reference-order kernels (0: LDS
+ *                    wave kernel up to N = 42, global-memory kernel beyond -- 1e-9, 10-30x slower, and 42 < N <= 64
+ *                    then needs dqq_scratch_bytes of scratch)
  *   "auto_fallback"  0 skips the dense-kernel launch of DQQ_P_AUTO -- measurement only: non-diagonal
  *                    tiles are then left unsolved (default 1) */
 int dqq_set_option(const char* name, int value);

@@ -40,14 +40,18 @@ def test_header_symbols_are_exported(lib):
 
 def test_version_and_limits(lib):
     assert b"gfx950" in lib.dqq_version()
-    assert lib.dqq_max_n(0) == 64 and lib.dqq_max_n(1) == 64 and lib.dqq_max_n(2) == 42
+    assert lib.dqq_max_n(0) == 64 and lib.dqq_max_n(1) == 64 and lib.dqq_max_n(2) == 64 and lib.dqq_max_n(3) == 21
     assert lib.dqq_workspace_bytes(0) >= 16
     assert lib.dqq_workspace_bytes(65536) >= 4 * 65536
     # scratch of the global-memory kernels: the caller's, a function of (kind, pass, N, B); 0 for every BASELINE config
     for kind, pas, N, B in ((0, 0, 8, 65536), (1, 0, 8, 65536), (1, 1, 8, 65536), (0, 0, 32, 262144), (0, 1, 32, 262144),
                             (0, 0, 64, 65536), (0, 1, 64, 65536)):
         assert lib.dqq_scratch_bytes(kind, pas, N, B) == 0
-    assert lib.dqq_scratch_bytes(0, 0, 65, 10) > 0 and lib.dqq_scratch_bytes(1, 1, 44, 10) > 0
+    assert lib.dqq_scratch_bytes(0, 0, 65, 10) > 0 and lib.dqq_scratch_bytes(1, 1, 66, 10) > 0
+    assert lib.dqq_scratch_bytes(1, 1, 44, 10) == 0 and lib.dqq_scratch_bytes(1, 1, 64, 10) == 0   # register-resident kernels
+    assert lib.dqq_set_option(b"wave_qcqp_bwd", 0) == 0        # the reference-order route needs (and demands) scratch
+    assert lib.dqq_scratch_bytes(1, 1, 44, 10) > 0 and lib.dqq_max_n(2) == 42
+    assert lib.dqq_set_option(b"wave_qcqp_bwd", 1) == 0
     assert lib.dqq_scratch_bytes(2, 1, 22, 10) > 0 and lib.dqq_scratch_bytes(3, 1, 200, 10) == 0
     assert lib.dqq_scratch_bytes(0, 0, 65, 4) * 2 == lib.dqq_scratch_bytes(0, 0, 65, 8)   # a slice per workgroup
     assert lib.dqq_scratch_bytes(0, 0, 65, 10 ** 6) == lib.dqq_scratch_bytes(0, 0, 65, 10 ** 7)  # persistent grid
@@ -123,3 +127,35 @@ def test_reference_import_lines_resolve():
     assert all(hasattr(q, n) for n in ("QPFn2", "QCQPFn2", "BoxQPFn2", "SignedBoxQPFn2"))
     nb = importlib.import_module("qcqp_no_batch")
     assert hasattr(nb, "QPFn2") and hasattr(nb, "QCQPFn2")
+
+
+def test_missing_pybind_module_never_rebuilds_the_hip_units():
+    """the optional pybind11 module has its own staleness test.  Its absence alone must not recompile the HIP
+    translation units (a host without pybind11 would rebuild the library on every build.build() call), a stale module is
+    deleted before its rebuild is attempted (a failed rebuild falls back to ctypes, never to a module with another
+    argument order), and the outcome is recorded in the stamp file."""
+    import time
+    from diffqcqp_amd import build
+    build.build()
+    assert not build.needs_build()
+    flags, note = build._read_stamp()
+    assert flags == build._flag_stamp() and note is not None and note.startswith("pybind11:")
+    if note != "pybind11: ok":
+        assert not os.path.exists(build.PYMOD)
+        return
+    lib_mtime = os.path.getmtime(build.LIB)
+    os.remove(build.PYMOD)
+    try:
+        assert not build.needs_build(), "a missing _dqq.so must not trigger a rebuild of the HIP units"
+        assert build._pybind_stale()
+        t0 = time.time()
+        build.build()
+        assert time.time() - t0 < 60 and os.path.getmtime(build.LIB) == lib_mtime     # only the module was rebuilt
+        assert os.path.exists(build.PYMOD) and not build._pybind_stale()
+        # a recorded failure is not retried until a dependency changes
+        os.remove(build.PYMOD)
+        build._write_stamp("pybind11: unavailable (test)")
+        assert not build.needs_build() and not build._pybind_stale()
+    finally:
+        build._write_stamp(build._build_pybind())
+    assert os.path.exists(build.PYMOD)

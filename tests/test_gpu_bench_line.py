@@ -42,3 +42,40 @@ def test_a_config_line_checks_itself_against_the_oracle():
     assert "configs[2]" in d["config"]["workload"]
     err = d.get("parity_max_abs_err_vs_oracle_sample") or d.get("parity")
     assert err is not None
+
+
+def test_headline_line_names_host_enqueue_and_every_kernel_inside_the_driver_preserved_keys():
+    """the driver's record keeps the scalar entries of `roofline` and `config`; what tells a host-bound
+    step from a GPU-bound one (host enqueue time, the one-stream step, the per-kernel durations, the fixed cost of a timed
+    region) must therefore be scalars there, and no fraction may exceed 1 without the moved figure beside it."""
+    d = _run("--no-per-config")
+    rl = d["roofline"]
+    for k in ("host_enqueue_us_per_step", "single_stream_ms_per_step", "kernels_sum_us", "kernel_us_qp_fwd", "kernel_us_qp_bwd",
+              "kernel_us_qcqp_fwd", "kernel_us_qcqp_bwd", "region_fixed_us", "us_per_step_steady_state",
+              "ms_per_step_long_region", "step_moved_frac", "moved_frac", "kernel_us_qcqp_bwd_with_empty_drain"):
+        assert isinstance(rl.get(k), float), k
+    assert 0 < rl["host_enqueue_us_per_step"] < 1e3 * d["ms_per_step"] * 1.05
+    assert 0 < rl["step_moved_frac"] < 1 and 0 < rl["moved_frac"] < 1
+    assert rl["kernel_us_qcqp_bwd_with_empty_drain"] > rl["kernel_us_qcqp_bwd"] * 0.9
+
+
+def test_rccl_branch_with_one_rank():
+    """the code the driver's `torch.distributed.run ... bench.py --gpus N` executes -- RCCL init, barriers,
+    the all-gather of x into a caller-owned buffer overlapped with the backward, MAX over ranks -- run here with one rank so
+    that first contact with a multi-GPU node is not the first execution."""
+    env = dict(os.environ, DQQ_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
+                        "--repeats", "2", "--config", "4", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "exactly one line on stdout (RCCL's banner must not land there)"
+    d = json.loads(lines[0])
+    assert d["config"]["rccl_world"] == 1 and d["scaling"] == "strong" and d["config"]["B_total"] == 262144
+    assert d["without_gather"]["rccl_world"] == 1 and d["without_gather"]["ms_per_step"] > 0
+    assert d["gather_after_backward"]["ms_per_step"] > 0
+    assert d["without_gather"]["allgather_bytes_per_rank"] == 262144 * 32 * 8
+    # the gather is the identity at one rank: the three rates must agree within a few percent
+    assert d["ms_per_step"] < 1.15 * d["without_gather"]["ms_per_step"]

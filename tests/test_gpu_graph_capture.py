@@ -96,10 +96,21 @@ def test_scratch_is_the_callers(ops):
     for kind in (0, 1, 2, 3):
         for pas in (0, 1):
             for N in (2, 8, 21, 32, 64):
-                if (kind, pas) in ((1, 1), (2, 1)) and N > (42 if kind == 1 else 21):
+                if (kind, pas) == (2, 1) and N > 21:
                     assert L.dqq_scratch_bytes(kind, pas, N, 1000) > 0
-                else:
+                else:   # QCQP backward up to N = 64 included: the register-resident kernels use no scratch
                     assert L.dqq_scratch_bytes(kind, pas, N, 1000) == 0, (kind, pas, N)
+    # dqq_scratch_bytes follows the route: with the reference-order QCQP backward selected, 42 < N <= 64 reaches the
+    # global-memory kernel and the call demands (and uses) its scratch
+    assert L.dqq_max_n(2) == 64
+    _capi.set_option("wave_qcqp_bwd", 0)
+    try:
+        assert L.dqq_scratch_bytes(1, 1, 64, 1000) > 0 and L.dqq_scratch_bytes(1, 1, 42, 1000) == 0
+        assert L.dqq_max_n(2) == 42
+        assert ops.workspace_bytes(1000, 1, 1, 64) == L.dqq_workspace_bytes(1000) + L.dqq_scratch_bytes(1, 1, 64, 1000)
+    finally:
+        _capi.set_option("wave_qcqp_bwd", 1)
+    assert ops.workspace_bytes(1000, 1, 1, 64) == L.dqq_workspace_bytes(1000)
     need = L.dqq_scratch_bytes(0, 0, 70, 24)
     assert need > 0 and L.dqq_scratch_bytes(0, 0, 70, 24) == need and L.dqq_scratch_bytes(0, 0, 70, 0) == 0
     d = make_problem("qp", 24, 70, 8300, "dense")
@@ -148,6 +159,51 @@ def test_workspace_cache_is_reused_and_bounded(ops):
     p1 = ops._workspace(dev, 2051).data_ptr()
     x2 = ops.qp_forward(P, q, 1e-7, 1000)
     assert ops._workspace(dev, 2051).data_ptr() == p1 and torch.equal(x1, x2)
+
+
+def test_workspace_lifetime_under_graph_capture(ops):
+    """a captured graph bakes in the workspace pointer.  (1) A caller-owned `workspace=` is used as given.
+    (2) A cached workspace that was handed out during a capture is never replaced in place: when a larger call arrives
+    later the cache moves on to a new tensor and the captured one stays alive, so a replay cannot scribble over memory
+    the allocator has given to someone else.  (3) A first call inside a capture is refused (it would allocate + memset)."""
+    dev = torch.device("cuda", 0)
+    d = make_problem("qcqp", 300, 8, 8700, "mixed")
+    P, q, ln, mu = (d[k].cuda() for k in ("P", "q", "l_n", "mu"))
+    own = ops.make_workspace(dev, 300, 1, 0, 8)
+    x_own = ops.qcqp_forward(P, q, ln, mu, 1e-7, 1000, workspace=own)
+    x_ref = ops.qcqp_forward(P, q, ln, mu, 1e-7, 1000)
+    torch.cuda.synchronize()
+    assert torch.equal(x_own, x_ref) and int(own[:2].abs().sum()) == 0
+    with pytest.raises(ValueError):
+        ops.qcqp_forward(P, q, ln, mu, 1e-7, 1000, workspace=own[:8])
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    x = torch.empty(300, 8, 1, device="cuda", dtype=torch.float64)
+    fresh = torch.cuda.Stream()
+    graph0 = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="stream capture"):
+        with torch.cuda.graph(graph0, stream=fresh):
+            ops.qcqp_forward(P, q, ln, mu, 1e-7, 1000, out=x)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        ops.qcqp_forward(P, q, ln, mu, 1e-7, 1000, out=x)      # warm-up: the cache entry of this stream
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        ops.qcqp_forward(P, q, ln, mu, 1e-7, 1000, out=x)
+    captured = ops._workspaces[(0, s.cuda_stream)]
+    assert any(w is captured for w in ops._pinned)
+    with torch.cuda.stream(s):                                  # a larger batch on the same stream: the cache grows ...
+        dbig = make_problem("qp", 200000, 8, 8701)
+        ops.qp_forward(dbig["P"].cuda(), dbig["q"].cuda(), 1e-7, 1000)
+    torch.cuda.synchronize()
+    assert ops._workspaces[(0, s.cuda_stream)] is not captured   # ... into a NEW tensor
+    assert any(w is captured for w in ops._pinned)               # the captured one is still alive
+    x.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(x, x_ref) and int(captured[:2].abs().sum()) == 0
 
 
 def test_functions_take_the_layout_from_the_module_default(oracle, ops):

@@ -44,7 +44,8 @@ def ops():
     _capi.set_option("fwd_lpp", 0)
     _capi.set_option("wpb", 0)
     _capi.set_option("fuse_fallback", -1)
-    _capi.set_option("dense_block", 1)
+    _capi.set_option("dense_wave64", 1)
+    _capi.set_option("wave_qcqp_bwd", 1)
     _capi.set_option("lane_dense", 1)
     _capi.set_option("dense_teams", 1)
     _capi.set_option("small_bwd", 1)
@@ -291,64 +292,44 @@ def test_dense_kernel_matches_oracle(oracle, ops, kind, N, B, structure):
 
 @pytest.mark.parametrize("kind", ["qp", "qcqp"])
 @pytest.mark.parametrize("N,B", [(32, 40), (64, 12)])
-def test_block_and_wave_dense_forward_agree(oracle, ops, kind, N, B):
-    """N = 32 / 64 forward has two general kernels: workgroup-per-problem (default) and wave-per-problem.
-    Both follow the oracle's trajectory; they differ only in summation order."""
+def test_register_and_lds_wave_dense_forward_agree(oracle, ops, kind, N, B):
+    """N = 32 / 64 forward has two general kernels: the register-resident wave-per-problem kernel on the matrix cores
+    (default) and the LDS wave kernel in the reference's summation order ("dense_wave64" = 0).  Both follow the oracle's
+    trajectory; they differ only in summation order."""
     from diffqcqp_amd import _capi
     d = make_problem(kind, B, N, 650 + N, "dense")
     g = dev(d)
     xo, ito = oracle_fwd(oracle, kind, d)
     out = {}
-    for blk in (1, 0):
-        _capi.set_option("dense_block", blk)
-        out[blk] = hip_fwd(ops, kind, g, layout=_capi.P_DENSE)
-        check_forward(out[blk][0], out[blk][1], xo, ito, min_match=0.9)
-    _capi.set_option("dense_block", 1)
+    try:
+        for reg in (1, 0):
+            _capi.set_option("dense_wave64", reg)
+            out[reg] = hip_fwd(ops, kind, g, layout=_capi.P_DENSE)
+            check_forward(out[reg][0], out[reg][1], xo, ito, min_match=0.9)
+    finally:
+        _capi.set_option("dense_wave64", 1)
     assert (out[0][0] - out[1][0]).abs().max() < 1e-8
 
 
 @pytest.mark.parametrize("N,B", [(32, 40), (64, 12), (64, 300)])
-def test_block_and_wave_dense_backward_agree(oracle, ops, N, B):
-    """N = 32 / 64 QP backward has two general kernels: workgroup-per-problem on the matrix cores (default)
-    and wave-per-problem in the reference's operation order.  Both are checked against the oracle."""
+def test_register_and_lds_wave_dense_backward_agree(oracle, ops, N, B):
+    """N = 32 / 64 QP backward has two general kernels: register-resident block Cholesky on the matrix cores (default) and
+    the LDS wave kernel in the reference's operation order ("dense_wave64" = 0).  Both are checked against the oracle."""
     from diffqcqp_amd import _capi
     d = make_problem("qp", B, N, 690 + N, "dense")
     g = dev(d)
     xo, _ = oracle_fwd(oracle, "qp", d)
     ref = oracle_bwd(oracle, "qp", d, xo)
     out = {}
-    for blk in (1, 0):
-        _capi.set_option("dense_block", blk)
-        out[blk] = hip_bwd(ops, "qp", g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
-        check_backward_exact(out[blk][0], out[blk][1], ref, exact=False)
-    _capi.set_option("dense_block", 1)
+    try:
+        for reg in (1, 0):
+            _capi.set_option("dense_wave64", reg)
+            out[reg] = hip_bwd(ops, "qp", g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
+            check_backward_exact(out[reg][0], out[reg][1], ref, exact=False)
+    finally:
+        _capi.set_option("dense_wave64", 1)
     for a, b in zip(out[0][0], out[1][0]):
         assert (a - b).abs().max() <= 1e-9 * max(1.0, float(b.abs().max()))
-
-
-@pytest.mark.parametrize("kind", ["qp", "qcqp"])
-@pytest.mark.parametrize("N,B", [(8, 1000), (6, 130), (4, 300), (2, 65)])
-def test_lane_and_wave_dense_forward_agree(oracle, ops, kind, N, B):
-    """N <= 8 forward has two general kernels: lane-per-problem (default) and wave-per-problem."""
-    from diffqcqp_amd import _capi
-    d = make_problem(kind, B, N, 660 + N, "dense")
-    g = dev(d)
-    xo, ito = oracle_fwd(oracle, kind, d)
-    out = {}
-    for lane in (1, 0):
-        _capi.set_option("lane_dense", lane)
-        out[lane] = hip_fwd(ops, kind, g, layout=_capi.P_DENSE)
-        check_forward(out[lane][0], out[lane][1], xo, ito, min_match=0.99)
-    # AUTO with the in-kernel fallback switched off: fast path -> work-list -> lane kernel
-    _capi.set_option("lane_dense", 1)
-    _capi.set_option("fuse_fallback", 0)
-    dm = make_problem(kind, B, N, 670 + N, "mixed")
-    xm, im = oracle_fwd(oracle, kind, dm)
-    for _ in range(2):
-        xh, ih = hip_fwd(ops, kind, dev(dm))
-        check_forward(xh, ih, xm, im, min_match=0.99)
-    _capi.set_option("fuse_fallback", -1)
-    assert (out[0][0] - out[1][0]).abs().max() < 1e-8
 
 
 @pytest.mark.parametrize("kind", ["qp", "qcqp"])
@@ -362,12 +343,16 @@ def test_dense_backward_teams_agree_with_one_problem_per_wave(oracle, ops, kind,
     ref = oracle_bwd(oracle, kind, d, xo)
     out = {}
     _capi.set_option("dense_wave64", 0)   # the LDS kernels (the matrix-core kernels take 16 < N by default)
-    for teams in (1, 0):
-        _capi.set_option("dense_teams", teams)
-        out[teams] = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
-        check_backward_exact(out[teams][0], out[teams][1], ref, exact=False)
-    _capi.set_option("dense_teams", 1)
-    _capi.set_option("dense_wave64", 1)
+    _capi.set_option("wave_qcqp_bwd", 0)
+    try:
+        for teams in (1, 0):
+            _capi.set_option("dense_teams", teams)
+            out[teams] = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
+            check_backward_exact(out[teams][0], out[teams][1], ref, exact=False)
+    finally:
+        _capi.set_option("dense_teams", 1)
+        _capi.set_option("dense_wave64", 1)
+        _capi.set_option("wave_qcqp_bwd", 1)
     for a, b in zip(out[0][0], out[1][0]):
         assert torch.equal(a, b)  # identical operation order -> identical bits
 
@@ -392,55 +377,21 @@ def test_small_dense_backward_is_bit_exact_and_matches_the_wave_kernel(oracle, o
     check_backward_exact(out[0][0], out[0][1], ref, exact=False)
 
 
-@pytest.mark.parametrize("kind,N,B", [("qcqp", 32, 96), ("qcqp", 64, 40), ("box", 16, 128), ("box", 32, 48),
-                                      ("qcqp", 50, 24), ("qcqp", 44, 24), ("box", 26, 30), ("box", 22, 30)])
-def test_workgroup_backward_for_large_systems(oracle, ops, kind, N, B):
-    """Systems of up to 96 unknowns, padded to 48 / 80 / 96 slots: workgroup-per-problem backward on the matrix
-    cores (bwd_block.hip), opt-in ("block_bwd"; the default beyond the wave kernel is the reference-order
-    global-memory kernel, test_no_size_limit / test_reference_order_backward_beyond_the_wave_kernel).
-    Its tile products associate sums differently from the oracle's loops; the Tikhonov systems of this
-    backward have cond(K) up to ~1e9 (active contacts: K has eigenvalues next to mu = 1e-7), which turns 1e-16
-    into up to ~1e-5 relative on a few problems -- the reference itself would show the same against another
-    BLAS.  Hence: gradients within 1e-4 where the refinement exits agree, median error below 1e-7."""
-    from diffqcqp_amd import _capi
-    d = make_problem(kind, B, N, 730 + N, "dense")
-    g = dev(d)
-    _capi.set_option("block_bwd", 1)
-    try:
-        if kind == "qcqp":
-            xo, _ = oracle_fwd(oracle, kind, d)
-            ref = oracle_bwd(oracle, kind, d, xo)
-            grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
-            check_end_to_end(grads, st, ref, max_flip=0.2, tol=1e-4)
-            same = npy(st) == ref[-1]
-            assert np.median(np.abs(npy(grads[1]) - ref[1])[same].max(axis=(1, 2))) < 1e-7
-        else:
-            xo, _ = oracle.boxqp_fwd_batch(d["P"].numpy(), d["q"].numpy(), d["l_min"].numpy(), d["l_max"].numpy(), 1e-7,
-                                           1000, nthreads=8)
-            ref, out, duals = _box_bwd(oracle, ops, d, xo, layout=_capi.P_DENSE)
-            assert np.array_equal(npy(out[4])[:, 0], ref[5][:, 0])      # dual recovery: per-coordinate blocks, exact
-            assert np.array_equal(npy(duals[0]), ref[4])
-            check_end_to_end(list(out[:4]), out[4][:, 1], (ref[0], ref[1], ref[2], ref[3], ref[5][:, 1]), max_flip=0.2,
-                             tol=1e-4)
-    finally:
-        _capi.set_option("block_bwd", 0)
-
-
 @pytest.mark.parametrize("kind,N,B", [("qcqp", 64, 40), ("qcqp", 50, 24), ("qcqp", 44, 24), ("box", 32, 48), ("box", 22, 30)])
 def test_reference_order_backward_beyond_the_wave_kernel(oracle, ops, kind, N, B):
     """The global-memory workgroup kernel in the reference's operation order -- the default for box 21 < N <= 32, and for
-    QCQP 42 < N <= 64 behind dense_wave64 = 0 (the matrix-core kernels take 16 < N <= 64 since round 3): same 1e-9 bar
+    QCQP 42 < N <= 64 behind wave_qcqp_bwd = 0 (the matrix-core kernels take 16 < N <= 64 since round 3): same 1e-9 bar
     (and identical refinement step counts) as the LDS wave kernel below those sizes."""
     from diffqcqp_amd import _capi
     d = make_problem(kind, B, N, 730 + N, "dense")
     g = dev(d)
     if kind == "qcqp":
         xo, _ = oracle_fwd(oracle, kind, d)
-        _capi.set_option("dense_wave64", 0)
+        _capi.set_option("wave_qcqp_bwd", 0)
         try:
             grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
         finally:
-            _capi.set_option("dense_wave64", 1)
+            _capi.set_option("wave_qcqp_bwd", 1)
         check_backward_exact(grads, st, oracle_bwd(oracle, kind, d, xo), exact=False)
     else:
         xo = oracle.boxqp_fwd_batch(d["P"].numpy(), d["q"].numpy(), d["l_min"].numpy(), d["l_max"].numpy(), 1e-7, 1000,
@@ -468,7 +419,6 @@ def test_wave_per_problem_forward_every_size(oracle, ops, kind, N, B):
         xo, ito, xh, ith = _box_fwd(oracle, ops, kind, d, layout=_capi.P_DENSE)
     check_forward(xh, ith, xo, ito, min_match=0.97)
     _capi.set_option("dense_wave64", 0)
-    _capi.set_option("dense_block", 0)
     try:
         if kind in ("qp", "qcqp"):
             xw, itw = hip_fwd(ops, kind, g, layout=_capi.P_DENSE)
@@ -476,7 +426,6 @@ def test_wave_per_problem_forward_every_size(oracle, ops, kind, N, B):
             _, _, xw, itw = _box_fwd(oracle, ops, kind, d, layout=_capi.P_DENSE)
     finally:
         _capi.set_option("dense_wave64", 1)
-        _capi.set_option("dense_block", 1)
     assert (xw - xh).abs().max() < 1e-8 and (itw == ith).float().mean() >= 0.97
     if kind == "qp":
         # QP backward: every 16 < N <= 64 runs on the same register-resident design (K on the matrix cores);
@@ -676,10 +625,12 @@ def test_box_forward_dense_and_mixed(oracle, ops, kind, N, B, structure):
         check_forward(xh, ith, xo, ito, min_match=0.99 if N < 32 else 0.9)
     if structure == "dense" and N in (8, 32):  # the wave kernel behind the lane / workgroup kernels agrees
         _capi.set_option("lane_dense", 0)
-        _capi.set_option("dense_block", 0)
-        xo, ito, xw, itw = _box_fwd(oracle, ops, kind, d, layout=_capi.P_DENSE)
-        _capi.set_option("lane_dense", 1)
-        _capi.set_option("dense_block", 1)
+        _capi.set_option("dense_wave64", 0)
+        try:
+            xo, ito, xw, itw = _box_fwd(oracle, ops, kind, d, layout=_capi.P_DENSE)
+        finally:
+            _capi.set_option("lane_dense", 1)
+            _capi.set_option("dense_wave64", 1)
         check_forward(xw, itw, xo, ito, min_match=0.99)
         assert (xw - xh).abs().max() < 1e-8
 
@@ -1168,7 +1119,7 @@ def test_qcqp_backward_wave_kernel_16_to_32(oracle, ops, N, B):
     registers (N <= 32: bwd_wave_qcqp.hip, the system matrix too; beyond: bwd_wave_qcqp_big.hip, the matrix streamed;
     block Cholesky).  Against the oracle on the oracle's x (tolerances: REASSOC_TOL, the
     reference's own evaluation-order noise) and against the LDS wave kernel in the reference's summation order
-    (dense_wave64 = 0); refinement exits that differ are checked against the reference formula at the kernel's own
+    (wave_qcqp_bwd = 0); refinement exits that differ are checked against the reference formula at the kernel's own
     exit (orc_set_force_ir_steps)."""
     from diffqcqp_amd import _capi
     d = make_problem("qcqp", B, N, 6400 + N, "dense")
@@ -1184,9 +1135,9 @@ def test_qcqp_backward_wave_kernel_16_to_32(oracle, ops, N, B):
         check_backward_reassociated(oracle, "qcqp", d, xo, (gP, gq, gl, gm), st, ref)
         assert torch.isfinite(duals[0]).all() and torch.isfinite(duals[1]).all()
     # the kernel in the reference's summation order agrees (bit-exact with the oracle on identical x)
-    _capi.set_option("dense_wave64", 0)
+    _capi.set_option("wave_qcqp_bwd", 0)
     try:
         grads, st2 = hip_bwd(ops, "qcqp", g, xs, layout=_capi.P_DENSE)
         check_backward_exact(grads, st2, ref, exact=False)
     finally:
-        _capi.set_option("dense_wave64", 1)
+        _capi.set_option("wave_qcqp_bwd", 1)

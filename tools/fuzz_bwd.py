@@ -25,7 +25,7 @@ for t in range(trials):
     if N not in (2, 4, 8, 16, 32, 64) and structure == "diag": structure = "dense"
     opts = {"fuse_fallback": int(rng.choice([-1, 0, 1])), "wpb": int(rng.choice([0, 1, 4])),
             "small_bwd": int(rng.choice([0, 1])), "dense_teams": int(rng.choice([0, 1])),
-            "dense_wave64": int(rng.choice([0, 1])), "dense_block": int(rng.choice([0, 1]))}
+            "dense_wave64": int(rng.choice([0, 1])), "wave_qcqp_bwd": int(rng.choice([0, 1]))}
     use_cache = bool(rng.integers(2)) and layout == 0
     d = make_problem(kind, B, N, 7000 + t, "dense" if structure == "nonsym" else structure)
     if structure == "nonsym":
@@ -55,9 +55,9 @@ for t in range(trials):
         grads, st, gref, sref = out[:4], out[4].cpu().numpy()[:, 1], ref[:4], ref[5][:, 1]
     same = st == sref
     rel = 0.0
-    # the QCQP's contact gradients through the matrix-core kernels (16 < N <= 64, dense_wave64 = 1): the evaluation-order
+    # the QCQP's contact gradients through the matrix-core kernels (16 < N <= 64, wave_qcqp_bwd = 1): the evaluation-order
     # noise of the reference's own formulas is up to 8.6e-6 there (tests/test_gpu_parity.py: REASSOC_TOL); judged at 2e-5
-    reassoc = kind == "qcqp" and 16 < N <= 64 and opts["dense_wave64"] == 1 and structure != "diag"
+    reassoc = kind == "qcqp" and 16 < N <= 64 and opts["wave_qcqp_bwd"] == 1 and structure != "diag"
     for k, (a, b) in enumerate(zip(grads, gref)):
         a, b = a.cpu().numpy()[same], b[same]
         if a.size:
@@ -70,5 +70,5 @@ for t in range(trials):
     if not ok:
         bad += 1
         print("FAIL", t, kind, N, B, structure, layout, opts, "cache", use_cache, "rel %.2e exits equal %.3f finite %s" % (rel, same.mean(), finite), flush=True)
-for k, v in {"fuse_fallback": -1, "wpb": 0, "small_bwd": 1, "dense_teams": 1, "dense_wave64": 1, "dense_block": 1}.items(): _capi.set_option(k, v)
+for k, v in {"fuse_fallback": -1, "wpb": 0, "small_bwd": 1, "dense_teams": 1, "dense_wave64": 1, "wave_qcqp_bwd": 1}.items(): _capi.set_option(k, v)
 print("%d trials, %d failures, worst rel err %.2e" % (trials, bad, worst))

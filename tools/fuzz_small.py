@@ -29,7 +29,7 @@ for t in range(trials):
     if structure == "mixed": layout = 0
     eps = float(rng.choice([1e-7, 1e-7, 1e-10, 1e-5]))
     max_iter = int(rng.choice([1000, 1000, 1, 7, 16, 40]))
-    opts = {"fwd_lpp": int(rng.choice([0] + LPP.get(N, []))), "dense_wave64": int(rng.choice([0, 1])), "dense_block": int(rng.choice([0, 1])),
+    opts = {"fwd_lpp": int(rng.choice([0] + LPP.get(N, []))), "dense_wave64": int(rng.choice([0, 1])),
             "lane_dense": int(rng.choice([0, 1])), "small_fwd": int(rng.choice([0, 1])), "fuse_fallback": int(rng.choice([-1, 0, 1])),
             "fwd_compact": int(rng.choice([0, 1])), "wpb": int(rng.choice([0, 1, 4])),
             "lane_defer": int(rng.choice([0, 1, 3, 7])), "fwd_respread": int(rng.choice([0, 5, 16]))}
@@ -62,6 +62,6 @@ for t in range(trials):
     if not ok:
         bad += 1
         print("FAIL", t, kind, N, B, structure, layout, eps, max_iter, opts, "err %.2e iters equal %.4f" % (err, same), flush=True)
-for k, v in {"fwd_lpp": 0, "fuse_fallback": -1, "fwd_compact": 0, "wpb": 0, "dense_wave64": 1, "dense_block": 1, "lane_dense": 1,
+for k, v in {"fwd_lpp": 0, "fuse_fallback": -1, "fwd_compact": 0, "wpb": 0, "dense_wave64": 1, "lane_dense": 1,
              "small_fwd": 1, "lane_defer": 0, "fwd_respread": 16}.items(): _capi.set_option(k, v)
 print("%d trials, %d failures, worst |dx| %.2e" % (trials, bad, worst))

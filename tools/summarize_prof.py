@@ -45,6 +45,7 @@ def bench_key(s):
 def main():
     kt, sq, fe, wr, outdir, tag = sys.argv[1:7]
     suffix = sys.argv[7] if len(sys.argv) > 7 else ""
+    sq2 = sys.argv[8] if len(sys.argv) > 8 else ""
     os.makedirs(outdir, exist_ok=True)
     c = sqlite3.connect(kt)
     rows = c.execute("select name, count(*), avg(end-start), min(end-start), max(end-start), sum(end-start) "
@@ -56,8 +57,8 @@ def main():
         for r in rows:
             w.writerow([short(r[0]), r[1], "%.0f" % r[2], r[3], r[4], r[5], "%.2f" % (100.0 * r[5] / tot)])
     pmc = {}
-    for db in (sq, fe, wr):
-        if not os.path.exists(db):
+    for db in (sq, fe, wr, sq2):
+        if not db or not os.path.exists(db):
             continue
         c = sqlite3.connect(db)
         for name, counter, val, n in c.execute("select kernel_name, counter_name, avg(value), count(*) "
@@ -71,6 +72,14 @@ def main():
             v["hbm_write_bytes_per_launch"] = v["WRITE_SIZE"] * 1024
         if "SQ_INSTS_VALU" in v and v.get("SQ_WAVES"):
             v["valu_insts_per_wave"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"]
+        # VALU lane utilisation (the gfx9 "VALUUtilization" formula): thread-cycles of VALU work / (cycles a VALU
+        # instruction was active x 64 lanes)
+        if v.get("SQ_ACTIVE_INST_VALU") and "SQ_THREAD_CYCLES_VALU" in v:
+            v["valu_lane_utilisation"] = v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64.0)
+        if v.get("SQ_WAVE_CYCLES"):
+            for cn in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"):
+                if cn in v:
+                    v[cn + "_frac"] = v[cn] / v["SQ_WAVE_CYCLES"]
         key = bench_key(k)
         if key and "hbm_bytes_per_launch" in v:
             e = latest.setdefault(key, {"kernels": [], "hbm_bytes_per_launch": 0.0})
@@ -80,7 +89,10 @@ def main():
             # work-list launch next to it
             if v.get("SQ_INSTS_VALU", 0.0) >= e.get("SQ_INSTS_VALU", -1.0):
                 e["main_kernel"] = k
-                for extra in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES"):
+                for extra in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES",
+                              "SQ_INSTS_SALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES",
+                              "valu_lane_utilisation", "SQ_WAIT_INST_ANY_frac", "SQ_WAIT_ANY_frac", "SQ_ACTIVE_INST_ANY_frac",
+                              "SQ_ACTIVE_INST_VALU_frac"):
                     if extra in v:
                         e[extra] = v[extra]
     for e in latest.values():
