@@ -435,14 +435,14 @@ def measure(cfg, args, ctx, light=False):
         torch.cuda.synchronize()
     finally:
         _capi.set_option("auto_fallback", 1)
-    # the empty work-list launch behind every DQQ_P_AUTO backward of a diagonal batch, bracketed on its own: with and
-    # without it, per backward launch (rocprofv3 read 5.5 us where DESIGN said 2.5)
+    # the empty work-list launch behind every DQQ_P_AUTO backward of a diagonal batch: 50 backward calls back to back on
+    # one stream, with and without it (rocprofv3 read 5.5 us per empty launch where DESIGN said 2.5).
+    # Back-to-back figures are ~3 us below the event-bracketed ones above (no event packets between the launches).
     drain_us = None
     if all_diag and any(c.backward for c in chains) and not light:
         drain_us = {}
-        for c in chains:
-            if not c.backward:
-                continue
+
+        def b2b(c):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             c.launch(1, sh)
             torch.cuda.synchronize()
@@ -451,7 +451,17 @@ def measure(cfg, args, ctx, light=False):
                 c.launch(1, sh)
             e1.record(main_stream)
             torch.cuda.synchronize()
-            drain_us[c.names[1]] = e0.elapsed_time(e1) / 50 * 1e3
+            return e0.elapsed_time(e1) / 50 * 1e3
+        for c in chains:
+            if not c.backward:
+                continue
+            with_drain = b2b(c)
+            try:
+                _capi.set_option("auto_fallback", 0)
+                without = b2b(c)
+            finally:
+                _capi.set_option("auto_fallback", 1)
+            drain_us[c.names[1]] = (without, with_drain)
     kernels = {}
     for j, (c, w) in enumerate(launches):
         ts = sorted(ev[r][j][0].elapsed_time(ev[r][j][1]) for r in range(nrep))
@@ -485,8 +495,9 @@ def measure(cfg, args, ctx, light=False):
     for k, v in kernels.items():
         roofline["kernel_us_" + k] = v["mean_us"]
     if drain_us:
-        for k, v in drain_us.items():
-            roofline["kernel_us_" + k + "_with_empty_drain"] = v
+        for k, (without, with_drain) in drain_us.items():
+            roofline["b2b_us_" + k] = without
+            roofline["b2b_us_" + k + "_with_empty_drain"] = with_drain
     if region_fit:
         roofline.update(region_fit)
     # HBM traffic and VALU instruction counts are PMC measurements of a separate rocprofv3 run (tools/profile.sh):

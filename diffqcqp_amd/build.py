@@ -27,6 +27,7 @@ UNITS = {
     "dense.hip": ["-ffp-contract=off"],
     "general_any.hip": ["-ffp-contract=off"],
     "bwd_small.hip": ["-ffp-contract=off"],
+    "bwd_lane_dense.hip": ["-ffp-contract=off"],
     "dense_wave64.hip": ["-ffp-contract=fast"],
     "bwd_wave_qcqp.hip": ["-ffp-contract=off"],
     "bwd_wave_qcqp_big.hip": ["-ffp-contract=off"],

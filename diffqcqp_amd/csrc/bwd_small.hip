@@ -40,7 +40,11 @@ static hipError_t launch_small(const BwdArgs& a, bool use_worklist, hipStream_t 
     const long cap = 256L * 16;
     // work-list mode: the list holds at most B entries (a small batch does not pay for 1024 idle workgroups);
     // beyond 1024 persistent workgroups the team kernel gets slower, not faster (65536 x 8 dense: 102 vs 155 us)
+#if defined(DQQ_SMALL_WPB)
+    const long lim = use_worklist ? 4096 / WPB : cap;
+#else
     const long lim = use_worklist ? 1024 : cap;
+#endif
     const unsigned grid = (unsigned)(need < lim ? (need > 0 ? need : 1) : lim);
     auto kernel = bwd_small_kernel<KIND, N>;
     if (lds_bytes > 48 * 1024) {

@@ -14,6 +14,7 @@ extern std::atomic<int> g_lane_dense;
 extern std::atomic<int> g_lane_defer;
 extern std::atomic<int> g_dense_teams;
 extern std::atomic<int> g_small_bwd;
+extern std::atomic<int> g_lane_bwd;
 extern std::atomic<int> g_small_fwd;
 extern std::atomic<int> g_wave_qcqp_bwd;
 }
@@ -38,6 +39,7 @@ Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback"
                       {"lane_defer", &dqq::g_lane_defer},
                       {"dense_teams", &dqq::g_dense_teams},
                       {"small_bwd", &dqq::g_small_bwd},
+                      {"lane_bwd", &dqq::g_lane_bwd},
                       {"small_fwd", &dqq::g_small_fwd},
                       {"wave_qcqp_bwd", &dqq::g_wave_qcqp_bwd}};
 

@@ -14,6 +14,7 @@ std::atomic<int> g_lane_dense{1};  // 0: never the lane-per-problem kernel of N 
 std::atomic<int> g_dense_teams{1}; // 0: backward always one problem per wave (option "dense_teams")
 std::atomic<int> g_small_fwd{1};   // 0: never the team-per-problem forward of N = 10..16 (option "small_fwd")
 std::atomic<int> g_small_bwd{1};   // 0: never the statically sized team backward of N <= 8 (option "small_bwd")
+std::atomic<int> g_lane_bwd{1};    // 0: never the lane-per-problem backward of N <= 8, DQQ_P_DENSE (option "lane_bwd")
 
 
 // Workgroups hold `wpb` independent waves (wave-private LDS slices, no workgroup barrier): more waves
@@ -186,6 +187,10 @@ static hipError_t launch_bwd_kind(const BwdArgs& a, bool use_worklist, hipStream
 hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
+    // a batch DECLARED dense that fills the chip: a lane per problem (bwd_lane_dense.hip; the same bits as the team kernel).
+    // Not in work-list mode: its 512-register waves need an empty SIMD each, and an empty list must cost next to nothing.
+    if (!use_worklist && g_lane_bwd.load() != 0 && bwd_lane_dense_supported(kind, a.N, a.B))
+        return launch_bwd_lane_dense(kind, a, s);
     if (bwd_small_supported(kind, a.N) && g_small_bwd.load() != 0) return launch_bwd_small(kind, a, use_worklist, s);
     if (bwd_dense_wave64_supported(kind, a.N) && g_dense_wave64.load() != 0)
         return launch_bwd_dense_wave64(kind, a, use_worklist, s);

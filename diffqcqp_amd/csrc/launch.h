@@ -351,6 +351,9 @@ bool bwd_uses_any(int kind, int N);
 int public_max_n(int kind);           // dqq_max_n
 hipError_t launch_fwd_any(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s);
 hipError_t launch_bwd_any(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);
+// lane-per-problem backward for N = 2, 4, 6, 8, QP / QCQP, whole batches declared dense (bwd_lane_dense.hip)
+bool bwd_lane_dense_supported(int kind, int N, long B);
+hipError_t launch_bwd_lane_dense(int kind, const BwdArgs& a, hipStream_t s);
 // statically sized team backward for even N <= 16, QP / QCQP (bwd_small.hip); launch_bwd_dense routes to it
 bool bwd_small_supported(int kind, int N);
 hipError_t launch_bwd_small(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);

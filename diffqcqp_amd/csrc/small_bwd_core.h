@@ -38,7 +38,11 @@ struct SmallSys {
     static constexpr int T = (M <= 8) ? 8 : (M <= 16 ? 16 : 32);              // team width
     static constexpr int LDA = (M + 1) & ~1;                                   // even: rows start 16-byte aligned
     static constexpr int LDS_DOUBLES = 2 * M * LDA + 8 * M;                    // [A_t, then K^-1], [L], vectors
+#if defined(DQQ_SMALL_WPB)
+    static constexpr int WPB = DQQ_SMALL_WPB;   // developer A/B (tools/ab_build.sh)
+#else
     static constexpr int WPB = (LDS_DOUBLES * (64 / T) * 8 * 4 <= 40 * 1024) ? 4 : 2;
+#endif
 };
 
 // Solver::iterative_refinement (Solver.cpp:15-44) for a ROWS x M matrix A_t, by a team.  a[k] = A_t[k][lane]

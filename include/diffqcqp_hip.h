@@ -182,6 +182,8 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
  *                    wave-per-problem kernel (0)
  *   "small_bwd"      general path, even N <= 16 backward (QP, QCQP): statically sized team kernel (1, default) or the
  *                    wave / team kernel with run-time sizes (0)
+ *   "lane_bwd"       general path, N = 2, 4, 6, 8 backward (QP, QCQP), DQQ_P_DENSE, B >= 16384: lane-per-problem kernel (1,
+ *                    default) or the team kernel (0).  Bit-identical results.
  *   "lane_dense"     general path, N = 2..8 forward: lane-per-problem kernel (1, default) or the
  *                    wave-per-problem kernel (0)
  *   "lane_defer"     general forward for N <= 16 (lane-per-problem kernel, the group solve inside the fused fast

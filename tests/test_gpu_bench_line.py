@@ -52,11 +52,11 @@ def test_headline_line_names_host_enqueue_and_every_kernel_inside_the_driver_pre
     rl = d["roofline"]
     for k in ("host_enqueue_us_per_step", "single_stream_ms_per_step", "kernels_sum_us", "kernel_us_qp_fwd", "kernel_us_qp_bwd",
               "kernel_us_qcqp_fwd", "kernel_us_qcqp_bwd", "region_fixed_us", "us_per_step_steady_state",
-              "ms_per_step_long_region", "step_moved_frac", "moved_frac", "kernel_us_qcqp_bwd_with_empty_drain"):
+              "ms_per_step_long_region", "step_moved_frac", "moved_frac", "b2b_us_qcqp_bwd", "b2b_us_qcqp_bwd_with_empty_drain"):
         assert isinstance(rl.get(k), float), k
     assert 0 < rl["host_enqueue_us_per_step"] < 1e3 * d["ms_per_step"] * 1.05
     assert 0 < rl["step_moved_frac"] < 1 and 0 < rl["moved_frac"] < 1
-    assert rl["kernel_us_qcqp_bwd_with_empty_drain"] > rl["kernel_us_qcqp_bwd"] * 0.9
+    assert rl["b2b_us_qcqp_bwd_with_empty_drain"] > rl["b2b_us_qcqp_bwd"] * 0.9
 
 
 def test_rccl_branch_with_one_rank():

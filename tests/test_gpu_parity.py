@@ -377,6 +377,34 @@ def test_small_dense_backward_is_bit_exact_and_matches_the_wave_kernel(oracle, o
     check_backward_exact(out[0][0], out[0][1], ref, exact=False)
 
 
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("N,B", [(8, 16384 + 77), (8, 20000), (6, 16384), (4, 16500), (2, 16384 + 1)])
+def test_lane_per_problem_backward_is_the_team_kernel_bit_for_bit(oracle, ops, kind, N, B):
+    """Dense P declared dense, B >= 16384: one lane per problem (bwd_lane_dense.hip) -- triangular loops, structural
+    zeros left out, K in LDS, the factor and the explicit inverse in registers.  Same operation order as the team kernel
+    (bwd_small.hip) and the oracle: every output and every refinement step count identical, ragged last wave included;
+    bit-exact against the oracle on the oracle's x."""
+    from diffqcqp_amd import _capi
+    d = make_problem(kind, B, N, 760 + N, "dense")
+    g = dev(d)
+    n = 3000
+    xo, _ = oracle_fwd(oracle, kind, {k: v[:n] for k, v in d.items()})
+    x = hip_fwd(ops, kind, g, layout=_capi.P_DENSE)[0]
+    x[:n] = torch.from_numpy(xo).cuda()          # the first n problems: the oracle's x, the rest: the kernel's own
+    out = {}
+    try:
+        for opt in (1, 0):
+            _capi.set_option("lane_bwd", opt)
+            out[opt] = hip_bwd(ops, kind, g, x, layout=_capi.P_DENSE)
+    finally:
+        _capi.set_option("lane_bwd", 1)
+    for a, b in zip(out[1][0], out[0][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(out[1][1], out[0][1])
+    ref = oracle_bwd(oracle, kind, {k: v[:n] for k, v in d.items()}, xo)
+    check_backward_exact([t[:n] for t in out[1][0]], out[1][1][:n], ref, exact=True)
+
+
 @pytest.mark.parametrize("kind,N,B", [("qcqp", 64, 40), ("qcqp", 50, 24), ("qcqp", 44, 24), ("box", 32, 48), ("box", 22, 30)])
 def test_reference_order_backward_beyond_the_wave_kernel(oracle, ops, kind, N, B):
     """The global-memory workgroup kernel in the reference's operation order -- the default for box 21 < N <= 32, and for
