@@ -316,6 +316,11 @@ def measure(cfg, args, ctx, light=False):
         for _ in range(k):
             fn()
         enq[0] = time.perf_counter() - t0   # the host is done enqueueing here (no synchronise yet): host-bound iff ~ el
+        # spin on the streams' completion before the synchronize() that closes the region: a blocked synchronize() wakes
+        # up ~30 us after the GPU is done (tools/probe_region_dissect.py: 1219 -> 1188 us for 20 headline steps), which is
+        # the host's scheduler, not the path being measured; the region still ends with synchronize() on both streams
+        while not (main_stream.query() and (side is None or side.query())):
+            pass
         drain()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
@@ -579,7 +584,8 @@ def measure(cfg, args, ctx, light=False):
         },
         "repeats": {"R": len(times), "ms_per_step_median": elapsed / steps * 1e3, "ms_per_step_min": times[0] / steps * 1e3,
                     "ms_per_step_max": times[-1] / steps * 1e3,
-                    "note": "R regions of exactly `steps` steps; value / ms_per_step are the median region"},
+                    "note": "R regions of exactly `steps` steps; value / ms_per_step are the median region; a region ends with "
+                            "stream.query() spin + synchronize()"},
         "roofline": roofline,
         "kernels": kernels,
         "per_gpu_value": units_per_step * steps / elapsed / world,

@@ -15,7 +15,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdiffqcqp_hip.so")
+# DQQ_LIB: developer override -- another build of the same C ABI (tools/build_variant.sh), bound with ctypes
+LIB_PATH = os.environ.get("DQQ_LIB") or os.path.join(_HERE, "lib", "libdiffqcqp_hip.so")
 PYMOD_PATH = os.path.join(_HERE, "lib", "_dqq.so")
 
 P_AUTO, P_DENSE, P_DIAG = 0, 1, 2
@@ -88,7 +89,7 @@ def lib():
     is not there."""
     global _lib, _binding
     if _lib is None:
-        want = os.environ.get("DQQ_BINDING", "")
+        want = os.environ.get("DQQ_BINDING", "") or ("ctypes" if os.environ.get("DQQ_LIB") else "")
         mod = None if want == "ctypes" else pybind_lib()
         if mod is None and want == "pybind11":
             raise RuntimeError("diffqcqp_amd: DQQ_BINDING=pybind11 but %s is not built" % PYMOD_PATH)

@@ -19,8 +19,11 @@
 // Storage per lane (QCQP, N = 8: M = 12 unknowns): the factor L (72 doubles) and the explicit inverse K^-1 (144: its two
 // triangles are computed by different operation sequences and are not bitwise symmetric, so both are kept) in registers
 // -- one wave per SIMD, 512 registers per lane --, K itself (72, read again by every refinement body) in LDS, lane-
-// interleaved (element e of lane l at (e * 64 + l) * 8: conflict-free, 36.9 KB per wave = 4 waves per CU).  K^-1 A^T b is
-// accumulated while the columns of the inverse are produced, and the first refinement body (x = 0) multiplies nothing.
+// interleaved (element e of lane l at (e * 64 + l) * 8: conflict-free, 36.9 KB per wave = 4 waves per CU), and so is A^T b
+// while the inverse is formed (the 8 slots that are left + 4 registers).  That is 326 of the 336 doubles a lane can hold
+// (512 registers + 640 B of LDS).  The first refinement body (x = 0) multiplies nothing.
+#include <utility>
+
 #include "kkt_core.h"
 #include "launch.h"
 
@@ -40,20 +43,132 @@ struct LaneSys {
         return (KIND == 1) ? (i < NC ? i : NC + i * (i + 1) / 2 - NC * (NC + 1) / 2 + j) : i * (i + 1) / 2 + j;
     }
     static constexpr int SLOTS = slot(M - 1, M - 1) + 1;
+    // What does not fit the registers waits in the lane's LDS column.  Four waves per CU (one per SIMD) leave a lane 80
+    // slots (640 B); the QCQP at N = 8 takes 160 (TWO waves per CU, see lane_ir): K, then A^T b, then the first PARK
+    // columns of the inverse.  A^T b is not touched while the inverse is formed: its LAST AB_LDS entries go to LDS, the
+    // first M - AB_LDS stay in registers.
+    static constexpr bool WIDE = (KIND == 1 && N == 8);
+    static constexpr int CAP = WIDE ? 160 : 80;
+    static constexpr int AB_LDS = (CAP - SLOTS) < M ? (CAP - SLOTS) : M;
+    static constexpr int AB_REG = M - AB_LDS;
+    static constexpr int PARK = WIDE ? (CAP - SLOTS - AB_LDS) / M : 0;     // columns of K^-1 kept in LDS
+    static constexpr int PARK0 = SLOTS + AB_LDS;                          // their first slot
+    static constexpr int LDS_SLOTS = SLOTS + AB_LDS + PARK * M;
 };
 
 // K in LDS: element e of this lane
 #define DQQ_KL(e) kl[(e) * 64]
 
+// a / b, correctly rounded, from r = RN(1 / b) (the result of an IEEE division): the product a r corrected twice by its
+// exact residual.  After the first correction the quotient is within an ulp; the second is Markstein's step, which
+// yields the correctly rounded quotient when r is the correctly rounded reciprocal.  5 FP64 instructions where the IEEE
+// sequence (scale, seed, Newton steps, fix-ups) takes ~11 -- and the factorisation divides ~280 times per problem by
+// only M different pivots.  tools/ubench/div_by_recip.hip: 2^34 pairs incl. quotients next to rounding midpoints, no
+// mismatch against a / b.  (Zero results come out as +0 where IEEE gives -0; nothing here depends on a zero's sign.
+// Pivots are sqrt(K_kk - ...) with K = A A^T + 1e-7 I: never 0 / inf on finite data; on non-finite data both forms
+// give non-finite results.)
+#ifndef DQQ_LANE_FASTDIV
+#define DQQ_LANE_FASTDIV 1
+#endif
+static DQQ_D double div_by(double a, double b, double r)
+{
+#if DQQ_LANE_FASTDIV
+    double q = a * r;
+    double e = __builtin_fma(-b, q, a);
+    q = __builtin_fma(e, r, q);
+    e = __builtin_fma(-b, q, a);
+    return __builtin_fma(e, r, q);
+#else
+    (void)r;
+    return a / b;
+#endif
+}
+
+#ifndef DQQ_LANE_PAIR
+#define DQQ_LANE_PAIR 2
+#endif
+// Columns C0 .. C0 + W - 1 of K^-1 by solveInPlace(Identity) (Solver.cpp:22-23): forward, then backward substitution, the
+// W columns side by side -- a triangular solve is one long dependent chain (66 adds + 12 quotients per substitution at
+// M = 12), and with one wave per SIMD a second, independent chain is what fills the FP64 pipeline's latency.  C0 is a
+// template argument: as a loop over the columns the compiler left this rolled and put the factor in scratch memory.
+// Finished columns go to LDS (the first S::PARK) or to Kinv.
+template <typename S, int C>
+static DQQ_D __attribute__((always_inline)) void inv_fwd_row(const double (&L)[S::M][S::M], const double (&rcp)[S::M],
+                                                             double (&y)[S::M], int i)
+{
+#pragma clang fp contract(off)
+    if (i < C) {
+        y[i] = 0.0;
+    } else if (i == C) {
+        y[i] = rcp[C];                                         // 1.0 / L[c][c]
+    } else {
+        double t = 0.0;
+#pragma unroll
+        for (int j = C; j < i; ++j)
+            if (!S::kz(i, j)) t -= L[i][j] * y[j];
+        y[i] = div_by(t, L[i][i], rcp[i]);
+    }
+}
+template <typename S>
+static DQQ_D __attribute__((always_inline)) void inv_bwd_row(const double (&L)[S::M][S::M], const double (&rcp)[S::M],
+                                                             double (&y)[S::M], int i)
+{
+#pragma clang fp contract(off)
+    double t = y[i];
+#pragma unroll
+    for (int j = i + 1; j < S::M; ++j)
+        if (!S::kz(j, i)) t -= L[j][i] * y[j];
+    y[i] = div_by(t, L[i][i], rcp[i]);
+}
+template <typename S, int C>
+static DQQ_D __attribute__((always_inline)) void inv_keep(const double (&y)[S::M], double (&Kinv)[S::M][S::M], double* kl)
+{
+#pragma unroll
+    for (int i = 0; i < S::M; ++i) {
+        if (C < S::PARK) kl[(S::PARK0 + C * S::M + i) * 64] = y[i];
+        else Kinv[i][C] = y[i];
+    }
+}
+template <typename S, int C0>
+static DQQ_D __attribute__((always_inline)) void lane_inverse_cols(const double (&L)[S::M][S::M], const double (&rcp)[S::M],
+                                                                   double (&Kinv)[S::M][S::M], double* kl)
+{
+    constexpr int M = S::M;
+    constexpr bool TWO = (DQQ_LANE_PAIR == 2) && (C0 + 1 < M);
+    constexpr int C1 = TWO ? C0 + 1 : C0;
+    double y0[M], y1[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        inv_fwd_row<S, C0>(L, rcp, y0, i);
+        if (TWO) inv_fwd_row<S, C1>(L, rcp, y1, i);
+    }
+#pragma unroll
+    for (int i = M - 1; i >= 0; --i) {
+        inv_bwd_row<S>(L, rcp, y0, i);
+        if (TWO) inv_bwd_row<S>(L, rcp, y1, i);
+    }
+    inv_keep<S, C0>(y0, Kinv, kl);
+    if (TWO) inv_keep<S, C1>(y1, Kinv, kl);
+}
+template <typename S, int... I>
+static DQQ_D __attribute__((always_inline)) void lane_inverse_all(const double (&L)[S::M][S::M], const double (&rcp)[S::M],
+                                                                  double (&Kinv)[S::M][S::M], double* kl,
+                                                                  std::integer_sequence<int, I...>)
+{
+    (lane_inverse_cols<S, I * DQQ_LANE_PAIR>(L, rcp, Kinv, kl), ...);
+}
+
 // Solver::iterative_refinement (Solver.cpp:15-44) on K = A_t^T A_t + mu I (lower triangle in the lane's LDS column) and
 // Ab = A_t^T b, in the operation order of small_bwd_core.h: team_ir.  Returns xs, the number of bodies in `steps`.
+// Ab: entries [0, AB_REG) in abr, the rest in the lane's LDS column behind K.
 template <typename S>
-static DQQ_D void lane_ir(const double* __restrict__ kl, const double (&Ab)[S::M], double (&xs)[S::M], int& steps)
+static DQQ_D void lane_ir(double* kl, const double (&abr)[S::AB_REG > 0 ? S::AB_REG : 1], double (&xs)[S::M],
+                          int& steps)
 {
 #pragma clang fp contract(off)
     constexpr int M = S::M;
     // ---- llt(), :23 -- left-looking, column by column
-    double L[M][M];
+    double L[M][M], rcp[M];   // rcp[k] = 1 / L[k][k] (IEEE): also entry (k, k) of column k of the forward substitution
 #pragma unroll
     for (int k = 0; k < M; ++k) {
         double s = 0.0;
@@ -63,6 +178,7 @@ static DQQ_D void lane_ir(const double* __restrict__ kl, const double (&Ab)[S::M
         double xk = DQQ_KL(S::slot(k, k)) - s;
         xk = sqrt(xk);
         L[k][k] = xk;
+        rcp[k] = 1.0 / xk;
 #pragma unroll
         for (int i = k + 1; i < M; ++i) {
             if (S::kz(i, k)) continue;   // (0 - 0) / xk
@@ -70,38 +186,31 @@ static DQQ_D void lane_ir(const double* __restrict__ kl, const double (&Ab)[S::M
 #pragma unroll
             for (int j = 0; j < k; ++j)
                 if (!S::kz(i, j) && !S::kz(k, j)) t += L[i][j] * L[k][j];
-            L[i][k] = (DQQ_KL(S::slot(i, k)) - t) / xk;
+            L[i][k] = div_by(DQQ_KL(S::slot(i, k)) - t, xk, rcp[k]);
         }
     }
-    // ---- solveInPlace(Identity), :22-23, column by column; K^-1 A^T b (:27) accumulated as the columns arrive
-    double Kinv[M][M], KinvAb[M];
+    // The factor (84 doubles with the reciprocal pivots) and the growing inverse (144) do not fit 512 registers together
+    // (M = 12), and what the compiler then spills it reloads in the middle of dependent chains -- with ONE wave per SIMD
+    // every such round trip to memory is paid in full: the first version of this kernel, 250 scratch accesses per lane,
+    // took 123 us for 65536 problems where the N = 6 instantiation, which fits, takes 25.  K (72) + the factor (84) + the
+    // inverse (144) + A^T b (12) are 312 of the 336 doubles a lane owns with four waves per CU -- too tight for a
+    // register allocator.  So the QCQP at N = 8 runs TWO waves per CU (80 KB of LDS each: 160 slots per lane) and parks
+    // the first PARK = 6 columns of the inverse in LDS as they are finished; the refinement bodies read them from there.
+    constexpr int PARK = S::PARK;
+    double Kinv[M][M];
+    lane_inverse_all<S>(L, rcp, Kinv, kl, std::make_integer_sequence<int, (M + DQQ_LANE_PAIR - 1) / DQQ_LANE_PAIR>{});
+    // entry (i, j) of the inverse: the parked columns from LDS
+#define DQQ_KINV(i, j) ((j) < PARK ? DQQ_KL(S::PARK0 + (j) * M + (i)) : Kinv[i][j])
+    // ---- K^-1 A^T b, :27 (the factor is dead: A^T b comes back from LDS)
+    double Ab[M], KinvAb[M];
 #pragma unroll
-    for (int i = 0; i < M; ++i) KinvAb[i] = 0.0;
+    for (int i = 0; i < M; ++i) Ab[i] = (i < S::AB_REG) ? abr[i < S::AB_REG ? i : 0] : DQQ_KL(S::SLOTS + i - S::AB_REG);
 #pragma unroll
-    for (int c = 0; c < M; ++c) {
-        double y[M];
+    for (int i = 0; i < M; ++i) {
+        double t = 0.0;
 #pragma unroll
-        for (int i = 0; i < M; ++i) {
-            if (i < c) { y[i] = 0.0; continue; }
-            double t = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-            for (int j = c; j < i; ++j)
-                if (!S::kz(i, j)) t -= L[i][j] * y[j];
-            y[i] = t / L[i][i];
-        }
-#pragma unroll
-        for (int i = M - 1; i >= 0; --i) {
-            double t = y[i];
-#pragma unroll
-            for (int j = i + 1; j < M; ++j)
-                if (!S::kz(j, i)) t -= L[j][i] * y[j];
-            y[i] = t / L[i][i];
-        }
-#pragma unroll
-        for (int i = 0; i < M; ++i) {
-            Kinv[i][c] = y[i];
-            KinvAb[i] += y[i] * Ab[c];
-        }
+        for (int j = 0; j < M; ++j) t += DQQ_KINV(i, j) * Ab[j];
+        KinvAb[i] = t;
     }
     // ---- the refinement loop, :26-41.  Lanes leave it one by one (the wave runs the longest).
 #pragma unroll
@@ -111,6 +220,9 @@ static DQQ_D void lane_ir(const double* __restrict__ kl, const double (&Ab)[S::M
     steps = 0;
     bool done = false;
     for (int it = 0; it < kIrMaxIter; ++it) {
+        // K (and the parked columns of the inverse) are read from LDS in EVERY body: without this the loads are hoisted out
+        // of the loop as invariants, into registers that are not there
+        asm volatile("" : "+v"(kl));
         if (!done) {
             steps = it + 1;
             double xn[M];
@@ -123,7 +235,7 @@ static DQQ_D void lane_ir(const double* __restrict__ kl, const double (&Ab)[S::M
                 for (int i = 0; i < M; ++i) {
                     double tmp = 0.0;
 #pragma unroll
-                    for (int j = 0; j < M; ++j) tmp += Kinv[i][j] * xs[j];
+                    for (int j = 0; j < M; ++j) tmp += DQQ_KINV(i, j) * xs[j];
                     xn[i] = kMuIr * tmp + KinvAb[i];
                 }
             }
@@ -147,6 +259,43 @@ static DQQ_D void lane_ir(const double* __restrict__ kl, const double (&Ab)[S::M
         }
         if (__all(done)) break;
     }
+#undef DQQ_KINV
+}
+
+// grad_P = -dl x^T (qcqp.py:49 / :174) of the wave's 64 problems, staged in LDS (the K area is dead) and streamed out with
+// coalesced 16-byte stores -- the tile is contiguous in memory, a lane's own matrix is N*N*8 bytes from its neighbour's.
+template <int N>
+static DQQ_D void store_grad_P_tile(double* __restrict__ smem, double* __restrict__ grad_P, long first, int nvalid,
+                                    const double (&dl)[N], const double (&xv)[N])
+{
+#pragma clang fp contract(off)
+    constexpr int NN = N * N, TS = NN + 1, CPP = NN / 2;
+    __syncthreads();   // every read of K is done
+    double* Gl = smem + (int)threadIdx.x * TS;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) Gl[i * N + j] = -(dl[i] * xv[j]);
+    __syncthreads();
+    double* Gw = grad_P + first * (long)NN;
+#pragma unroll
+    for (int k = 0; k < CPP; ++k) {
+        const int ch = k * 64 + (int)threadIdx.x;
+        const int pp = ch / CPP, w = ch % CPP;
+        if (pp < nvalid) {
+            // written once, not read again by this launch: non-temporal
+            __builtin_nontemporal_store(smem[pp * TS + 2 * w], Gw + 2 * (long)ch);
+            __builtin_nontemporal_store(smem[pp * TS + 2 * w + 1], Gw + 2 * (long)ch + 1);
+        }
+    }
+}
+
+// A^T b, entry i (a compile-time constant after unrolling): the first AB_REG in registers, the rest in LDS behind K
+template <typename S>
+static DQQ_D void set_ab(double* __restrict__ kl, double (&abr)[S::AB_REG > 0 ? S::AB_REG : 1], int i, double v)
+{
+    if (i < S::AB_REG) abr[i < S::AB_REG ? i : 0] = v;
+    else DQQ_KL(S::SLOTS + i - S::AB_REG) = v;
 }
 
 } // namespace
@@ -167,17 +316,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 
     const bool valid = slot < B;
     const long prob = valid ? slot : B - 1;   // lanes past the end redo the last problem and store nothing
 
+    // ---- load.  A lane's matrix is N*N contiguous doubles, N*N*8 bytes from its neighbour's: read lane by lane, every
+    // load instruction touches 64 cache lines for 1 KiB of data, and with the whole chip streaming that way the tiles do
+    // not stay in L1 / L2 until their remaining chunks are asked for.  The wave's tile of 64 matrices is contiguous:
+    // stream it with coalesced 16-byte loads through LDS (row stride N*N + 1 doubles: conflict-free reads), before K moves in.
+    constexpr int NN = N * N, TS = NN + 1, CPP = NN / 2;   // doubles per matrix, LDS row stride, 16-byte chunks per matrix
+    const long first = (long)blockIdx.x * 64;
+    const int nvalid = (B - first) < 64 ? (int)(B - first) : 64;
     double Pm[N][N], xv[N], gv[N], qv[N];
     {
-        const double* Pg = P + prob * (long)(N * N);
+        const double* Pw = P + first * (long)NN;
+        const int last = nvalid * CPP - 1;                     // (a ragged last tile re-reads its last chunk: no branches)
+#pragma unroll
+        for (int k = 0; k < CPP; ++k) {
+            int ch = k * 64 + (int)threadIdx.x;                // chunk of the tile
+            ch = ch < last ? ch : last;
+            const int pp = ch / CPP, w = ch % CPP;
+            const double2 t = *reinterpret_cast<const double2*>(Pw + 2 * (long)ch);
+            smem[pp * TS + 2 * w] = t.x;
+            smem[pp * TS + 2 * w + 1] = t.y;
+        }
+        __syncthreads();   // (one wave per workgroup: an LDS fence)
+        const double* Pl = smem + (valid ? (int)threadIdx.x : nvalid - 1) * TS;
 #pragma unroll
         for (int i = 0; i < N; ++i)
 #pragma unroll
-            for (int j = 0; j < N; j += 2) {
-                const double2 t = *reinterpret_cast<const double2*>(Pg + i * N + j);
-                Pm[i][j] = t.x;
-                Pm[i][j + 1] = t.y;
-            }
+            for (int j = 0; j < N; ++j) Pm[i][j] = Pl[i * N + j];
+        __syncthreads();   // the tile is in registers: K may overwrite it
 #pragma unroll
         for (int i = 0; i < N; i += 2) {
             const double2 a = *reinterpret_cast<const double2*>(x + prob * N + i);
@@ -188,7 +353,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 
             qv[i] = c.x; qv[i + 1] = c.y;
         }
     }
-    double Ab[M], xs[M];
+    double abr[S::AB_REG > 0 ? S::AB_REG : 1], xs[M];
     int steps = 0;
 
     if constexpr (KIND == 0) {
@@ -217,7 +382,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 
             double s = 0.0;                                                     // A^T b, :19
 #pragma unroll
             for (int k = 0; k < N; ++k) s += Pm[i][k] * bv[k];
-            Ab[i] = s;
+            set_ab<S>(kl, abr, i, s);
 #pragma unroll
             for (int j = 0; j <= i; ++j) {                                      // A^T A + mu I, :20-21
                 double t = 0.0;
@@ -227,21 +392,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 
                 DQQ_KL(S::slot(i, j)) = t;
             }
         }
-        lane_ir<S>(kl, Ab, xs, steps);
+        lane_ir<S>(kl, abr, xs, steps);
+        double dl[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) dl[i] = act[i] ? 0.0 : xs[i];                // :187-191
         if (valid) {
-            double* Gp = grad_P != nullptr ? grad_P + prob * (long)(N * N) : nullptr;
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const double dl = act[i] ? 0.0 : xs[i];                         // :187-191
-                if (grad_q != nullptr) grad_q[prob * N + i] = -dl;
-                if (Gp != nullptr) {
-#pragma unroll
-                    for (int j = 0; j < N; j += 2)
-                        *reinterpret_cast<double2*>(Gp + i * N + j) = make_double2(-(dl * xv[j]), -(dl * xv[j + 1]));
-                }
-            }
+            for (int i = 0; i < N; ++i)
+                if (grad_q != nullptr) grad_q[prob * N + i] = -dl[i];
             if (ir_steps != nullptr) ir_steps[prob] = steps;
         }
+        if (grad_P != nullptr) store_grad_P_tile<N>(smem, grad_P, first, nvalid, dl, xv);
     } else {
         // ---- (P l + q), :606
         double plq[N];
@@ -293,7 +454,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 
             double s = 0.0;
             s += aA[c] * gv[2 * c];
             s += aB[c] * gv[2 * c + 1];
-            Ab[c] = s;
+            set_ab<S>(kl, abr, c, s);
             double t = 0.0;
             t += aS[c] * aS[c];
             t += aA[c] * aA[c];
@@ -306,7 +467,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 
             double s = 0.0;
 #pragma unroll
             for (int j = 0; j < N; ++j) s += Pm[i][j] * gv[j];
-            Ab[NC + i] = s;
+            set_ab<S>(kl, abr, NC + i, s);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 double t = 0.0;
@@ -325,7 +486,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 
                 DQQ_KL(S::slot(NC + i, NC + j)) = t;
             }
         }
-        lane_ir<S>(kl, Ab, xs, steps);
+        lane_ir<S>(kl, abr, xs, steps);
         if (valid) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
@@ -336,18 +497,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 
                 if (gamma_out != nullptr) gamma_out[prob * NC + c] = gam[c];
                 if (dgamma_out != nullptr) dgamma_out[prob * NC + c] = dg;
             }
-            double* Gp = grad_P != nullptr ? grad_P + prob * (long)(N * N) : nullptr;
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const double dl = xs[NC + i];
-                if (grad_q != nullptr) grad_q[prob * N + i] = -dl;
-                if (Gp != nullptr) {
-#pragma unroll
-                    for (int j = 0; j < N; j += 2)
-                        *reinterpret_cast<double2*>(Gp + i * N + j) = make_double2(-(dl * xv[j]), -(dl * xv[j + 1]));
-                }
-            }
+            for (int i = 0; i < N; ++i)
+                if (grad_q != nullptr) grad_q[prob * N + i] = -xs[NC + i];
             if (ir_steps != nullptr) ir_steps[prob] = steps;
+        }
+        if (grad_P != nullptr) {
+            double dl[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) dl[i] = xs[NC + i];
+            store_grad_P_tile<N>(smem, grad_P, first, nvalid, dl, xv);
         }
     }
 }
@@ -358,7 +517,8 @@ template <int KIND, int N>
 static hipError_t launch_lane_bwd(const BwdArgs& a, hipStream_t s)
 {
     using S = LaneSys<KIND, N>;
-    const size_t lds = sizeof(double) * 64 * (size_t)S::SLOTS;
+    // the lane-interleaved K area (+ A^T b), or the staged tile of P / grad_P (stride N*N + 1), whichever is larger
+    const size_t lds = sizeof(double) * 64 * (size_t)(S::LDS_SLOTS > N * N + 1 ? S::LDS_SLOTS : N * N + 1);
     const long grid = (a.B + 63) / 64;
     return launch(bwd_lane_dense_kernel<KIND, N>, dim3((unsigned)grid), dim3(64), lds, s, a.P, a.q, a.l_n, a.mu, a.x,
                   a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.epsilon, a.ir_steps);
