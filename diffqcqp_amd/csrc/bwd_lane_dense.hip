@@ -524,11 +524,19 @@ static hipError_t launch_lane_bwd(const BwdArgs& a, hipStream_t s)
                   a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.epsilon, a.ir_steps);
 }
 
-// P declared dense, QP / QCQP, N = 2, 4, 6, 8, batches that fill the chip (a lane per problem needs 64 problems per
-// wave and a wave per SIMD: below ~16 Ki problems the team kernel's 4 problems per wave spread a small batch better)
+// P declared dense, QP / QCQP, N = 2, 4, 6, 8, batches that fill the chip: a lane per problem needs 64 problems per wave
+// and a wave per SIMD, below that the team kernel's 4 to 8 problems per wave spread a batch better.  Backward, us, team
+// / lane (tools/probe_lane_bwd.py --sweep):   QCQP N = 8: B = 16384 34 / 35, 24576 49 / 34, 32768 64 / 42, 65536 117 / 86,
+// 131072 221 / 140;  QCQP N = 6: 16384 25 / 20, 65536 79 / 26, 131072 146 / 48;  QP N = 8: 16384 20 / 19, 32768 24 / 14,
+// 65536 37 / 22, 131072 68 / 42;  QP N = 6: 65536 21 / 12;  N <= 4: launch-bound up to 65536, 131072: 46 / 25 (QCQP N = 4)
 bool bwd_lane_dense_supported(int kind, int N, long B)
 {
-    return (kind == kKindQP || kind == kKindQCQP) && (N == 2 || N == 4 || N == 6 || N == 8) && B >= 16384;
+#if defined(DQQ_LANE_BWD_MIN_B)
+    const long min_b = DQQ_LANE_BWD_MIN_B;   // developer sweep (tools/probe_lane_bwd.py --sweep)
+#else
+    const long min_b = (N == 8) ? 24576 : 16384;
+#endif
+    return (kind == kKindQP || kind == kKindQCQP) && (N == 2 || N == 4 || N == 6 || N == 8) && B >= min_b;
 }
 
 hipError_t launch_bwd_lane_dense(int kind, const BwdArgs& a, hipStream_t s)

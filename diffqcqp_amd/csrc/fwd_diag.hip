@@ -83,6 +83,12 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long tile = (long)blockIdx.x * WPB + wave;
     const long first = tile * PPW;
+#if defined(DQQ_PROBE_SCRATCH)
+    // developer probe (tools/probe_scratch_cost.py): a private segment that is never touched at run time -- what does its
+    // mere presence cost a launch?
+    volatile double junk[DQQ_PROBE_SCRATCH];
+    if (B < 0) junk[lane % DQQ_PROBE_SCRATCH] = eps;
+#endif
     if (first >= B) return; // whole wave leaves before any workgroup barrier
     DQQ_TL(0);
     const int nvalid = (B - first) < PPW ? (int)(B - first) : PPW;

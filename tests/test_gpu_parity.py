@@ -378,9 +378,9 @@ def test_small_dense_backward_is_bit_exact_and_matches_the_wave_kernel(oracle, o
 
 
 @pytest.mark.parametrize("kind", ["qp", "qcqp"])
-@pytest.mark.parametrize("N,B", [(8, 16384 + 77), (8, 20000), (6, 16384), (4, 16500), (2, 16384 + 1)])
+@pytest.mark.parametrize("N,B", [(8, 24576 + 77), (8, 30000), (6, 16384), (4, 16500), (2, 16384 + 1)])
 def test_lane_per_problem_backward_is_the_team_kernel_bit_for_bit(oracle, ops, kind, N, B):
-    """Dense P declared dense, B >= 16384: one lane per problem (bwd_lane_dense.hip) -- triangular loops, structural
+    """Dense P declared dense, B >= 16384 (N = 8: 24576): one lane per problem (bwd_lane_dense.hip) -- triangular loops, structural
     zeros left out, K in LDS, the factor and the explicit inverse in registers.  Same operation order as the team kernel
     (bwd_small.hip) and the oracle: every output and every refinement step count identical, ragged last wave included;
     bit-exact against the oracle on the oracle's x."""

@@ -14,7 +14,10 @@ def t(fn, n=20):
     b.record(); b.synchronize(); return a.elapsed_time(b) * 1e3 / n
 
 for kind in ("qcqp", "qp"):
-    for N, B in ((8, 65536), (8, 65536 + 37), (8, 262144), (6, 65536), (4, 65536), (2, 65536), (8, 16384)):
+    sizes = ((8, 65536), (8, 65536 + 37), (8, 262144), (6, 65536), (4, 65536), (2, 65536), (8, 16384))
+    if "--sweep" in sys.argv:   # where does a lane per problem start to pay?  (bwd_lane_dense_supported's thresholds)
+        sizes = tuple((N, B) for N in (8, 6, 4, 2) for B in (16384, 24576, 32768, 49152, 65536, 131072))
+    for N, B in sizes:
         d = {k: v.cuda() for k, v in make_problem(kind, B, N, 4242 + N, "dense").items()}
         if kind == "qp":
             x = ops.qp_forward(d["P"], d["q"], 1e-7, 1000, layout=1)
