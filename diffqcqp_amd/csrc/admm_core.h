@@ -105,23 +105,33 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
 
 
 #if defined(__HIPCC__) // (the solver above also compiles for the host: tests/hostcore)
-// The loop of admm_fwd_diag from iteration it0 on, over state that already exists (admm_fwd_diag_respread's second
-// phase).  Returns through the state; `iters` is the number of iterations executed in total.
+// The loop of admm_fwd_diag from iteration it0 on, over state that already exists (admm_fwd_diag_respread's later
+// phases).  Returns through the state; `iters` is the number of iterations executed in total.  lanes_at > 0: the loop is
+// also left -- with more = true on the lanes whose problems still run, and the next iteration in it_next -- once at
+// most that many lanes of the wave are still in it.
 template <int KIND, int E, class G>
 DQQ_D void admm_diag_resume(double (&M)[E], double (&Minv)[E], const double (&q)[E], double (&qp)[E], double (&l2)[E],
                             double (&u)[E], const double* rad, double& rho, double& inv_rho, double& tau_inc,
                             double& tau_dec, double& Mmin, int& rho_up, int& cpt, bool& bad, int& iters, int it0,
-                            int max_iter, double eps, double mu, int adaptive, bool valid)
+                            int max_iter, double eps, double mu, int adaptive, bool valid, int lanes_at, bool& more,
+                            int& it_next)
 {
     constexpr bool QP_LIKE = (KIND != 1);
     static_assert(KIND < 2, "QP / QCQP");
     const double *lo = nullptr, *hi = nullptr, *sg = nullptr;
     (void)lo; (void)hi; (void)sg;
+    more = false;
+    it_next = it0;
     if (valid) {
         for (int it = it0; it < max_iter; ++it) {
 #define DQQ_ADMM_ON_STOP break
 #include "admm_diag_body.inc"
 #undef DQQ_ADMM_ON_STOP
+            if (lanes_at > 0 && __popcll(__ballot(true)) <= lanes_at) {
+                more = it + 1 < max_iter;
+                it_next = it + 1;
+                break;
+            }
         }
     }
 }
@@ -139,8 +149,8 @@ DQQ_D void admm_diag_resume(double (&M)[E], double (&Minv)[E], const double (&q)
 // (xout / itout point at the tile's first problem); the others return theirs as admm_fwd_diag does.
 template <int KIND>
 DQQ_D int admm_fwd_diag_respread(const double (&p)[4], const double (&q)[4], const double* rad, double eps, double mu,
-                                 int max_iter, int adaptive, bool valid, double (&x)[4], int respread_at, double* lds,
-                                 double* __restrict__ xout, int* __restrict__ itout, bool& moved)
+                                 int max_iter, int adaptive, bool valid, double (&x)[4], int respread_at, int respread2_at,
+                                 double* lds, double* __restrict__ xout, int* __restrict__ itout, bool& moved)
 {
     constexpr int E = 4;
     using G = LaneGroup<2>;
@@ -232,14 +242,88 @@ DQQ_D int admm_fwd_diag_respread(const double (&p)[4], const double (&q)[4], con
             for (int e = 0; e < E2; ++e) { M2[e] = Minv2[e] = 1.0; q2[e] = qp2[e] = l22[e] = u2[e] = 0.0; }
         }
         double Mmin2 = fmin(M2[0], M2[1]);
-        int iters2 = it0;
+        int iters2 = it0, it_next2 = it0;
+        bool more2 = false;
         admm_diag_resume<KIND, E2, G4>(M2, Minv2, q2, qp2, l22, u2, rad2, rho2, inv_rho2, tau_inc2, tau_dec2, Mmin2,
-                                       rho_up2, cpt2, bad2, iters2, it0, max_iter, eps, mu, adaptive, valid2);
-        bad2 = G4::max(bad2 ? 1.0 : 0.0) > 0.0;
-        if (valid2) {
-            *reinterpret_cast<double2*>(xout + pl2 * 8 + 2 * (lane & 3)) =
-                bad2 ? make_double2(NAN, NAN) : make_double2(l22[0], l22[1]);
-            if (itout != nullptr && (lane & 3) == 0) itout[pl2] = iters2;
+                                       rho_up2, cpt2, bad2, iters2, it0, max_iter, eps, mu, adaptive, valid2,
+                                       4 * respread2_at, more2, it_next2);
+        const unsigned long long mm2 = __ballot(more2);
+        if (!more2) {
+            bad2 = G4::max(bad2 ? 1.0 : 0.0) > 0.0;
+            if (valid2) {
+                *reinterpret_cast<double2*>(xout + pl2 * 8 + 2 * (lane & 3)) =
+                    bad2 ? make_double2(NAN, NAN) : make_double2(l22[0], l22[1]);
+                if (itout != nullptr && (lane & 3) == 0) itout[pl2] = iters2;
+            }
+        }
+        if (mm2 != 0) { // wave-uniform
+            // ---- the last survivors (at most respread2_at <= 8 problems) move onto EIGHT lanes per problem, one coordinate
+            // per lane: what such a tail costs is its instruction count per iteration (a lone problem's wave issues one
+            // instruction every few cycles whatever its width), and the E = 1 body is about 60 % of the E = 2 body.
+            constexpr int E3 = 1;
+            using G8 = LaneGroup<8>;
+            const int s4 = lane & 3;
+            const unsigned long long firsts3 = mm2 & 0x1111111111111111ull;       // one bit per moving problem
+            const int r3 = __popcll(firsts3 & ((1ull << (lane & ~3)) - 1));
+            const int nmv3 = __popcll(firsts3);
+            const bool valid3 = lane < 8 * nmv3;
+            double* mine3 = lds + 8 * r3 + 2 * s4;     // coordinates 2 s4, 2 s4 + 1 of problem r3 -> slots 8 r3 + 2 s4, + 1
+            auto move3 = [&](const double (&a)[2], const double (&b)[2], double (&a3)[1], double (&b3)[1]) {
+                wave_lds_fence();
+                if (more2) {
+                    *reinterpret_cast<double2*>(mine3) = make_double2(a[0], a[1]);
+                    *reinterpret_cast<double2*>(mine3 + 128) = make_double2(b[0], b[1]);
+                }
+                wave_lds_fence();
+                a3[0] = lds[lane];
+                b3[0] = lds[128 + lane];
+            };
+            double M3[E3], Minv3[E3], q3[E3], qp3[E3], l23[E3], u3[E3], rad3[1];
+            move3(M2, Minv2, M3, Minv3);
+            move3(q2, qp2, q3, qp3);
+            move3(l22, u2, l23, u3);
+            wave_lds_fence();
+            if (more2) {
+                if (s4 == 0) {
+                    lds[r3] = rho2;
+                    lds[16 + r3] = inv_rho2;
+                    lds[32 + r3] = tau_inc2;
+                    lds[48 + r3] = tau_dec2;
+                    ldsi[r3] = rho_up2;
+                    ldsi[16 + r3] = cpt2;
+                    ldsi[32 + r3] = pl2;
+                    ldsi[48 + r3] = bad2 ? 1 : 0;
+                    ldsi[64] = it_next2;
+                }
+                lds[64 + 4 * r3 + s4] = rad2[0];      // lane s4 of the four holds contact s4
+            }
+            wave_lds_fence();
+            const int g3 = lane >> 3;
+            double rho3 = lds[g3], inv_rho3 = lds[16 + g3], tau_inc3 = lds[32 + g3], tau_dec3 = lds[48 + g3];
+            int rho_up3 = ldsi[g3], cpt3 = ldsi[16 + g3];
+            const int pl3 = ldsi[32 + g3];
+            bool bad3 = ldsi[48 + g3] != 0;
+            const int it03 = ldsi[64];
+            rad3[0] = lds[64 + 4 * g3 + ((lane & 7) >> 1)];
+            wave_lds_fence();
+            if (!valid3) {
+                rho3 = inv_rho3 = tau_inc3 = tau_dec3 = 1.0;
+                rad3[0] = 1.0;
+                bad3 = false;
+                M3[0] = Minv3[0] = 1.0;
+                q3[0] = qp3[0] = l23[0] = u3[0] = 0.0;
+            }
+            double Mmin3 = M3[0];
+            int iters3 = it03, it_next3 = it03;
+            bool more3 = false;
+            admm_diag_resume<KIND, E3, G8>(M3, Minv3, q3, qp3, l23, u3, rad3, rho3, inv_rho3, tau_inc3, tau_dec3, Mmin3,
+                                           rho_up3, cpt3, bad3, iters3, it03, max_iter, eps, mu, adaptive, valid3, 0, more3,
+                                           it_next3);
+            bad3 = G8::max(bad3 ? 1.0 : 0.0) > 0.0;
+            if (valid3) {
+                xout[pl3 * 8 + (lane & 7)] = bad3 ? NAN : l23[0];
+                if (itout != nullptr && (lane & 7) == 0) itout[pl3] = iters3;
+            }
         }
     }
     bad = G::max(bad ? 1.0 : 0.0) > 0.0;

@@ -9,6 +9,7 @@
 namespace dqq {
 extern std::atomic<int> g_fwd_compact;
 extern std::atomic<int> g_fwd_respread;
+extern std::atomic<int> g_fwd_respread2;
 extern std::atomic<int> g_dense_wave64;
 extern std::atomic<int> g_lane_dense;
 extern std::atomic<int> g_lane_defer;
@@ -34,6 +35,7 @@ Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback"
                       {"fuse_fallback", &g_fuse},
                       {"fwd_compact", &dqq::g_fwd_compact},
                       {"fwd_respread", &dqq::g_fwd_respread},
+                      {"fwd_respread2", &dqq::g_fwd_respread2},
                       {"dense_wave64", &dqq::g_dense_wave64},
                       {"lane_dense", &dqq::g_lane_dense},
                       {"lane_defer", &dqq::g_lane_defer},

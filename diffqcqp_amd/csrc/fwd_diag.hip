@@ -38,6 +38,9 @@ namespace dqq {
 // twice the lanes (admm_core.h admm_fwd_diag_respread; N = 8, two lanes per problem, QP / QCQP).  0 = never.
 // Results do not depend on it (bit-identical, tests/test_gpu_compaction.py).
 std::atomic<int> g_fwd_respread{16};
+// Option "fwd_respread2": once at most this many (0..8) of the re-spread problems are still iterating, they move again,
+// onto EIGHT lanes per problem (one coordinate per lane).  0 = never.  Bit-identical results.
+std::atomic<int> g_fwd_respread2{8};
 int lane_defer_for(int kind); // fwd_lane_dense.hip: the general routines' deferred refactorisation (option lane_defer)
 constexpr bool fwd_diag_respreads(int kind, int n, int lpp) { return kind < 2 && n == 8 && lpp == 2; }
 
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
                                                             int* __restrict__ ws,
                                                             double* __restrict__ pdiag_out,
                                                             unsigned char* __restrict__ flags_out, int respread_at,
-                                                            int gdefer)
+                                                            int respread2_at, int gdefer)
 {
     constexpr int E = N / LPP;       // coordinates per lane
     constexpr int PPW = 64 / LPP;    // problems per wave tile
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
     if (!solved) {
         if constexpr (RSP)
             it = admm_fwd_diag_respread<KIND>(p, qv, rad, eps, mu_prox, max_iter, adaptive, valid, xv, respread_at,
-                                              s_diag[wave], x + first * N, iters ? iters + first : nullptr, moved);
+                                              respread2_at, s_diag[wave], x + first * N, iters ? iters + first : nullptr, moved);
         else
             it = admm_fwd_diag<KIND, E, LaneGroup<LPP>>(p, qv, rad, N, eps, mu_prox, max_iter, adaptive, valid, xv, lo,
                                                         hi, sg);
@@ -259,7 +262,7 @@ static hipError_t launch_one(const FwdArgs& a, hipStream_t s)
     return launch((fwd_diag_kernel<KIND, N, LPP, WPB, FUSE, CMP>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q,
                        a.l_n, a.mu, a.v, a.x, a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.layout, a.iters, a.ws,
                        a.pdiag_out, a.flags_out, std::min(16, std::max(0, g_fwd_respread.load())),
-                       lane_defer_for(KIND));
+                       std::min(8, std::max(0, g_fwd_respread2.load())), lane_defer_for(KIND));
 }
 
 // Option "fwd_compact": 1 = repack the tiles of a workgroup as their problems stop (admm_compact.h).  OFF by

@@ -173,6 +173,9 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
  *   "fwd_respread"   diagonal fast path, N = 8 on two lanes per problem: once at most this many (0..16, default
  *                    16; 0 = never) of a wave's 32 problems are still iterating they move onto four lanes per
  *                    problem and finish with half the arithmetic per lane.  Bit-identical results.
+ *   "fwd_respread2"  the same again: once at most this many (0..8, default 8; 0 = never) of the re-spread problems are
+ *                    still iterating they move onto eight lanes per problem, one coordinate per lane (a long tail costs
+ *                    its instruction count per iteration).  Bit-identical results.
  *   "fwd_compact"    diagonal fast path, N = 8: repack the tiles of a workgroup as their problems stop (1), or
  *                    leave every tile to its wave (0, default: at the bench shape the barriers cost more than the
  *                    saved wave-iterations; it pays for heavy-tailed iteration counts).  Bit-identical results.

@@ -102,14 +102,16 @@ def test_compaction_heavy_tail_distribution():
         assert ia.max() > 60
 
 
-def _run_respread(kind, d, eps, max_iter, at, lpp=2):
+def _run_respread(kind, d, eps, max_iter, at, lpp=2, at2=0):
     from diffqcqp_amd import _capi
     _capi.set_option("fwd_respread", at)
+    _capi.set_option("fwd_respread2", at2)
     _capi.set_option("fwd_lpp", lpp)
     try:
         return _run(kind, d, eps, max_iter, 0)
     finally:
         _capi.set_option("fwd_respread", 16)  # the defaults
+        _capi.set_option("fwd_respread2", 8)
         _capi.set_option("fwd_lpp", 0)
 
 
@@ -130,6 +132,11 @@ def test_respread_bit_identical(kind, B):
             xb, ib = _run_respread(kind, d, eps, max_iter, at)
             assert np.array_equal(ia, ib), (eps, max_iter, at)
             assert np.array_equal(xa, xb, equal_nan=True), (eps, max_iter, at)
+        # the second move: the last survivors onto eight lanes per problem, one coordinate per lane ("fwd_respread2")
+        for at, at2 in ((16, 8), (16, 1), (16, 3), (7, 7), (2, 8), (12, 5)):
+            xb, ib = _run_respread(kind, d, eps, max_iter, at, at2=at2)
+            assert np.array_equal(ia, ib), (eps, max_iter, at, at2)
+            assert np.array_equal(xa, xb, equal_nan=True), (eps, max_iter, at, at2)
     assert np.isnan(xa[3::41]).all() and np.isfinite(np.delete(xa, np.s_[3::41], axis=0)).all()
 
 
@@ -143,7 +150,7 @@ def test_respread_against_oracle_and_with_dense_tiles(kind):
     d0["P"] = P
     d = {k: v.cuda() for k, v in d0.items()}
     xa, ia = _run_respread(kind, d, 1e-7, 1000, 0)
-    xb, ib = _run_respread(kind, d, 1e-7, 1000, 16)
+    xb, ib = _run_respread(kind, d, 1e-7, 1000, 16, at2=8)
     assert np.array_equal(ia, ib) and np.array_equal(xa, xb)
     n = 600
     Pn, q = d0["P"][:n].numpy(), d0["q"][:n].numpy()
