@@ -135,18 +135,21 @@ class Chain:
         t, L, p = self.sets[s], self.lib, (lambda a: a.data_ptr())
         ws = self.workspace(stream)
         wsb, B, N = ws.numel() * 4, self.B, self.N
+        # the verified-diagonal hand-off exists for DQQ_P_AUTO only (diffqcqp_amd/qcqp.py: _cache_for): a batch declared
+        # dense passes no pdiag / flags (with them the C ABI would clear the flags with a memset launch per forward)
+        pd, fl = (p(t["pdiag"]), p(t["flags"])) if self.layout == 0 else (None, None)
         if which == 0 and self.kind == "qp":
             return L.dqq_qp_fwd_f64, (p(t["P"]), p(t["q"]), p(t["x"]), B, N, EPS, MU_PROX, MAX_ITER, 1, self.layout, None,
-                                      p(t["pdiag"]), p(t["flags"]), p(ws), wsb, stream)
+                                      pd, fl, p(ws), wsb, stream)
         if which == 0:
             return L.dqq_qcqp_fwd_f64, (p(t["P"]), p(t["q"]), p(t["l_n"]), p(t["mu"]), p(t["x"]), B, N, EPS, MU_PROX,
-                                        MAX_ITER, 1, self.layout, None, p(t["pdiag"]), p(t["flags"]), p(ws), wsb, stream)
+                                        MAX_ITER, 1, self.layout, None, pd, fl, p(ws), wsb, stream)
         if self.kind == "qp":
             return L.dqq_qp_bwd_f64, (p(t["P"]), p(t["q"]), p(t["x"]), p(t["g"]), p(t["gP"]), p(t["gq"]), B, N, 1e-10,
-                                      self.layout, None, p(t["pdiag"]), p(t["flags"]), p(ws), wsb, stream)
+                                      self.layout, None, pd, fl, p(ws), wsb, stream)
         return L.dqq_qcqp_bwd_f64, (p(t["P"]), p(t["q"]), p(t["l_n"]), p(t["mu"]), p(t["x"]), p(t["g"]), p(t["gP"]),
                                     p(t["gq"]), p(t["gl"]), p(t["gm"]), None, None, B, N, 1e-10, self.layout, None,
-                                    p(t["pdiag"]), p(t["flags"]), p(ws), wsb, stream)
+                                    pd, fl, p(ws), wsb, stream)
 
     def launch(self, which, stream, s=0):
         key = (which, stream, s)
