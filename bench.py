@@ -288,11 +288,11 @@ def measure(cfg, args, ctx, light=False):
 
     def step(s=0):
         """One pass of the hot path over this rank's batch (all chains; set s of each)."""
-        if side is not None:  # interleave so that both streams are fed
-            chains[0].launch(0, streams[0], s)
+        if side is not None:  # interleave so that both streams are fed; the longer chain (the QCQP) first
             chains[1].launch(0, streams[1], s)
-            chains[0].launch(1, streams[0], s)
+            chains[0].launch(0, streams[0], s)
             chains[1].launch(1, streams[1], s)
+            chains[0].launch(1, streams[0], s)
         else:
             for c in chains:
                 c.run(sh, s)

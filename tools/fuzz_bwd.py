@@ -18,6 +18,8 @@ for t in range(trials):
     N = int(rng.choice([2, 4, 8, 16, 32] if len(sys.argv) <= 3 else [2, 3, 5, 6, 8, 10, 12, 16, 17, 20, 22, 24, 32, 33, 40, 44, 48, 56, 64, 70]))
     if kind == "qcqp" and N % 2: N += 1
     B = int(rng.choice([1, 5, 16, 17, 64, 130, 1000, 2049]))
+    if N <= 8 and kind != "box" and rng.integers(8) == 0:
+        B = int(rng.choice([16384, 16421, 24576, 24700, 33001]))   # the lane-per-problem backward (bwd_lane_dense.hip, DQQ_P_DENSE)
     if N >= 32: B = min(B, 130 if N == 32 else 17)
     if N > 16 and kind == 'box': B = min(B, 17)
     structure = str(rng.choice(["diag", "dense", "mixed", "nonsym"]))
@@ -25,7 +27,7 @@ for t in range(trials):
     if N not in (2, 4, 8, 16, 32, 64) and structure == "diag": structure = "dense"
     opts = {"fuse_fallback": int(rng.choice([-1, 0, 1])), "wpb": int(rng.choice([0, 1, 4])),
             "small_bwd": int(rng.choice([0, 1])), "dense_teams": int(rng.choice([0, 1])),
-            "dense_wave64": int(rng.choice([0, 1])), "wave_qcqp_bwd": int(rng.choice([0, 1]))}
+            "dense_wave64": int(rng.choice([0, 1])), "wave_qcqp_bwd": int(rng.choice([0, 1])), "lane_bwd": int(rng.choice([0, 1, 1]))}
     use_cache = bool(rng.integers(2)) and layout == 0
     d = make_problem(kind, B, N, 7000 + t, "dense" if structure == "nonsym" else structure)
     if structure == "nonsym":
@@ -70,5 +72,5 @@ for t in range(trials):
     if not ok:
         bad += 1
         print("FAIL", t, kind, N, B, structure, layout, opts, "cache", use_cache, "rel %.2e exits equal %.3f finite %s" % (rel, same.mean(), finite), flush=True)
-for k, v in {"fuse_fallback": -1, "wpb": 0, "small_bwd": 1, "dense_teams": 1, "dense_wave64": 1, "wave_qcqp_bwd": 1}.items(): _capi.set_option(k, v)
+for k, v in {"fuse_fallback": -1, "wpb": 0, "small_bwd": 1, "dense_teams": 1, "dense_wave64": 1, "wave_qcqp_bwd": 1, "lane_bwd": 1}.items(): _capi.set_option(k, v)
 print("%d trials, %d failures, worst rel err %.2e" % (trials, bad, worst))

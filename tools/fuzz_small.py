@@ -32,7 +32,8 @@ for t in range(trials):
     opts = {"fwd_lpp": int(rng.choice([0] + LPP.get(N, []))), "dense_wave64": int(rng.choice([0, 1])),
             "lane_dense": int(rng.choice([0, 1])), "small_fwd": int(rng.choice([0, 1])), "fuse_fallback": int(rng.choice([-1, 0, 1])),
             "fwd_compact": int(rng.choice([0, 1])), "wpb": int(rng.choice([0, 1, 4])),
-            "lane_defer": int(rng.choice([0, 1, 3, 7])), "fwd_respread": int(rng.choice([0, 5, 16]))}
+            "lane_defer": int(rng.choice([0, 1, 3, 7])), "fwd_respread": int(rng.choice([0, 5, 16])),
+            "fwd_respread2": int(rng.choice([0, 3, 8]))}
     d = make_problem(kind, B, N, 9000 + t, "dense" if structure == "nonsym" else structure)
     if structure == "nonsym":
         g = torch.Generator().manual_seed(t)
@@ -63,5 +64,5 @@ for t in range(trials):
         bad += 1
         print("FAIL", t, kind, N, B, structure, layout, eps, max_iter, opts, "err %.2e iters equal %.4f" % (err, same), flush=True)
 for k, v in {"fwd_lpp": 0, "fuse_fallback": -1, "fwd_compact": 0, "wpb": 0, "dense_wave64": 1, "lane_dense": 1,
-             "small_fwd": 1, "lane_defer": 0, "fwd_respread": 16}.items(): _capi.set_option(k, v)
+             "small_fwd": 1, "lane_defer": 0, "fwd_respread": 16, "fwd_respread2": 8}.items(): _capi.set_option(k, v)
 print("%d trials, %d failures, worst |dx| %.2e" % (trials, bad, worst))
