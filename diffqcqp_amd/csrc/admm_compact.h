@@ -196,6 +196,8 @@ DQQ_D void admm_fwd_diag_compact(const double (&p)[E], const double (&q_in)[E], 
                 inv_rho = sh.state[k++][slot];
                 tau_inc = sh.state[k++][slot];
                 tau_dec = sh.state[k++][slot];
+                itau_inc = fast_rcp(tau_inc);
+                itau_dec = fast_rcp(tau_dec);
                 Mmin = sh.state[k++][slot];
                 idx = __double_as_longlong(sh.state[k++][slot]);
                 const int packed = (int)__double_as_longlong(sh.state[k++][slot]);

@@ -122,6 +122,7 @@ DQQ_D void admm_diag_resume(double (&M)[E], double (&Minv)[E], const double (&q)
     (void)lo; (void)hi; (void)sg;
     more = false;
     it_next = it0;
+    double itau_inc = fast_rcp(tau_inc), itau_dec = fast_rcp(tau_dec);   // (state of the body; a function of the taus)
     if (valid) {
         for (int it = it0; it < max_iter; ++it) {
 #define DQQ_ADMM_ON_STOP break

@@ -250,6 +250,7 @@ DQQ_D int group_dense_fwd(const double* __restrict__ Pg, const double (&q)[N / L
     G::pow_pair(L / mu, p40, p15);
     double rho = sqrt(mu * L) * p40;
     double tau_inc = p15, tau_dec = tau_inc;
+    double itau_inc = fast_rcp(tau_inc), itau_dec = itau_inc;   // (admm_diag_body.inc: the reciprocals are state)
     double inv_rho = fast_rcp(rho);
     bool bad = !(rho > 0.0) || !(rho < 1.79e308);
     double qp[E], l2[E], u[E];
