@@ -520,6 +520,11 @@ static hipError_t launch_lane_bwd(const BwdArgs& a, hipStream_t s)
     // the lane-interleaved K area (+ A^T b), or the staged tile of P / grad_P (stride N*N + 1), whichever is larger
     const size_t lds = sizeof(double) * 64 * (size_t)(S::LDS_SLOTS > N * N + 1 ? S::LDS_SLOTS : N * N + 1);
     const long grid = (a.B + 63) / 64;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_lane_dense_kernel<KIND, N>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     return launch(bwd_lane_dense_kernel<KIND, N>, dim3((unsigned)grid), dim3(64), lds, s, a.P, a.q, a.l_n, a.mu, a.x,
                   a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.epsilon, a.ir_steps);
 }
