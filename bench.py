@@ -27,8 +27,10 @@ on both sides and reduced with MAX over the ranks; `ms_per_step` / `value` are t
 Default run (no --config): on ONE GPU the headline step, followed by short runs of BASELINE configs 2, 3, 4, 5
 (`per_config`: 3 regions each, dominant kernel, roofline fractions, CPU baseline) and the dense-P check (`dense_p_n8`),
 so that one driver-run line carries every workload.  Under torch.distributed.run (WORLD_SIZE set; any number of
-ranks) the line is configs[3] -- the batch SPLIT over the ranks, RCCL all-gather of x, with and without the gather --
-and the weak-scaling headline is the sub-record `weak_headline`.
+ranks) the line is the SAME headline step on every rank (weak scaling, no data-path collective: value(N) / (N value(1)) is
+the scaling efficiency); `with_gather` = the same step with the path's optional exchange step -- the RCCL all-gather of both
+families' x, behind their forwards, beside their backwards --, and configs[3], the batch SPLIT over the ranks (strong
+scaling, with / without / serialised gather), is the sub-record `strong_config4`.
 
 Rank 0 prints ONE JSON line.  Besides the contract keys:
   roofline      the launch with the largest mean duration: algorithmic bytes / its duration from
@@ -265,7 +267,12 @@ def measure(cfg, args, ctx, light=False):
         B_rank = hi - lo
     else:
         B_rank = B_total
-    gather = cfg == 4                  # the path's one exchange step
+    # the path's one exchange step: the all-gather of x.  configs[3] (the batch SPLIT over the ranks) carries
+    # it in `value`; the headline (weak scaling: every rank its own B problems per family -- the solve itself needs no
+    # collective) is also timed with it when the run is distributed: `with_gather`
+    gather = cfg == 4
+    gather_extra = cfg == 0 and use_dist
+    B_gather = B_total if scaling == "strong" else B_rank * world      # rows of a gathered x
     steps, repeats, warmup = max(args.steps, 1), max(args.repeats, 1), max(args.warmup, 1)
     if cfg == 5 and args.steps == 100 and args.repeats == 10:
         steps, repeats = 5, 5          # a step is ~6 ms of a 4.3 GB working set: bound the default run
@@ -280,11 +287,13 @@ def measure(cfg, args, ctx, light=False):
     sh = main_stream.cuda_stream
     side = ctx["side"] if (len(chains) == 2 and args.streams == 2) else None
     streams = [sh, side.cuda_stream if side is not None else sh]
-    x_all = gather_scratch = None
-    if gather and use_dist:   # the exchange step's buffers are the caller's: nothing is allocated inside a timed step
-        x_all = torch.empty((B_total, families[0][1], 1), dtype=F64, device=dev)
-        rows = parallel.gather_scratch_rows(B_total, world)
-        gather_scratch = torch.empty((rows, families[0][1], 1), dtype=F64, device=dev) if rows else None
+    tstreams = [main_stream, side if side is not None else main_stream]   # the torch stream each chain is launched on
+    x_all, gather_scratch = [None] * len(chains), [None] * len(chains)
+    if (gather or gather_extra) and use_dist:   # the exchange step's buffers are the caller's: nothing is allocated inside a timed step
+        rows = parallel.gather_scratch_rows(B_gather, world)
+        for i, c in enumerate(chains):
+            x_all[i] = torch.empty((B_gather, c.N, 1), dtype=F64, device=dev)
+            gather_scratch[i] = torch.empty((rows, c.N, 1), dtype=F64, device=dev) if rows else None
 
     def step(s=0):
         """One pass of the hot path over this rank's batch (all chains; set s of each)."""
@@ -335,27 +344,36 @@ def measure(cfg, args, ctx, light=False):
         enq_log.append((el, enq[0], k))
         return el
 
+    def gather_x(i, async_op):
+        """All-gather of chain i's x, ordered behind the work already enqueued on that chain's stream (RCCL synchronises
+        with torch's CURRENT stream: the side chain's collective is issued with its stream current)."""
+        with torch.cuda.stream(tstreams[i]):
+            return parallel.gather_batch(chains[i].sets[0]["x"], B_gather, async_op=async_op, out=x_all[i],
+                                         scratch=gather_scratch[i])
+
     def step_and_gather_serial():
-        nonlocal x_all
         step()
         if use_dist:
-            parallel.gather_batch(chains[0].sets[0]["x"], B_total, out=x_all, scratch=gather_scratch)
-        else:
-            x_all = chains[0].sets[0]["x"]
+            for i in range(len(chains)):
+                gather_x(i, False)
 
     def step_and_gather():
         """The path's one exchange step where it belongs: x is complete after the FORWARD, so its all-gather (RCCL's own
         stream, ordered behind the forward) travels over xGMI while the backward of the same problems runs -- the
-        backward needs this rank's x only.  The step ends when both are done (the launch stream waits for the
-        collective)."""
-        nonlocal x_all
+        backward needs this rank's x only.  The step ends when both are done (the launch streams wait for the
+        collectives)."""
         if not use_dist:
-            return step_and_gather_serial()
-        chains[0].launch(0, sh)
-        _, work = parallel.gather_batch(chains[0].sets[0]["x"], B_total, async_op=True, out=x_all, scratch=gather_scratch)
-        for w in range(1, len(chains[0].names)):
-            chains[0].launch(w, sh)
-        work.wait()
+            return step()
+        order = list(range(len(chains)))[::-1]        # the longer chain (the QCQP of the headline) first
+        for i in order:
+            chains[i].launch(0, streams[i])
+        works = [(i, gather_x(i, True)[1]) for i in order]
+        for i in order:
+            for w in range(1, len(chains[i].names)):
+                chains[i].launch(w, streams[i])
+        for i, work in works:
+            with torch.cuda.stream(tstreams[i]):
+                work.wait()
 
     timed = step_and_gather if gather else step
 
@@ -432,27 +450,38 @@ def measure(cfg, args, ctx, light=False):
     # regions of 5K steps: T(K) = F + s K from the two medians (the driver times --steps 20, the
     # builder's profiles used to time --steps 100; the fixed ~90 us of a region are 8 % of the former, 1.6 % of the latter)
     region_fit = None
-    if not light and not gather:
+    if not light and cfg != 4:
         kl = 5 * steps
         tl = sorted(region(timed, kl) for _ in range(3))[1]
         s_fit = (tl - elapsed) / (kl - steps)
         region_fit = {"long_region_steps": kl, "ms_per_step_long_region": tl / kl * 1e3,
                       "us_per_step_steady_state": s_fit * 1e6, "region_fixed_us": (elapsed - steps * s_fit) * 1e6}
-    if gather and use_dist:
-        torch.cuda.synchronize()
-        lo_r, hi_r = parallel.shard_bounds(B_total, rank, world)
-        assert x_all.shape[0] == B_total and torch.equal(x_all[lo_r:hi_r], chains[0].sets[0]["x"]), "all-gather of x"
     extra = {}
+    units_per_step_all = B_total if scaling == "strong" else sum(c.B for c in chains) * world
+    if gather_extra:   # the same regions WITH the exchange step: all-gather of every family's x behind its forward
+        for _ in range(3):
+            step_and_gather()
+        tw = sorted(region(step_and_gather, steps) for _ in range(max(repeats // 2, 1)))
+        extra["with_gather"] = {"ms_per_step": tw[len(tw) // 2] / steps * 1e3, "value": units_per_step_all * steps / tw[len(tw) // 2],
+                                "allgather_bytes_per_rank": sum(c.B * c.N * 8 for c in chains),
+                                "rccl_world": dist.get_world_size(),
+                                "note": "x of every rank all-gathered in every step (one collective per family, behind its forward, "
+                                        "beside its backward); two torch.distributed calls per 56 us step: host-side cost included"}
+    if (gather or gather_extra) and use_dist:
+        torch.cuda.synchronize()
+        lo_r, hi_r = parallel.shard_bounds(B_gather, rank, world)
+        for i, c in enumerate(chains):
+            assert x_all[i].shape[0] == B_gather and torch.equal(x_all[i][lo_r:hi_r], c.sets[0]["x"]), "all-gather of x"
     if gather and use_dist:   # the same regions with the gather behind the whole step instead of beside the backward
         tg = sorted(region(step_and_gather_serial, steps) for _ in range(max(repeats // 2, 1)))
         extra["gather_after_backward"] = {"ms_per_step": tg[len(tg) // 2] / steps * 1e3,
-                                          "value": B_total * steps / tg[len(tg) // 2],
+                                          "value": units_per_step_all * steps / tg[len(tg) // 2],
                                           "note": "all-gather of x serialised behind the backward"}
     if gather:   # the same regions without the exchange step
         tn = sorted(region(step, steps) for _ in range(max(repeats // 2, 1)))
         extra["without_gather"] = {"ms_per_step": tn[len(tn) // 2] / steps * 1e3,
-                                   "value": B_total * steps / tn[len(tn) // 2],
-                                   "allgather_bytes_per_rank": B_rank * families[0][1] * 8,
+                                   "value": units_per_step_all * steps / tn[len(tn) // 2],
+                                   "allgather_bytes_per_rank": sum(c.B * c.N * 8 for c in chains),
                                    "rccl_world": dist.get_world_size() if use_dist else 1}
     if side is not None and not light:   # context: the same steps strictly on one stream
         save, side = side, None
@@ -587,8 +616,10 @@ def measure(cfg, args, ctx, light=False):
             "p_layout": ("dense (declared)" if chains[0].layout == 1 else
                          "auto (off-diagonals verified in-kernel; non-diagonal tiles go to the general kernel)"),
             "launch": "eager, one C-ABI call per pass" + (", the two families on two streams" if side is not None else ""),
-            "sharding": ("batch split over the ranks, no data-path collective; RCCL all-gather of x per step, issued after the forward and overlapped with the backward"
-                         if gather else ("batch shards, no collective" if world > 1 else "single GPU")),
+            "sharding": (("batch split over the ranks" if scaling == "strong" else "every rank its own batch (weak scaling)") +
+                         ", no data-path collective; RCCL all-gather of x per step, issued after the forward and overlapped with the backward"
+                         if (gather and use_dist) else ("every rank its own batch (weak scaling), no data-path collective; the optional "
+                                                         "all-gather of x is timed separately: with_gather" if use_dist else "single GPU")),
             "rccl_world": dist.get_world_size() if use_dist else 1,
         },
         "repeats": {"R": len(times), "ms_per_step_median": elapsed / steps * 1e3, "ms_per_step_min": times[0] / steps * 1e3,
@@ -755,8 +786,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=None, choices=(0, 2, 3, 4, 5, 6, 7),
                     help="BASELINE.json configs entry (1-based); 0 = the headline step (configs 2'+3).  Default: the "
-                         "headline on one GPU; with WORLD_SIZE > 1, configs[3] (the batch split over the ranks + RCCL "
-                         "all-gather) with the weak-scaling headline as a sub-record")
+                         "headline (distributed: on every rank, weak scaling; with_gather = with the RCCL all-gather of x) and "
+                         "configs[3] (the batch split over the ranks) as the sub-record strong_config4")
     ap.add_argument("--repeats", type=int, default=10, help="timed regions of exactly --steps steps; the median is reported")
     ap.add_argument("--streams", type=int, default=2, choices=(1, 2),
                     help="headline only: 2 = the QP chain and the QCQP chain on two HIP streams")
@@ -804,17 +835,20 @@ def main():
            "capi": _capi, "side": torch.cuda.Stream()}
 
     default_run = args.config is None
-    # With more than one rank (or under torch.distributed.run) and no --config, the line is the workload north_star
-    # names for multi-GPU: configs[3], B=262144 N=32 split over the ranks with the RCCL all-gather of x
-    primary = args.config if args.config is not None else (4 if launched or world > 1 else 0)
+    # No --config: the headline step, on one GPU and on N (round 4: ONE workload across the driver's N = 1, 2, 4, 8 lines, so
+    # that value(N) / (N value(1)) is a scaling efficiency; the solve needs no collective).  Distributed, the same step is also
+    # timed with the path's optional exchange step (`with_gather`), and configs[3], the batch SPLIT over the ranks with the
+    # all-gather of x (strong scaling), is the sub-record `strong_config4`.
+    primary = args.config if args.config is not None else 0
     out = measure(primary, args, ctx)
     if default_run:
-        if primary == 4:
-            sub = measure(0, args, ctx, light=True)
+        if use_dist:
+            sub = measure(4, args, ctx, light=True)
             if rank == 0:
-                out["weak_headline"] = condensed(sub)
-                out["weak_headline"]["note"] = "per GPU and step: the single-GPU headline workload on every rank, no " \
-                                               "collective (weak scaling); value = all ranks"
+                out["strong_config4"] = condensed(sub)
+                out["strong_config4"]["note"] = "BASELINE configs[3]: B=262144 N=32 split over the ranks, all-gather of x " \
+                                                "behind the forward (strong scaling); N=1 reference: per_config.config_4 of a plain run"
+                out["config"].update(flat_summary("strong_cfg4", out["strong_config4"]))
         elif not args.no_per_config:
             per = {}
             for cfg in (2, 3, 4, 5):
@@ -834,8 +868,9 @@ def main():
                                   "ref_figure_qp_fwd_ms_bench_eps": ex["reference_figure_workload"]["qp_fwd_ms_eps1e-7_maxiter1000"],
                                   "ref_figure_qcqp_fwd_ms_bench_eps": ex["reference_figure_workload"]["qcqp_fwd_ms_eps1e-7_maxiter1000"]})
     if rank == 0:
-        out["scaling_note"] = ("N=1: `value` = headline (weak), strong scaling of configs[3] = per_config.config_4; N>1: `value` = "
-                               "configs[3] split over the ranks (strong), weak headline = weak_headline.value")
+        out["scaling_note"] = ("`value` = the headline step on every rank (weak scaling, no collective; with_gather = with the "
+                               "all-gather of x); configs[3] split over the ranks (strong scaling) = strong_config4 (N>1) / "
+                               "per_config.config_4 (plain N=1 run)")
         out["environment"] = gpu_environment()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:

@@ -79,3 +79,26 @@ def test_rccl_branch_with_one_rank():
     assert d["without_gather"]["allgather_bytes_per_rank"] == 262144 * 32 * 8
     # the gather is the identity at one rank: the three rates must agree within a few percent
     assert d["ms_per_step"] < 1.15 * d["without_gather"]["ms_per_step"]
+
+
+def test_distributed_default_line_is_the_headline_with_the_gather():
+    """What the driver's scaling command prints (no --config, RCCL initialised): the SAME headline workload as the N = 1 line
+    -- so that value(N) / (N value(1)) is a scaling efficiency --, `with_gather` = the same step with the all-gather of both
+    families' x, and configs[3] (strong scaling) as the sub-record `strong_config4`.  One rank here."""
+    env = dict(os.environ, DQQ_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29578")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
+                        "--repeats", "2", "--no-cpu-baseline", "--no-cold"], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["scaling"] == "weak" and d["config"]["rccl_world"] == 1 and d["config"]["B_total"] == 131072
+    assert "weak scaling" in d["config"]["sharding"]
+    wg = d["with_gather"]
+    assert wg["ms_per_step"] >= 0.9 * d["ms_per_step"] and wg["allgather_bytes_per_rank"] == 2 * 65536 * 8 * 8 and wg["rccl_world"] == 1
+    s4 = d["strong_config4"]
+    assert s4["without_gather"]["rccl_world"] == 1 and s4["gather_after_backward"]["ms_per_step"] > 0
+    assert d["config"]["strong_cfg4_ms_per_step"] == s4["ms_per_step"]
