@@ -16,12 +16,14 @@
 // +-0, and a running sum that started at +0.0 is never -0.0, so leaving them out changes no bit (finite data).  The
 // results are bit-identical to the team kernel's and to the oracle's on identical x (tests/test_gpu_parity.py).
 //
-// Storage per lane (QCQP, N = 8: M = 12 unknowns): the factor L (72 doubles) and the explicit inverse K^-1 (144: its two
-// triangles are computed by different operation sequences and are not bitwise symmetric, so both are kept) in registers
-// -- one wave per SIMD, 512 registers per lane --, K itself (72, read again by every refinement body) in LDS, lane-
-// interleaved (element e of lane l at (e * 64 + l) * 8: conflict-free, 36.9 KB per wave = 4 waves per CU), and so is A^T b
-// while the inverse is formed (the 8 slots that are left + 4 registers).  That is 326 of the 336 doubles a lane can hold
-// (512 registers + 640 B of LDS).  The first refinement body (x = 0) multiplies nothing.
+// Storage per lane (QCQP, N = 8: M = 12 unknowns): the factor L (72 doubles + 12 reciprocal pivots) and the explicit inverse
+// K^-1 (144: its two triangles are computed by different operation sequences and are not bitwise symmetric, so both are
+// kept) do not fit 512 registers together, K itself (72) is read again by every refinement body, and a lane owns 336 doubles
+// (512 registers + 640 B of LDS at four waves per CU).  Any spill is poison at one wave per SIMD (see lane_ir).  So: K is
+// built into LDS (lane-interleaved: element e of lane l at (e * 64 + l) * 8, conflict-free) for the factorisation; while the
+// inverse is formed its slots take the first six columns of the inverse; then K is built a SECOND time, column by column of P
+// straight from L2, into the registers the dead factor leaves (qcqp_rebuild_K: the same sums in the same order, the same bits).
+// A^T b waits in the 8 slots that are left + 4 registers.  The first refinement body (x = 0) multiplies nothing.
 #include <utility>
 
 #include "kkt_core.h"
@@ -47,13 +49,21 @@ struct LaneSys {
     // slots (640 B); the QCQP at N = 8 takes 160 (TWO waves per CU, see lane_ir): K, then A^T b, then the first PARK
     // columns of the inverse.  A^T b is not touched while the inverse is formed: its LAST AB_LDS entries go to LDS, the
     // first M - AB_LDS stay in registers.
-    static constexpr bool WIDE = (KIND == 1 && N == 8);
+#ifndef DQQ_LANE_REGEN
+#define DQQ_LANE_REGEN 1
+#endif
+    // REGEN (the QCQP at N = 8): K is needed by the factorisation and, much later, by the refinement bodies -- in between, while
+    // the inverse is formed, its 72 LDS slots hold the first PARK = 6 columns of the inverse, and K is built a SECOND time
+    // (same code, same bits: ~1000 instructions and a re-read of the inputs out of L2) into the registers the dead factor
+    // leaves behind.  80 slots per lane = four waves per CU; with K kept (WIDE: 160 slots) only two waves fit a CU.
+    static constexpr bool REGEN = (DQQ_LANE_REGEN != 0) && (KIND == 1 && N == 8);
+    static constexpr bool WIDE = (KIND == 1 && N == 8) && !REGEN;
     static constexpr int CAP = WIDE ? 160 : 80;
     static constexpr int AB_LDS = (CAP - SLOTS) < M ? (CAP - SLOTS) : M;
     static constexpr int AB_REG = M - AB_LDS;
-    static constexpr int PARK = WIDE ? (CAP - SLOTS - AB_LDS) / M : 0;     // columns of K^-1 kept in LDS
-    static constexpr int PARK0 = SLOTS + AB_LDS;                          // their first slot
-    static constexpr int LDS_SLOTS = SLOTS + AB_LDS + PARK * M;
+    static constexpr int PARK = WIDE ? (CAP - SLOTS - AB_LDS) / M : (REGEN ? SLOTS / M : 0);   // columns of K^-1 kept in LDS
+    static constexpr int PARK0 = REGEN ? 0 : SLOTS + AB_LDS;              // their first slot (REGEN: over the dead K)
+    static constexpr int LDS_SLOTS = REGEN ? SLOTS + AB_LDS : SLOTS + AB_LDS + PARK * M;
 };
 
 // K in LDS: element e of this lane
@@ -161,9 +171,12 @@ static DQQ_D __attribute__((always_inline)) void lane_inverse_all(const double (
 // Solver::iterative_refinement (Solver.cpp:15-44) on K = A_t^T A_t + mu I (lower triangle in the lane's LDS column) and
 // Ab = A_t^T b, in the operation order of small_bwd_core.h: team_ir.  Returns xs, the number of bodies in `steps`.
 // Ab: entries [0, AB_REG) in abr, the rest in the lane's LDS column behind K.
-template <typename S>
+struct NoRegen {
+    template <typename T> DQQ_D void operator()(T&) const {}
+};
+template <typename S, typename Regen = NoRegen>
 static DQQ_D void lane_ir(double* kl, const double (&abr)[S::AB_REG > 0 ? S::AB_REG : 1], double (&xs)[S::M],
-                          int& steps)
+                          int& steps, Regen regen = Regen())
 {
 #pragma clang fp contract(off)
     constexpr int M = S::M;
@@ -192,13 +205,17 @@ static DQQ_D void lane_ir(double* kl, const double (&abr)[S::AB_REG > 0 ? S::AB_
     // The factor (84 doubles with the reciprocal pivots) and the growing inverse (144) do not fit 512 registers together
     // (M = 12), and what the compiler then spills it reloads in the middle of dependent chains -- with ONE wave per SIMD
     // every such round trip to memory is paid in full: the first version of this kernel, 250 scratch accesses per lane,
-    // took 123 us for 65536 problems where the N = 6 instantiation, which fits, takes 25.  K (72) + the factor (84) + the
-    // inverse (144) + A^T b (12) are 312 of the 336 doubles a lane owns with four waves per CU -- too tight for a
-    // register allocator.  So the QCQP at N = 8 runs TWO waves per CU (80 KB of LDS each: 160 slots per lane) and parks
-    // the first PARK = 6 columns of the inverse in LDS as they are finished; the refinement bodies read them from there.
+    // took 123 us for 65536 problems where the N = 6 instantiation, which fits, takes 25.  The first PARK = 6 columns of the
+    // inverse are parked in LDS as they are finished (the refinement bodies read them from there).  Where that LDS comes from:
+    // WIDE -- 160 slots per lane, two waves per CU, K stays in LDS: 87 us per 65536; REGEN (default) -- the columns go over
+    // the dead K's slots, four waves per CU, and K is rebuilt into registers after the inverse (`regen`): 69 us.
     constexpr int PARK = S::PARK;
     double Kinv[M][M];
     lane_inverse_all<S>(L, rcp, Kinv, kl, std::make_integer_sequence<int, (M + DQQ_LANE_PAIR - 1) / DQQ_LANE_PAIR>{});
+    // REGEN: the factor is dead, K comes back -- into registers
+    double Kreg[S::REGEN ? S::SLOTS : 1];
+    if constexpr (S::REGEN) regen(Kreg);
+#define DQQ_KENT(a, b) (S::REGEN ? Kreg[S::REGEN ? S::slot(a, b) : 0] : DQQ_KL(S::slot(a, b)))
     // entry (i, j) of the inverse: the parked columns from LDS
 #define DQQ_KINV(i, j) ((j) < PARK ? DQQ_KL(S::PARK0 + (j) * M + (i)) : Kinv[i][j])
     // ---- K^-1 A^T b, :27 (the factor is dead: A^T b comes back from LDS)
@@ -250,7 +267,7 @@ static DQQ_D void lane_ir(double* kl, const double (&abr)[S::AB_REG > 0 ? S::AB_
 #pragma unroll
                 for (int j = 0; j < M; ++j) {
                     const int a = i > j ? i : j, b = i > j ? j : i;
-                    if (!S::kz(a, b)) d += DQQ_KL(S::slot(a, b)) * xs[j];
+                    if (!S::kz(a, b)) d += DQQ_KENT(a, b) * xs[j];
                 }
                 d = d - Ab[i];
                 ss += d * d;                                                    // :31
@@ -260,6 +277,7 @@ static DQQ_D void lane_ir(double* kl, const double (&abr)[S::AB_REG > 0 ? S::AB_
         if (__all(done)) break;
     }
 #undef DQQ_KINV
+#undef DQQ_KENT
 }
 
 // grad_P = -dl x^T (qcqp.py:49 / :174) of the wave's 64 problems, staged in LDS (the K area is dead) and streamed out with
@@ -299,6 +317,175 @@ static DQQ_D void set_ab(double* __restrict__ kl, double (&abr)[S::AB_REG > 0 ? 
 }
 
 } // namespace
+
+// dualFromPrimalQCQP (:584-617) and the active set of solveDerivativesQCQP (:622-641), contact by contact;
+// row c of A = [[diag(S), diag(gamma) C^T],[C, P + blkdiag(2 gamma_i I2)]] (:643-657): aS at column c, aA / aB at
+// the contact's two coordinate columns; an inactive contact's row is zero
+template <int N>
+static DQQ_D __attribute__((always_inline)) void qcqp_contacts(const double (&xv)[N], const double (&plq)[N],
+                                                               const double (&lnv)[N / 2], const double (&mcv)[N / 2],
+                                                               double dual_eps, double (&gam)[N / 2], bool (&cact)[N / 2],
+                                                               double (&aS)[N / 2], double (&aA)[N / 2], double (&aB)[N / 2])
+{
+#pragma clang fp contract(off)
+    constexpr int NC = N / 2;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double ln = lnv[c], mc = mcv[c];
+        const double r = ln * mc;                                           // pybindings.cpp:65
+        const double xa = xv[2 * c], xb = xv[2 * c + 1];
+        double g0 = 0.0;
+        const double slack = r + -sqrt(xa * xa + xb * xb);
+        if (!(slack > dual_eps || r < dual_eps)) {
+            const double ca = 2 * xa, cb = 2 * xb;
+            const double G = ca * ca + cb * cb;
+            const double rhs = ca * plq[2 * c] + cb * plq[2 * c + 1];
+            const double Lg = sqrt(G);
+            g0 = -((rhs / Lg) / Lg);
+        }
+        double Sc = -(r * r);
+        Sc = Sc + (xa * xa + xb * xb);
+        cact[c] = Sc > -kActiveEps && r > kActiveEps;
+        gam[c] = g0;
+        aS[c] = cact[c] ? Sc : 0.0;
+        aA[c] = cact[c] ? g0 * (2 * xa) : 0.0;
+        aB[c] = cact[c] ? g0 * (2 * xb) : 0.0;
+    }
+}
+
+// K of the same system once more (REGEN), straight from memory and COLUMN by column of P: an entry of K is a sum over the
+// columns m = 0 .. N-1 in ascending order whichever way the loops nest, so accumulating all entries while the columns stream by
+// gives the bits of qcqp_system's row-wise sums -- with 8 doubles of P live instead of 64 (the inverse's registers are full).
+template <typename S, int N>
+static DQQ_D __attribute__((always_inline)) void qcqp_rebuild_K(const double* __restrict__ Pg, const double (&xv)[N],
+                                                                const double (&qv)[N], const double (&lnv)[N / 2],
+                                                                const double (&mcv)[N / 2], double dual_eps, double (&gam)[N / 2],
+                                                                bool (&cact)[N / 2], double (&Kreg)[S::SLOTS])
+{
+#pragma clang fp contract(off)
+    constexpr int NC = N / 2;
+    double plq[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) plq[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+        for (int i = 0; i < N; ++i) plq[i] += Pg[i * N + j] * xv[j];            // (P l)_i, j ascending, :606
+#pragma unroll
+    for (int i = 0; i < N; ++i) plq[i] = plq[i] + qv[i];
+    double aS[NC], aA[NC], aB[NC], cx[N];
+    qcqp_contacts<N>(xv, plq, lnv, mcv, dual_eps, gam, cact, aS, aA, aB);
+#pragma unroll
+    for (int i = 0; i < N; ++i) cx[i] = cact[i / 2] ? 2 * xv[i] : 0.0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        double t = 0.0;
+        t += aS[c] * aS[c];
+        t += aA[c] * aA[c];
+        t += aB[c] * aB[c];
+        t += kMuIr;
+        Kreg[S::slot(c, c)] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            double t = 0.0;
+            if (i / 2 == c) t += cx[i] * aS[c];
+            Kreg[S::slot(NC + i, c)] = t;
+        }
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double t = 0.0;
+            if (i / 2 == j / 2) t += cx[i] * cx[j];
+            Kreg[S::slot(NC + i, NC + j)] = t;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        double col[N];                                                          // column m of D = P + blkdiag(2 gamma_i I2)
+#pragma unroll
+        for (int i = 0; i < N; ++i) col[i] = (i == m) ? 2 * gam[i / 2] + Pg[i * N + m] : Pg[i * N + m];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            Kreg[S::slot(NC + i, m / 2)] += col[i] * ((m & 1) ? aB[m / 2] : aA[m / 2]);
+#pragma unroll
+            for (int j = 0; j <= i; ++j) Kreg[S::slot(NC + i, NC + j)] += col[i] * col[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) Kreg[S::slot(NC + i, NC + i)] += kMuIr;
+}
+
+// The derivative system of solveDerivativesQCQP (Solver.cpp:619-681) from a problem's inputs: the contact duals gam and the
+// active set cact, and -- through putK(i, j, v), i >= j, and putAb(i, v) -- K = A A^T + mu I and A^T b.  Pm is overwritten
+// (its diagonal becomes that of D).  Called twice in the REGEN instantiation: the same code, the same bits.
+template <typename S, int N, typename PutK, typename PutAb>
+static DQQ_D __attribute__((always_inline)) void qcqp_system(double (&Pm)[N][N], const double (&xv)[N], const double (&gv)[N],
+                                                             const double (&qv)[N], const double (&lnv)[N / 2],
+                                                             const double (&mcv)[N / 2], double dual_eps, double (&gam)[N / 2],
+                                                             bool (&cact)[N / 2], PutK putK, PutAb putAb)
+{
+#pragma clang fp contract(off)
+    constexpr int NC = N / 2;
+    // ---- (P l + q), :606
+    double plq[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) s += Pm[i][j] * xv[j];
+        plq[i] = s + qv[i];
+    }
+    double aS[NC], aA[NC], aB[NC];
+    qcqp_contacts<N>(xv, plq, lnv, mcv, dual_eps, gam, cact, aS, aA, aB);
+    // coordinate row i of A: cx at its contact's column, D = P + blkdiag(2 gamma_i I2) behind it
+    double cx[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        cx[i] = cact[i / 2] ? 2 * xv[i] : 0.0;
+        Pm[i][i] = 2 * gam[i / 2] + Pm[i][i];
+    }
+    // ---- A^T b (:19), b = [0; grad_l] (:659-667), and K = A A^T + mu I (:20-21): sums over k = contact columns, then
+    // coordinate columns, structural zeros left out
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        double s = 0.0;
+        s += aA[c] * gv[2 * c];
+        s += aB[c] * gv[2 * c + 1];
+        putAb(c, s);
+        double t = 0.0;
+        t += aS[c] * aS[c];
+        t += aA[c] * aA[c];
+        t += aB[c] * aB[c];
+        t += kMuIr;
+        putK(c, c, t);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) s += Pm[i][j] * gv[j];
+        putAb(NC + i, s);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            double t = 0.0;
+            if (i / 2 == c) t += cx[i] * aS[c];
+            t += Pm[i][2 * c] * aA[c];
+            t += Pm[i][2 * c + 1] * aB[c];
+            putK(NC + i, c, t);
+        }
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double t = 0.0;
+            if (i / 2 == j / 2) t += cx[i] * cx[j];
+#pragma unroll
+            for (int m = 0; m < N; ++m) t += Pm[i][m] * Pm[j][m];
+            if (j == i) t += kMuIr;
+            putK(NC + i, NC + j, t);
+        }
+    }
+}
 
 template <int KIND, int N>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 1 && N > 4) ? 1 : 2))) void bwd_lane_dense_kernel(
@@ -404,93 +591,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 
         }
         if (grad_P != nullptr) store_grad_P_tile<N>(smem, grad_P, first, nvalid, dl, xv);
     } else {
-        // ---- (P l + q), :606
-        double plq[N];
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            double s = 0.0;
-#pragma unroll
-            for (int j = 0; j < N; ++j) s += Pm[i][j] * xv[j];
-            plq[i] = s + qv[i];
-        }
-        // ---- dualFromPrimalQCQP (:584-617) and the active set of solveDerivativesQCQP (:622-641), contact by contact;
-        // row c of A = [[diag(S), diag(gamma) C^T],[C, P + blkdiag(2 gamma_i I2)]] (:643-657): aS at column c, aA / aB at
-        // the contact's two coordinate columns; an inactive contact's row is zero
-        double gam[NC], aS[NC], aA[NC], aB[NC];
+        double lnv[NC], mcv[NC], gam[NC];
         bool cact[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const double ln = aux0[prob * NC + c], mc = aux1[prob * NC + c];
-            const double r = ln * mc;                                           // pybindings.cpp:65
-            const double xa = xv[2 * c], xb = xv[2 * c + 1];
-            double g0 = 0.0;
-            const double slack = r + -sqrt(xa * xa + xb * xb);
-            if (!(slack > dual_eps || r < dual_eps)) {
-                const double ca = 2 * xa, cb = 2 * xb;
-                const double G = ca * ca + cb * cb;
-                const double rhs = ca * plq[2 * c] + cb * plq[2 * c + 1];
-                const double Lg = sqrt(G);
-                g0 = -((rhs / Lg) / Lg);
-            }
-            double Sc = -(r * r);
-            Sc = Sc + (xa * xa + xb * xb);
-            cact[c] = Sc > -kActiveEps && r > kActiveEps;
-            gam[c] = g0;
-            aS[c] = cact[c] ? Sc : 0.0;
-            aA[c] = cact[c] ? g0 * (2 * xa) : 0.0;
-            aB[c] = cact[c] ? g0 * (2 * xb) : 0.0;
-        }
-        // coordinate row i of A: cx at its contact's column, D = P + blkdiag(2 gamma_i I2) behind it
-        double cx[N];
+        for (int c = 0; c < NC; ++c) { lnv[c] = aux0[prob * NC + c]; mcv[c] = aux1[prob * NC + c]; }
+        qcqp_system<S, N>(Pm, xv, gv, qv, lnv, mcv, dual_eps, gam, cact,
+                          [&](int i, int j, double v) __attribute__((always_inline)) { DQQ_KL(S::slot(i, j)) = v; },
+                          [&](int i, double v) __attribute__((always_inline)) { set_ab<S>(kl, abr, i, v); });
+        if constexpr (S::REGEN) {
+            // everything but A^T b is rebuilt after the inverse: nothing of the build stays live across the factorisation
+            lane_ir<S>(kl, abr, xs, steps, [&](double (&Kreg)[S::SLOTS]) __attribute__((always_inline)) {
+                const double* Pg = P + prob * (long)(N * N);
+                double x2[N], q2[N], ln2[NC], mc2[NC];
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            cx[i] = cact[i / 2] ? 2 * xv[i] : 0.0;
-            Pm[i][i] = 2 * gam[i / 2] + Pm[i][i];
-        }
-        // ---- A^T b (:19), b = [0; grad_l] (:659-667), and K = A A^T + mu I (:20-21): sums over k = contact columns, then
-        // coordinate columns, structural zeros left out
+                for (int i = 0; i < N; i += 2) {
+                    const double2 a = *reinterpret_cast<const double2*>(x + prob * N + i);
+                    const double2 c = *reinterpret_cast<const double2*>(q + prob * N + i);
+                    x2[i] = a.x; x2[i + 1] = a.y;
+                    q2[i] = c.x; q2[i + 1] = c.y;
+                }
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            double s = 0.0;
-            s += aA[c] * gv[2 * c];
-            s += aB[c] * gv[2 * c + 1];
-            set_ab<S>(kl, abr, c, s);
-            double t = 0.0;
-            t += aS[c] * aS[c];
-            t += aA[c] * aA[c];
-            t += aB[c] * aB[c];
-            t += kMuIr;
-            DQQ_KL(S::slot(c, c)) = t;
-        }
+                for (int c = 0; c < NC; ++c) { ln2[c] = aux0[prob * NC + c]; mc2[c] = aux1[prob * NC + c]; }
+                qcqp_rebuild_K<S, N>(Pg, x2, q2, ln2, mc2, dual_eps, gam, cact, Kreg);
+            });
+            // (x, l_n, mu come back from memory for the outputs: nothing but gam / cact lives through the refinement loop)
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            double s = 0.0;
-#pragma unroll
-            for (int j = 0; j < N; ++j) s += Pm[i][j] * gv[j];
-            set_ab<S>(kl, abr, NC + i, s);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                double t = 0.0;
-                if (i / 2 == c) t += cx[i] * aS[c];
-                t += Pm[i][2 * c] * aA[c];
-                t += Pm[i][2 * c + 1] * aB[c];
-                DQQ_KL(S::slot(NC + i, c)) = t;
+            for (int i = 0; i < N; i += 2) {
+                const double2 a = *reinterpret_cast<const double2*>(x + prob * N + i);
+                xv[i] = a.x; xv[i + 1] = a.y;
             }
 #pragma unroll
-            for (int j = 0; j <= i; ++j) {
-                double t = 0.0;
-                if (i / 2 == j / 2) t += cx[i] * cx[j];
-#pragma unroll
-                for (int m = 0; m < N; ++m) t += Pm[i][m] * Pm[j][m];
-                if (j == i) t += kMuIr;
-                DQQ_KL(S::slot(NC + i, NC + j)) = t;
-            }
+            for (int c = 0; c < NC; ++c) { lnv[c] = aux0[prob * NC + c]; mcv[c] = aux1[prob * NC + c]; }
+        } else {
+            lane_ir<S>(kl, abr, xs, steps);
         }
-        lane_ir<S>(kl, abr, xs, steps);
         if (valid) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const double ln = aux0[prob * NC + c], mc = aux1[prob * NC + c];
+                const double ln = lnv[c], mc = mcv[c];
                 const double dg = cact[c] ? xs[c] : 0.0;                        // :671-674
                 if (gout0 != nullptr) gout0[prob * NC + c] = QcqpContact::e2(gam[c], ln, mc) * dg;   // grad_l_n
                 if (gout1 != nullptr) gout1[prob * NC + c] = QcqpContact::e1(gam[c], ln, mc) * dg;   // grad_mu
