@@ -18,6 +18,7 @@ __global__ __launch_bounds__(256, (SmallSys<KIND, N>::M > 16 ? 1 : 2)) void bwd_
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int team = lane / T, tl = lane % T;
+    if (team >= TP && lane != 0) return;   // (T need not divide 64: the lanes left over idle)
     double* sw = smem + (wave * TP + team) * S::LDS_DOUBLES;
     const long count = use_worklist ? (long)ws[kWsCount] : B;
     const long nteams = (long)gridDim.x * wpb * TP;

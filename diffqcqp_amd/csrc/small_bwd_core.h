@@ -15,7 +15,7 @@
 //     so the arithmetic on them is the reference's operation for operation.  The QP keeps the ORIGINAL
 //     coordinate order with active rows / columns masked (a symmetric permutation of the reference's
 //     [active, inactive] order with the same property).
-//   * a team of T = 8 / 16 / 32 lanes owns a problem (64/T problems per wave); lane i owns unknown i: its
+//   * a team of T = M lanes owns a problem (64/T problems per wave); lane i owns unknown i: its
 //     column of the matrix handed to iterative_refinement, row i of K = A^T A + mu I, row i of the Cholesky
 //     factor, column i (then row i) of K^-1 -- all in registers.  What other lanes need is published to
 //     the team's LDS slice once and read back as broadcasts.
@@ -35,13 +35,21 @@ template <int KIND, int N>
 struct SmallSys {
     static constexpr int NC = N / 2;
     static constexpr int M = (KIND == 0) ? N : (KIND == 1 ? N + NC : 3 * N); // unknowns of the derivative system
-    static constexpr int T = (M <= 8) ? 8 : (M <= 16 ? 16 : 32);              // team width
+    // team width: exactly the number of unknowns (round 4; it was the next power of two -- 12 of 16 lanes worked on the QCQP at
+    // N = 8, 9 of 16 at N = 6).  Nothing needs a power of two: what a lane needs from its team goes through the team's LDS slice
+    // and team_ballot shifts by team * T.  64 / T teams per wave, the 64 mod T lanes left over idle.  Dense P, B = 65536, backward, us:
+    // QCQP N = 8 124 -> 113, N = 6 79 -> 54, N = 4 26 -> 24; QP N = 8 36.4 -> 35.6, N = 6 20 -> 18.5, N = 4 14.7 -> 11.5.
+#if defined(DQQ_SMALL_T_POW2)
+    static constexpr int T = (M <= 8) ? 8 : (M <= 16 ? 16 : 32);              // developer A/B
+#else
+    static constexpr int T = (M == 3) ? 4 : M;                                 // (three-lane teams measured slower than four)
+#endif
     static constexpr int LDA = (M + 1) & ~1;                                   // even: rows start 16-byte aligned
     static constexpr int LDS_DOUBLES = 2 * M * LDA + 8 * M;                    // [A_t, then K^-1], [L], vectors
 #if defined(DQQ_SMALL_WPB)
     static constexpr int WPB = DQQ_SMALL_WPB;   // developer A/B (tools/ab_build.sh)
 #else
-    static constexpr int WPB = (LDS_DOUBLES * (64 / T) * 8 * 4 <= 40 * 1024) ? 4 : 2;
+    static constexpr int WPB = (LDS_DOUBLES * (64 / T) * 8 * 4 <= 64 * 1024) ? 4 : 2;   // two workgroups per CU by registers
 #endif
 };
 
