@@ -15,12 +15,17 @@ __global__ __launch_bounds__(256, (SmallSys<KIND, N>::M > 16 ? 1 : 2)) void bwd_
 {
     using S = SmallSys<KIND, N>;
     constexpr int T = S::T, TP = 64 / T;
+    // An empty work-list -- what this launch finds behind every backward of a diagonal batch -- leaves on ONE scalar load, before
+    // anything else: with the exit below the lane / team arithmetic the compiler had put a register spill (a scratch store by each
+    // of the 4096 waves) in front of it, and the headline step paid 4.5 us for it (round 4, A/B of the builds).
+    const long count = use_worklist ? (long)ws[kWsCount] : B;
+    if (count == 0) return;
+    asm volatile("" ::: "memory");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int team = lane / T, tl = lane % T;
     if (team >= TP && lane != 0) return;   // (T need not divide 64: the lanes left over idle)
     double* sw = smem + (wave * TP + team) * S::LDS_DOUBLES;
-    const long count = use_worklist ? (long)ws[kWsCount] : B;
     const long nteams = (long)gridDim.x * wpb * TP;
     for (long w = ((long)blockIdx.x * wpb + wave) * TP + team; w < count; w += nteams) {
         const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
