@@ -46,7 +46,10 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : (KIND == 1 ? 4 :
     // uncapped, the general routine would take it from 58 to 134 VGPRs.
     __shared__ __attribute__((aligned(16))) double s_dense[WPB][FUSE ? dense_bwd_lds_doubles(KIND, N) : 1];
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index is wave-uniform: in an SGPR, the tile's position (`first`, `nvalid`, pointers) is scalar arithmetic and
+    // costs no vector registers -- as a VGPR value the fused forward kept `first` and `nvalid` in SCRATCH (spilled and
+    // reloaded in front of the stream of P, on the path every tile takes)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const long tile = (long)blockIdx.x * WPB + wave;
     const long first = tile * T;
     if (first >= B) return; // whole wave leaves; no workgroup barrier is used below

@@ -83,7 +83,10 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
     constexpr bool GD = FUSE && N <= 8 && LD <= 4 && group_dense_supported(KIND, N, LD);
     [[maybe_unused]] bool dense_tile = false; // CMP: some tile of this workgroup is not diagonal
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index is wave-uniform: in an SGPR, the tile's position (`first`, `nvalid`, pointers) is scalar arithmetic and
+    // costs no vector registers -- as a VGPR value the fused forward kept `first` and `nvalid` in SCRATCH (spilled and
+    // reloaded in front of the stream of P, on the path every tile takes)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const long tile = (long)blockIdx.x * WPB + wave;
     const long first = tile * PPW;
 #if defined(DQQ_PROBE_SCRATCH)
