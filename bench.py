@@ -240,6 +240,11 @@ def gpu_environment():
     env = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
            "HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG"), "device": torch.cuda.get_device_name(0)}
     try:
+        from diffqcqp_amd import _capi
+        env["dqq_feedback"] = _capi._feedback is not None   # dqq_set_feedback registered (DQQ_FEEDBACK=0 turns it off)
+    except Exception:
+        pass
+    try:
         p = torch.cuda.get_device_properties(0)
         env.update({"compute_units": p.multi_processor_count, "clock_rate_khz_reported": getattr(p, "clock_rate", None)})
     except Exception:
@@ -848,6 +853,8 @@ def main():
     if use_dist:
         dist.barrier()
     _capi.lib()
+    from diffqcqp_amd import ops as _ops
+    _ops.feedback_default()   # what ops.*_backward does on its first DQQ_P_AUTO call (the chains below call the C ABI directly)
     ctx = {"rank": rank, "world": world, "dev": dev, "use_dist": use_dist, "dist": dist, "parallel": parallel,
            "capi": _capi, "side": torch.cuda.Stream()}
 

@@ -50,6 +50,7 @@ SIGNATURES = {
                            _vp, _sz, _vp], _i),
     "dqq_set_option": ([ctypes.c_char_p, _i], _i),
     "dqq_get_option": ([ctypes.c_char_p, ctypes.POINTER(_i)], _i),
+    "dqq_set_feedback": ([_vp, _sz], _i),
     "dqq_version": ([], ctypes.c_char_p),
 }
 
@@ -126,6 +127,32 @@ def get_option(name):
     v = _i(0)
     check(lib().dqq_get_option(name.encode(), ctypes.byref(v)), "dqq_get_option(%s)" % name)
     return v.value
+
+
+FEEDBACK_BYTES = 128   # DQQ_FEEDBACK_BYTES
+_feedback = None       # the registered buffer (a pinned tensor): alive as long as the library may write to it
+
+
+def enable_feedback(on=True):
+    """Register (or drop) the feedback buffer of include/diffqcqp_hip.h dqq_set_feedback: 128 bytes of pinned host memory
+    through which the drain launch of the N <= 8 backward tells the next call how many non-diagonal problems it found.
+    A timing hint only -- results are the same bits with and without.  Needs a GPU (pinned memory)."""
+    global _feedback
+    if not on:
+        check(lib().dqq_set_feedback(None, 0), "dqq_set_feedback(NULL)")
+        _feedback = None
+        return
+    if _feedback is None:
+        buf = torch.zeros(FEEDBACK_BYTES // 8, dtype=torch.int64).pin_memory()
+        check(lib().dqq_set_feedback(buf.data_ptr(), FEEDBACK_BYTES), "dqq_set_feedback")
+        _feedback = buf
+
+
+def feedback_words():
+    """The registered buffer's words as (B, entries) pairs, index kind * 4 + N / 2 - 1 (a debugging view), or None."""
+    if _feedback is None:
+        return None
+    return [((int(w) >> 32) & 0xffffffff, int(w) & 0xffffffff) for w in _feedback.tolist()]
 
 
 def version():

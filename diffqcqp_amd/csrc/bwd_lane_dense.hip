@@ -282,9 +282,10 @@ static DQQ_D void lane_ir(double* kl, const double (&abr)[S::AB_REG > 0 ? S::AB_
 
 // grad_P = -dl x^T (qcqp.py:49 / :174) of the wave's 64 problems, staged in LDS (the K area is dead) and streamed out with
 // coalesced 16-byte stores -- the tile is contiguous in memory, a lane's own matrix is N*N*8 bytes from its neighbour's.
-template <int N>
+// LIST (the wave's problems come from a work-list): member pp's matrix sits at its own problem index, held by lane pp.
+template <int N, bool LIST = false>
 static DQQ_D void store_grad_P_tile(double* __restrict__ smem, double* __restrict__ grad_P, long first, int nvalid,
-                                    const double (&dl)[N], const double (&xv)[N])
+                                    const double (&dl)[N], const double (&xv)[N], int prob32 = 0)
 {
 #pragma clang fp contract(off)
     constexpr int NN = N * N, TS = NN + 1, CPP = NN / 2;
@@ -300,10 +301,12 @@ static DQQ_D void store_grad_P_tile(double* __restrict__ smem, double* __restric
     for (int k = 0; k < CPP; ++k) {
         const int ch = k * 64 + (int)threadIdx.x;
         const int pp = ch / CPP, w = ch % CPP;
+        double* dst = Gw + 2 * (long)ch;
+        if constexpr (LIST) dst = grad_P + (long)__shfl(prob32, pp) * NN + 2 * w;
         if (pp < nvalid) {
             // written once, not read again by this launch: non-temporal
-            __builtin_nontemporal_store(smem[pp * TS + 2 * w], Gw + 2 * (long)ch);
-            __builtin_nontemporal_store(smem[pp * TS + 2 * w + 1], Gw + 2 * (long)ch + 1);
+            __builtin_nontemporal_store(smem[pp * TS + 2 * w], dst);
+            __builtin_nontemporal_store(smem[pp * TS + 2 * w + 1], dst + 1);
         }
     }
 }
@@ -487,21 +490,34 @@ static DQQ_D __attribute__((always_inline)) void qcqp_system(double (&Pm)[N][N],
     }
 }
 
-template <int KIND, int N>
+// LIST: the drain launch behind the diagonal fast path's backward (DQQ_P_AUTO) -- the problems are the entries of the
+// work-list `ws` (launch.h), 64 consecutive entries per wave; `B` is then the batch the list was drawn from.  The launch is
+// sized for B entries: a wave beyond the list leaves on one scalar load, the first one reports the list's length to the
+// host's feedback word (launch.h worklist_feedback) and the last one out re-zeroes the list's header.
+template <int KIND, int N, bool LIST>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 1 && N > 4) ? 1 : 2))) void bwd_lane_dense_kernel(
     const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ aux0,
     const double* __restrict__ aux1, const double* __restrict__ x, const double* __restrict__ grad_x,
     double* __restrict__ grad_P, double* __restrict__ grad_q, double* __restrict__ gout0, double* __restrict__ gout1,
-    double* __restrict__ gamma_out, double* __restrict__ dgamma_out, long B, double dual_eps, int* __restrict__ ir_steps)
+    double* __restrict__ gamma_out, double* __restrict__ dgamma_out, long B, double dual_eps, int* __restrict__ ir_steps,
+    int* __restrict__ ws, unsigned long long* __restrict__ feedback)
 {
 #pragma clang fp contract(off)
     using S = LaneSys<KIND, N>;
     constexpr int M = S::M, NC = S::NC;
+    const long total = LIST ? (long)ws[kWsCount] : B;   // problems of this launch
+    if constexpr (LIST) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) worklist_feedback(feedback, ws, B, total);
+        if ((long)blockIdx.x * 64 >= total) return;      // (an empty list: every wave, before anything else)
+        asm volatile("" ::: "memory");
+    }
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* kl = smem + threadIdx.x;
     const long slot = (long)blockIdx.x * 64 + threadIdx.x;
-    const bool valid = slot < B;
-    const long prob = valid ? slot : B - 1;   // lanes past the end redo the last problem and store nothing
+    const bool valid = slot < total;
+    // lanes past the end redo the last problem and store nothing
+    const long prob = LIST ? (long)ws[kWsEntries + (valid ? slot : total - 1)] : (valid ? slot : total - 1);
+    [[maybe_unused]] const int prob32 = (int)prob;
 
     // ---- load.  A lane's matrix is N*N contiguous doubles, N*N*8 bytes from its neighbour's: read lane by lane, every
     // load instruction touches 64 cache lines for 1 KiB of data, and with the whole chip streaming that way the tiles do
@@ -509,7 +525,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 
     // stream it with coalesced 16-byte loads through LDS (row stride N*N + 1 doubles: conflict-free reads), before K moves in.
     constexpr int NN = N * N, TS = NN + 1, CPP = NN / 2;   // doubles per matrix, LDS row stride, 16-byte chunks per matrix
     const long first = (long)blockIdx.x * 64;
-    const int nvalid = (B - first) < 64 ? (int)(B - first) : 64;
+    const int nvalid = (total - first) < 64 ? (int)(total - first) : 64;
     double Pm[N][N], xv[N], gv[N], qv[N];
     {
         const double* Pw = P + first * (long)NN;
@@ -519,7 +535,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 
             int ch = k * 64 + (int)threadIdx.x;                // chunk of the tile
             ch = ch < last ? ch : last;
             const int pp = ch / CPP, w = ch % CPP;
-            const double2 t = *reinterpret_cast<const double2*>(Pw + 2 * (long)ch);
+            const double* src = Pw + 2 * (long)ch;
+            if constexpr (LIST) src = P + (long)__shfl(prob32, pp) * NN + 2 * w;   // (runs of a tile's problems stay coalesced)
+            const double2 t = *reinterpret_cast<const double2*>(src);
             smem[pp * TS + 2 * w] = t.x;
             smem[pp * TS + 2 * w + 1] = t.y;
         }
@@ -589,7 +607,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 
                 if (grad_q != nullptr) grad_q[prob * N + i] = -dl[i];
             if (ir_steps != nullptr) ir_steps[prob] = steps;
         }
-        if (grad_P != nullptr) store_grad_P_tile<N>(smem, grad_P, first, nvalid, dl, xv);
+        if (grad_P != nullptr) store_grad_P_tile<N, LIST>(smem, grad_P, first, nvalid, dl, xv, prob32);
     } else {
         double lnv[NC], mcv[NC], gam[NC];
         bool cact[NC];
@@ -644,14 +662,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 
             double dl[N];
 #pragma unroll
             for (int i = 0; i < N; ++i) dl[i] = xs[NC + i];
-            store_grad_P_tile<N>(smem, grad_P, first, nvalid, dl, xv);
+            store_grad_P_tile<N, LIST>(smem, grad_P, first, nvalid, dl, xv, prob32);
         }
+    }
+    if constexpr (LIST) {
+        if (threadIdx.x == 0) worklist_release(ws, total, (int)((total + 63) / 64));   // the waves that did not leave at the top
     }
 }
 
 #undef DQQ_KL
 
-template <int KIND, int N>
+template <int KIND, int N, bool LIST>
 static hipError_t launch_lane_bwd(const BwdArgs& a, hipStream_t s)
 {
     using S = LaneSys<KIND, N>;
@@ -659,12 +680,13 @@ static hipError_t launch_lane_bwd(const BwdArgs& a, hipStream_t s)
     const size_t lds = sizeof(double) * 64 * (size_t)(S::LDS_SLOTS > N * N + 1 ? S::LDS_SLOTS : N * N + 1);
     const long grid = (a.B + 63) / 64;
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_lane_dense_kernel<KIND, N>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_lane_dense_kernel<KIND, N, LIST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    return launch(bwd_lane_dense_kernel<KIND, N>, dim3((unsigned)grid), dim3(64), lds, s, a.P, a.q, a.l_n, a.mu, a.x,
-                  a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.epsilon, a.ir_steps);
+    return launch(bwd_lane_dense_kernel<KIND, N, LIST>, dim3((unsigned)grid), dim3(64), lds, s, a.P, a.q, a.l_n, a.mu, a.x,
+                  a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.epsilon, a.ir_steps, a.ws,
+                  LIST ? worklist_feedback_slot(KIND, N) : nullptr);
 }
 
 // P declared dense, QP / QCQP, N = 2, 4, 6, 8, batches that fill the chip: a lane per problem needs 64 problems per wave
@@ -682,11 +704,13 @@ bool bwd_lane_dense_supported(int kind, int N, long B)
     return (kind == kKindQP || kind == kKindQCQP) && (N == 2 || N == 4 || N == 6 || N == 8) && B >= min_b;
 }
 
-hipError_t launch_bwd_lane_dense(int kind, const BwdArgs& a, hipStream_t s)
+hipError_t launch_bwd_lane_dense(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
-#define DQQ_CASE(NN)                                              \
-    if (a.N == NN) return kind == 0 ? launch_lane_bwd<0, NN>(a, s) : launch_lane_bwd<1, NN>(a, s);
+#define DQQ_CASE(NN)                                                                                              \
+    if (a.N == NN)                                                                                                \
+        return use_worklist ? (kind == 0 ? launch_lane_bwd<0, NN, true>(a, s) : launch_lane_bwd<1, NN, true>(a, s)) \
+                            : (kind == 0 ? launch_lane_bwd<0, NN, false>(a, s) : launch_lane_bwd<1, NN, false>(a, s));
     DQQ_CASE(2) DQQ_CASE(4) DQQ_CASE(6) DQQ_CASE(8)
 #undef DQQ_CASE
     return hipErrorInvalidValue;

@@ -11,7 +11,7 @@ __global__ __launch_bounds__(256, (SmallSys<KIND, N>::M > 16 ? 1 : 2)) void bwd_
     const double* __restrict__ aux1, const double* __restrict__ x, const double* __restrict__ grad_x,
     double* __restrict__ grad_P, double* __restrict__ grad_q, double* __restrict__ gout0, double* __restrict__ gout1,
     double* __restrict__ gamma_out, double* __restrict__ dgamma_out, long B, double dual_eps, int* __restrict__ ir_steps,
-    int* __restrict__ ws, int use_worklist)
+    int* __restrict__ ws, int use_worklist, unsigned long long* __restrict__ feedback)
 {
     using S = SmallSys<KIND, N>;
     constexpr int T = S::T, TP = 64 / T;
@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256, (SmallSys<KIND, N>::M > 16 ? 1 : 2)) void bwd_
     // anything else: with the exit below the lane / team arithmetic the compiler had put a register spill (a scratch store by each
     // of the 4096 waves) in front of it, and the headline step paid 4.5 us for it (round 4, A/B of the builds).
     const long count = use_worklist ? (long)ws[kWsCount] : B;
+    if (use_worklist && blockIdx.x == 0 && threadIdx.x == 0) worklist_feedback(feedback, ws, B, count);   // (launch.h: a hint for the next call)
     if (count == 0) return;
     asm volatile("" ::: "memory");
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -60,7 +61,7 @@ static hipError_t launch_small(const BwdArgs& a, bool use_worklist, hipStream_t 
     }
     return launch(kernel, dim3(grid), dim3(64 * WPB), lds_bytes, s, a.P, a.q, a.l_n, a.mu, a.x, a.grad_x, a.grad_P,
                        a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.epsilon, a.ir_steps, a.ws,
-                       use_worklist ? 1 : 0);
+                       use_worklist ? 1 : 0, use_worklist ? worklist_feedback_slot(KIND, N) : nullptr);
 }
 
 // The box QP instantiations (M = 3N: 24 unknowns at N = 8) exist and are correct, but run out of registers

@@ -16,6 +16,7 @@ extern std::atomic<int> g_lane_defer;
 extern std::atomic<int> g_dense_teams;
 extern std::atomic<int> g_small_bwd;
 extern std::atomic<int> g_lane_bwd;
+extern std::atomic<int> g_lane_list_drains;
 extern std::atomic<int> g_small_fwd;
 extern std::atomic<int> g_wave_qcqp_bwd;
 }
@@ -42,6 +43,7 @@ Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback"
                       {"dense_teams", &dqq::g_dense_teams},
                       {"small_bwd", &dqq::g_small_bwd},
                       {"lane_bwd", &dqq::g_lane_bwd},
+                      {"lane_list_drains", &dqq::g_lane_list_drains},
                       {"small_fwd", &dqq::g_small_fwd},
                       {"wave_qcqp_bwd", &dqq::g_wave_qcqp_bwd}};
 
@@ -105,6 +107,23 @@ int dqq_set_option(const char* name, int value)
     return DQQ_E_BAD_OPTION;
 }
 
+int dqq_set_feedback(void* host_buffer, size_t bytes)
+{
+    static_assert(DQQ_FEEDBACK_BYTES == dqq::kFeedbackWords * sizeof(unsigned long long), "feedback words");
+    if (host_buffer == nullptr) {
+        dqq::g_feedback_host.store(nullptr);
+        dqq::g_feedback_dev.store(nullptr);
+        return 0;
+    }
+    if (bytes < DQQ_FEEDBACK_BYTES || (reinterpret_cast<uintptr_t>(host_buffer) & 7) != 0) return DQQ_E_BAD_SIZE;
+    void* dev = nullptr;
+    const hipError_t e = hipHostGetDevicePointer(&dev, host_buffer, 0);   // (pinned / registered host memory only)
+    if (e != hipSuccess) return (int)e;
+    dqq::g_feedback_dev.store(static_cast<unsigned long long*>(dev));
+    dqq::g_feedback_host.store(static_cast<const volatile unsigned long long*>(host_buffer));
+    return 0;
+}
+
 int dqq_get_option(const char* name, int* value)
 {
     if (name == nullptr || value == nullptr) return DQQ_E_NULLPTR;
@@ -114,7 +133,9 @@ int dqq_get_option(const char* name, int* value)
 }
 
 // Routing is a function of (kind, N, B, p_layout) and the process-wide tuning knobs only: two calls with the same
-// arguments launch the same kernels, whatever ran before them, on whatever thread or stream.
+// arguments launch the same kernels, whatever ran before them, on whatever thread or stream.  (One exception, opt-in:
+// with a feedback buffer registered the drain launch of the N <= 8 backward is picked between two kernels of identical
+// results by what the last such launch found, launch.h.)
 static int fwd_dispatch(int kind, dqq::FwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t s)
 {
     if (a.B == 0) return 0;

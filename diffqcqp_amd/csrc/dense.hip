@@ -14,6 +14,9 @@ std::atomic<int> g_lane_dense{1};  // 0: never the lane-per-problem kernel of N 
 std::atomic<int> g_dense_teams{1}; // 0: backward always one problem per wave (option "dense_teams")
 std::atomic<int> g_small_fwd{1};   // 0: never the team-per-problem forward of N = 10..16 (option "small_fwd")
 std::atomic<int> g_small_bwd{1};   // 0: never the statically sized team backward of N <= 8 (option "small_bwd")
+std::atomic<unsigned long long*> g_feedback_dev{nullptr};                     // dqq_set_feedback (launch.h)
+std::atomic<const volatile unsigned long long*> g_feedback_host{nullptr};
+std::atomic<int> g_lane_list_drains{0};   // a counter, not a knob: drain launches routed to the lane kernel by the feedback word (tests)
 std::atomic<int> g_lane_bwd{1};    // 0: never the lane-per-problem backward of N <= 8, DQQ_P_DENSE (option "lane_bwd")
 
 
@@ -188,9 +191,16 @@ hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipSt
 {
     if (a.B == 0) return hipSuccess;
     // a batch DECLARED dense that fills the chip: a lane per problem (bwd_lane_dense.hip; the same bits as the team kernel).
-    // Not in work-list mode: its 512-register waves need an empty SIMD each, and an empty list must cost next to nothing.
+    // Not in work-list mode unless the list is known to be long: its 512-register waves need an empty SIMD each, and an empty
+    // list must cost next to nothing.
     if (!use_worklist && g_lane_bwd.load() != 0 && bwd_lane_dense_supported(kind, a.N, a.B))
-        return launch_bwd_lane_dense(kind, a, s);
+        return launch_bwd_lane_dense(kind, a, false, s);
+    // ... and the drain launch of a work-list that the last drain of this kind, N and B found that long (launch.h: feedback)
+    if (use_worklist && g_lane_bwd.load() != 0 && bwd_lane_dense_supported(kind, a.N, a.B) &&
+        bwd_lane_dense_supported(kind, a.N, worklist_predicted(kind, a.N, a.B))) {
+        g_lane_list_drains.fetch_add(1, std::memory_order_relaxed);
+        return launch_bwd_lane_dense(kind, a, true, s);
+    }
     if (bwd_small_supported(kind, a.N) && g_small_bwd.load() != 0) return launch_bwd_small(kind, a, use_worklist, s);
     if (bwd_dense_wave64_supported(kind, a.N) && g_dense_wave64.load() != 0)
         return launch_bwd_dense_wave64(kind, a, use_worklist, s);

@@ -5,6 +5,8 @@
 #include "../../include/diffqcqp_hip.h"
 #include "common.h"
 
+#include <atomic>
+
 #if defined(__HIPCC__)
 #include <tuple>
 #include <utility>
@@ -19,6 +21,7 @@ namespace dqq {
 constexpr int kWsCount = 0;
 constexpr int kWsTicket = 1;
 constexpr int kWsNext = 2; // work-list mode with dynamic pick-up: next unclaimed entry
+constexpr int kWsFbShadow = 4;  // [4..7]: what this workspace's drain launches last wrote to the feedback buffer, and where (below)
 constexpr int kWsSubTickets = 32;   // first of 32 sub-tickets, kWsSubStride ints apart
 constexpr int kWsSubStride = 32;    // 128 bytes: one sub-ticket per cache line
 // N >= 32 (one to sixteen problems per workgroup of the fast kernel: a dense batch through DQQ_P_AUTO queues from
@@ -70,6 +73,53 @@ static DQQ_D void worklist_release(int* ws, long count, int participants)
             }
         }
     }
+}
+#endif
+
+// ---- feedback from the drain launches (round 4).  Which kernel drains a work-list best depends on how long the list is: the
+// team kernel (bwd_small.hip) for a few thousand problems, the lane-per-problem kernel (bwd_lane_dense.hip) when the list
+// fills the chip -- and the host, which picks the kernel, never sees the length (it sits in device memory and nothing on
+// this path may wait for the device).  With a feedback buffer registered (dqq_set_feedback: 128 bytes of host memory the
+// device can write) every drain launch of the N <= 8 QP / QCQP backward stores (B, entries it found) in the word of its
+// (kind, N) -- when it differs from what the same workspace stored there last --; the NEXT backward of that kind, N and B
+// reads the word -- whatever launch wrote it last -- and routes by it.
+// A hint, never a dependency: both kernels drain ANY list, with the same bits (tests/test_gpu_parity.py), so a stale or racy
+// word costs time only; no buffer, a first call, another B: the team kernel, as before.
+constexpr int kFeedbackWords = 16;   // 8-byte words: kind (QP, QCQP) x N (2, 4, 6, 8), the rest spare
+extern std::atomic<unsigned long long*> g_feedback_dev;          // device-side address of the buffer, or nullptr
+extern std::atomic<const volatile unsigned long long*> g_feedback_host;
+inline int worklist_feedback_index(int kind, int N)
+{
+    return ((kind == 0 || kind == 1) && N >= 2 && N <= 8 && N % 2 == 0) ? kind * 4 + N / 2 - 1 : -1;
+}
+inline unsigned long long* worklist_feedback_slot(int kind, int N)
+{
+    unsigned long long* fb = g_feedback_dev.load(std::memory_order_relaxed);
+    const int i = worklist_feedback_index(kind, N);
+    return (fb != nullptr && i >= 0) ? fb + i : nullptr;
+}
+// entries the last finished drain launch of (kind, N) found, if it ran on a batch of B problems; -1: not known
+inline long worklist_predicted(int kind, int N, long B)
+{
+    const volatile unsigned long long* fb = g_feedback_host.load(std::memory_order_relaxed);
+    const int i = worklist_feedback_index(kind, N);
+    if (fb == nullptr || i < 0) return -1;
+    const unsigned long long w = fb[i];
+    return (w != 0 && (long)(w >> 32) == (B & 0xffffffffL)) ? (long)(w & 0xffffffffULL) : -1;
+}
+#if defined(__HIPCC__)
+// Call from ONE lane of the launch.  The store goes to host memory, and a launch that has one in flight ends later
+// (headline step +0.5 us, A/B): the workspace header remembers the last word this workspace sent and where, and an unchanged
+// word -- every step of a training loop on one kind of batch -- is not sent again.
+static DQQ_D void worklist_feedback(unsigned long long* fb, int* ws, long B, long count)
+{
+    if (fb == nullptr) return;
+    const unsigned long long v = ((unsigned long long)(B & 0xffffffffL) << 32) | (unsigned long long)count;
+    unsigned long long* shadow = reinterpret_cast<unsigned long long*>(ws + kWsFbShadow);   // (ws: 16-byte aligned)
+    if (shadow[0] == v && shadow[1] == reinterpret_cast<unsigned long long>(fb)) return;
+    shadow[0] = v;
+    shadow[1] = reinterpret_cast<unsigned long long>(fb);
+    __hip_atomic_store(fb, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 #endif
 
@@ -351,9 +401,10 @@ bool bwd_uses_any(int kind, int N);
 int public_max_n(int kind);           // dqq_max_n
 hipError_t launch_fwd_any(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s);
 hipError_t launch_bwd_any(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);
-// lane-per-problem backward for N = 2, 4, 6, 8, QP / QCQP, whole batches declared dense (bwd_lane_dense.hip)
+// lane-per-problem backward for N = 2, 4, 6, 8, QP / QCQP (bwd_lane_dense.hip): whole batches declared dense, or -- when the
+// feedback word says the list is long -- the drain launch of a work-list
 bool bwd_lane_dense_supported(int kind, int N, long B);
-hipError_t launch_bwd_lane_dense(int kind, const BwdArgs& a, hipStream_t s);
+hipError_t launch_bwd_lane_dense(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);
 // statically sized team backward for even N <= 16, QP / QCQP (bwd_small.hip); launch_bwd_dense routes to it
 bool bwd_small_supported(int kind, int N);
 hipError_t launch_bwd_small(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);

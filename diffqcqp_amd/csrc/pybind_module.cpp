@@ -35,6 +35,7 @@ PYBIND11_MODULE(_dqq, m)
     m.def("dqq_max_n", [](int kind) { return dqq_max_n(kind); });
     m.def("dqq_version", []() { return py::bytes(dqq_version()); });
     m.def("dqq_set_option", [](const py::bytes& name, int value) { return dqq_set_option(std::string(name).c_str(), value); });
+    m.def("dqq_set_feedback", [](O host_buffer, std::size_t bytes) { return dqq_set_feedback(ptr<void>(host_buffer), bytes); });
     m.def("dqq_get_option", [](const py::bytes& name) {
         int v = 0;
         const int rc = dqq_get_option(std::string(name).c_str(), &v);

@@ -8,6 +8,8 @@ Workspace: every op takes `workspace=` (ops.make_workspace); without it a per-(d
 capture: warm the capture stream up with one eager call first (or pass workspace=); a cached workspace that was live
 during a capture is never replaced or freed afterwards, so a replayed graph cannot write into recycled memory.
 """
+import os
+
 import torch
 
 from . import _capi
@@ -41,6 +43,25 @@ _MAX_WORKSPACES = 16   # cached (device, stream) pairs; the least recently used 
 _pinned = []           # workspaces handed out while a stream capture was going on: a captured graph has their address
                        # baked in, so they are never replaced, evicted or freed
 _need_cache = {}       # (kind, pas, N, B) -> bytes, cleared by set_option (dqq_scratch_bytes follows the tuning knobs)
+
+
+_feedback_tried = False
+
+
+def feedback_default():
+    """Once per process: register the feedback buffer of dqq_set_feedback (include/diffqcqp_hip.h) unless DQQ_FEEDBACK=0.
+    Through it the backward of a DQQ_P_AUTO batch of N <= 8 learns how many non-diagonal problems the previous one held and
+    picks the faster of two bit-identical kernels for them.  A failure to pin 128 bytes is not an error: the hint is
+    simply absent."""
+    global _feedback_tried
+    if _feedback_tried:
+        return
+    _feedback_tried = True
+    if os.environ.get("DQQ_FEEDBACK", "1") != "0" and torch.cuda.is_available():
+        try:
+            _capi.enable_feedback(True)
+        except (RuntimeError, ValueError):
+            pass
 
 
 def _capturing():
@@ -225,6 +246,8 @@ def qp_backward(P, q, x, grad_x, need_P=True, need_q=True, layout=_capi.P_AUTO, 
     steps = torch.empty(B, dtype=torch.int32, device=dev) if return_steps else None
     stream = _raw_stream(dev.index)
     ws = _workspace(dev, B, stream, 0, 1, N, workspace)
+    if not _feedback_tried and layout == _capi.P_AUTO and N <= 8:
+        feedback_default()
     with _device_guard(dev):
         pd, fl = cache if cache is not None else (None, None)
         rc = _capi.lib().dqq_qp_bwd_f64(_ptr(P), _ptr(q), _ptr(x), _ptr(grad_x), _ptr(gP), _ptr(gq), B, N,
@@ -255,6 +278,8 @@ def qcqp_backward(P, q, l_n, mu, x, grad_x, need=(True, True, True, True), layou
     steps = torch.empty(B, dtype=torch.int32, device=dev) if return_steps else None
     stream = _raw_stream(dev.index)
     ws = _workspace(dev, B, stream, 1, 1, N, workspace)
+    if not _feedback_tried and layout == _capi.P_AUTO and N <= 8:
+        feedback_default()
     with _device_guard(dev):
         gam, dgam = duals if duals is not None else (None, None)
         pd, fl = cache if cache is not None else (None, None)

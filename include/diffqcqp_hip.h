@@ -20,9 +20,12 @@
  *   - return value: 0 on success, <0 for an invalid argument (DQQ_E_*), >0 a
  *     hipError_t from the launch (the launch's own status: the calling thread's
  *     sticky HIP error is neither consumed nor cleared).  Nothing throws.  The only
- *     process-wide state is the tuning knobs of dqq_set_option(); with those fixed,
- *     the kernels a call launches -- and therefore its results, bit for bit -- are a
- *     function of its arguments alone (no history, thread-safe, any stream);
+ *     process-wide state is the tuning knobs of dqq_set_option() and the optional
+ *     feedback buffer of dqq_set_feedback(); with the knobs fixed, a call's results,
+ *     bit for bit, are a function of its arguments alone (no history, thread-safe,
+ *     any stream) -- and so are the kernels it launches unless a feedback buffer is
+ *     registered, which lets ONE launch of the QP / QCQP backward of N <= 8 be chosen
+ *     between two kernels with identical results (see dqq_set_feedback);
  *   - like the reference (Solver.cpp:76, :100), numerical failure is not
  *     signalled: a non-PD P or L=0 yields NaNs in the output;
  *   - `warm_start` does not appear: the reference accepts it and overwrites it
@@ -185,8 +188,9 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
  *                    wave-per-problem kernel (0)
  *   "small_bwd"      general path, even N <= 16 backward (QP, QCQP): statically sized team kernel (1, default) or the
  *                    wave / team kernel with run-time sizes (0)
- *   "lane_bwd"       general path, N = 2, 4, 6, 8 backward (QP, QCQP), DQQ_P_DENSE, B >= 16384: lane-per-problem kernel (1,
- *                    default) or the team kernel (0).  Bit-identical results.
+ *   "lane_bwd"       general path, N = 2, 4, 6, 8 backward (QP, QCQP), B >= 16384: lane-per-problem kernel (1, default) for
+ *                    DQQ_P_DENSE batches and -- with dqq_set_feedback -- for the long work-lists of DQQ_P_AUTO batches, or
+ *                    always the team kernel (0).  Bit-identical results.
  *   "lane_dense"     general path, N = 2..8 forward: lane-per-problem kernel (1, default) or the
  *                    wave-per-problem kernel (0)
  *   "lane_defer"     general forward for N <= 16 (lane-per-problem kernel, the group solve inside the fused fast
@@ -201,10 +205,29 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
  *                    evaluation-order noise of the reference's own formulas) or the reference-order kernels (0: LDS
  *                    wave kernel up to N = 42, global-memory kernel beyond -- 1e-9, 10-30x slower, and 42 < N <= 64
  *                    then needs dqq_scratch_bytes of scratch)
+ *   "lane_list_drains"  not a knob: a counter of the drain launches that dqq_set_feedback's word routed to the
+ *                    lane-per-problem kernel (read with dqq_get_option, reset by setting it)
  *   "auto_fallback"  0 skips the dense-kernel launch of DQQ_P_AUTO -- measurement only: non-diagonal
  *                    tiles are then left unsolved (default 1) */
 int dqq_set_option(const char* name, int value);
 int dqq_get_option(const char* name, int* value);
+
+/* Optional feedback buffer for the backward of DQQ_P_AUTO batches, N <= 8, QP / QCQP.
+ *
+ * Behind the diagonal fast path's backward, a second launch solves the problems whose P is not diagonal.  Two kernels can
+ * do it -- a team of lanes per problem (best for up to a few thousand such problems) and a lane per problem (2x faster once
+ * they fill the chip: 65536 dense 8x8 QCQP problems 100 -> ~60 us) -- and how many there are is known on the device only.
+ * With a buffer registered, that launch stores the number it found in the buffer, and the NEXT backward of the same kind, N
+ * and B picks its kernel by it (a training loop presents the same kind of batch step after step).  The two kernels give
+ * the same results bit for bit on any list, so the word is a hint: stale, racy or absent, it changes the time of a call and
+ * nothing else.  Nothing ever waits for the device.
+ *
+ * `host_buffer`: DQQ_FEEDBACK_BYTES of zero-initialised host memory that the device can write (hipHostMalloc /
+ * hipHostRegister, or torch's pin_memory()), 8-byte aligned, valid until replaced or the process ends; NULL unregisters.
+ * Returns 0, DQQ_E_BAD_SIZE (too small / misaligned), or the hipError_t of hipHostGetDevicePointer (not pinned memory).
+ * The library never allocates: without a buffer the team kernel is always the one launched, as before round 4. */
+#define DQQ_FEEDBACK_BYTES 128
+int dqq_set_feedback(void* host_buffer, size_t bytes);
 
 /* "diffqcqp_hip <version> gfx950" */
 const char* dqq_version(void);

@@ -76,6 +76,9 @@ def test_argument_validation_without_gpu(lib):
     # DQQ_P_DENSE beyond the register / LDS kernels: the scratch is the caller's, nothing is allocated inside
     assert f(one, one, one, 4, 80, 1e-7, 1e-7, 10, 1, 1, None, None, None, None, 0, None) == -5
     assert lib.dqq_set_option(b"no_such_knob", 1) == -6
+    # the feedback buffer: NULL unregisters; a buffer too small or misaligned is refused before anything touches it
+    assert lib.dqq_set_feedback(None, 0) == 0
+    assert lib.dqq_set_feedback(4096, 64) == -2 and lib.dqq_set_feedback(4100, 128) == -2
 
 
 def test_python_layer_fails_loudly_without_gpu():

@@ -405,6 +405,79 @@ def test_lane_per_problem_backward_is_the_team_kernel_bit_for_bit(oracle, ops, k
     check_backward_exact([t[:n] for t in out[1][0]], out[1][1][:n], ref, exact=True)
 
 
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("N,B", [(8, 24576 + 2048 + 13), (4, 16384 + 2048 + 500)])
+def test_feedback_routes_a_long_work_list_to_the_lane_kernel_same_bits(ops, kind, N, B):
+    """DQQ_P_AUTO, a batch that is (almost) all dense: the drain launch behind the diagonal backward reports the length of its
+    work-list to the feedback word (dqq_set_feedback); the next backward of the same kind, N and B drains with the
+    lane-per-problem kernel (bwd_lane_dense.hip, LIST) instead of the team kernel.  Same bits, whichever drains; the
+    work-list header is left clean (a third call); a stale word (the list has become short, or empty) costs time only."""
+    from diffqcqp_amd import _capi
+    d = make_problem(kind, B, N, 790 + N, "dense")
+    ndiag = 2048                                    # a diagonal stretch (whole tiles) in the middle: those take the fast path
+    for i in range(N):
+        for j in range(N):
+            if i != j:
+                d["P"][3008:3008 + ndiag, i, j] = 0.0
+    g = dev(d)
+    x = hip_fwd(ops, kind, g, layout=_capi.P_AUTO)[0]
+    slot = (0 if kind == "qp" else 1) * 4 + N // 2 - 1
+    was_on = _capi._feedback is not None
+    _capi.enable_feedback(True)
+    _capi.set_option("lane_list_drains", 0)
+    try:
+        _capi._feedback.zero_()
+        team = hip_bwd(ops, kind, g, x)             # nothing known yet: the team kernel drains, and reports
+        torch.cuda.synchronize()
+        assert _capi.get_option("lane_list_drains") == 0
+        assert _capi.feedback_words()[slot] == (B, B - ndiag)
+        lane = hip_bwd(ops, kind, g, x)             # the word says "long": the lane kernel drains
+        lane2 = hip_bwd(ops, kind, g, x)            # ... and left the list's header clean
+        torch.cuda.synchronize()
+        assert _capi.get_option("lane_list_drains") == 2
+        assert _capi.feedback_words()[slot] == (B, B - ndiag)
+        for other in (lane, lane2):
+            for a, b in zip(team[0], other[0]):
+                assert torch.equal(a, b)
+            assert torch.equal(team[1], other[1])
+        # the same B, now diagonal but for 70 problems: the stale word sends the lane kernel after a short list
+        d2 = make_problem(kind, B, N, 791 + N, "diag")
+        d2["P"][128:198] = d["P"][128:198]           # (tiles are pushed whole: 70 dense problems queue 5 tiles of 16 = 80)
+        g2 = dev(d2)
+        x2 = hip_fwd(ops, kind, g2, layout=_capi.P_AUTO)[0]
+        stale = hip_bwd(ops, kind, g2, x2)
+        torch.cuda.synchronize()
+        assert _capi.get_option("lane_list_drains") == 3
+        assert _capi.feedback_words()[slot][0] == B and 70 <= _capi.feedback_words()[slot][1] <= 70 + 64
+        fresh = hip_bwd(ops, kind, g2, x2)          # corrected: the team kernel again
+        torch.cuda.synchronize()
+        assert _capi.get_option("lane_list_drains") == 3
+        for a, b in zip(stale[0], fresh[0]):
+            assert torch.equal(a, b)
+        assert torch.equal(stale[1], fresh[1])
+        # a stale "long" in front of an EMPTY list (a diagonal batch): every wave of the lane kernel leaves at once
+        _capi._feedback[slot] = (B << 32) | B
+        d3 = make_problem(kind, B, N, 792 + N, "diag")
+        g3 = dev(d3)
+        x3 = hip_fwd(ops, kind, g3, layout=_capi.P_AUTO)[0]
+        e1 = hip_bwd(ops, kind, g3, x3)
+        torch.cuda.synchronize()
+        assert _capi.get_option("lane_list_drains") == 4 and _capi.feedback_words()[slot] == (B, 0)
+        e2 = hip_bwd(ops, kind, g3, x3)
+        for a, b in zip(e1[0], e2[0]):
+            assert torch.equal(a, b)
+        # without the buffer: the team kernel, whatever came before
+        _capi.enable_feedback(False)
+        _capi.set_option("lane_list_drains", 0)
+        off = hip_bwd(ops, kind, g, x)
+        torch.cuda.synchronize()
+        assert _capi.get_option("lane_list_drains") == 0
+        for a, b in zip(team[0], off[0]):
+            assert torch.equal(a, b)
+    finally:
+        _capi.enable_feedback(was_on)
+
+
 @pytest.mark.parametrize("kind,N,B", [("qcqp", 64, 40), ("qcqp", 50, 24), ("qcqp", 44, 24), ("box", 32, 48), ("box", 22, 30)])
 def test_reference_order_backward_beyond_the_wave_kernel(oracle, ops, kind, N, B):
     """The global-memory workgroup kernel in the reference's operation order -- the default for box 21 < N <= 32, and for
@@ -510,12 +583,20 @@ def test_auto_layout_mixed_batch_uses_fallback(oracle, ops, kind, N):
         else:
             check_backward_exact(grads, st, oracle_bwd(oracle, kind, d, xo), exact=False)
     for ws in ops._workspaces.values():
-        assert int(ws[:WS_HEADER_INTS].abs().sum()) == 0  # work-list count, exit tickets, pick-up index: left zeroed
+        assert header_is_clean(ws)  # work-list count, exit tickets, pick-up index: left zeroed
 
 
 # csrc/launch.h kWsEntries: count, ticket, next, 32 sub-tickets and the 32 segment counters of the N >= 32 list, a cache
 # line apart each
 WS_HEADER_INTS = 32 + 2 * 32 * 32
+
+
+def header_is_clean(ws):
+    """Count, exit tickets, pick-up index, segment counters: zero after every launch.  Ints 4..7 (kWsFbShadow) are not part
+    of the list: the last word this workspace's drain launches sent to the feedback buffer (dqq_set_feedback), and where."""
+    h = ws[:WS_HEADER_INTS].clone()
+    h[4:8] = 0
+    return int(h.abs().sum()) == 0
 
 
 @pytest.mark.parametrize("kind", ["qp", "qcqp"])
@@ -537,7 +618,7 @@ def test_worklist_header_is_rezeroed_by_large_drains(ops, kind, N, B):
             ga, sta = hip_bwd(ops, kind, g, xd)
             torch.cuda.synchronize()
             for ws in ops._workspaces.values():
-                assert int(ws[:WS_HEADER_INTS].abs().sum()) == 0
+                assert header_is_clean(ws)
             if first is None:
                 first = (xa, ita, ga, sta)
                 # the general kernels behind the work-list may differ from the ones DQQ_P_DENSE picks for this size
@@ -558,7 +639,7 @@ def test_worklist_header_is_rezeroed_by_large_drains(ops, kind, N, B):
         assert torch.isfinite(x1).all() and int(it1.min()) >= 1
         torch.cuda.synchronize()
         for ws in ops._workspaces.values():
-            assert int(ws[:WS_HEADER_INTS].abs().sum()) == 0
+            assert header_is_clean(ws)
     finally:
         _capi.set_option("fuse_fallback", -1)
 
@@ -1123,7 +1204,7 @@ def test_segmented_worklist_uneven_segments(ops, kind, N, B, pattern):
             ga, sa = hip_bwd(ops, kind, g, xd, layout=0)
             torch.cuda.synchronize()
             for ws in ops._workspaces.values():
-                assert int(ws[:WS_HEADER_INTS].abs().sum()) == 0
+                assert header_is_clean(ws)
             # queued problems: the very kernel DQQ_P_DENSE launches -> the same bits
             assert np.array_equal(npy(xa)[nd], npy(xd)[nd]) and np.array_equal(npy(ita)[nd], npy(itd)[nd])
             assert np.array_equal(npy(sa)[nd], npy(sd)[nd])

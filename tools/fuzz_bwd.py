@@ -1,6 +1,7 @@
 """Randomised parity of the backward routes against the oracle (x from the oracle on both sides): random kind, N, batch
 size, structure, layout, fused / work-list fallback, with and without the forward's diagonal hand-off.
-usage: python tools/fuzz_bwd.py [trials] [seed] [big]"""
+usage: python tools/fuzz_bwd.py [trials] [seed] [big | lane]   (lane: only the batches the lane-per-problem backward takes --
+N <= 8, QP / QCQP, B >= 16384 -- declared dense or through DQQ_P_AUTO with the feedback word of dqq_set_feedback poked)"""
 import os, sys
 import numpy as np
 import torch
@@ -12,14 +13,17 @@ from oracle import oracle as O
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-bad, worst = 0, 0.0
+bad, worst, lane_list = 0, 0.0, 0
+_capi.set_option("lane_list_drains", 0)
 for t in range(trials):
     kind = str(rng.choice(["qp", "qcqp", "box"]))
-    N = int(rng.choice([2, 4, 8, 16, 32] if len(sys.argv) <= 3 else [2, 3, 5, 6, 8, 10, 12, 16, 17, 20, 22, 24, 32, 33, 40, 44, 48, 56, 64, 70]))
+    LANE = len(sys.argv) > 3 and sys.argv[3] == "lane"
+    if LANE: kind = str(rng.choice(["qp", "qcqp"]))
+    N = int(rng.choice([2, 4, 8]) if LANE else rng.choice([2, 4, 8, 16, 32] if len(sys.argv) <= 3 else [2, 3, 5, 6, 8, 10, 12, 16, 17, 20, 22, 24, 32, 33, 40, 44, 48, 56, 64, 70]))
     if kind == "qcqp" and N % 2: N += 1
     B = int(rng.choice([1, 5, 16, 17, 64, 130, 1000, 2049]))
-    if N <= 8 and kind != "box" and rng.integers(8) == 0:
-        B = int(rng.choice([16384, 16421, 24576, 24700, 33001]))   # the lane-per-problem backward (bwd_lane_dense.hip, DQQ_P_DENSE)
+    if N <= 8 and kind != "box" and (LANE or rng.integers(8) == 0):
+        B = int(rng.choice([16384, 16421, 24576, 24700, 33001]))   # the lane-per-problem backward (bwd_lane_dense.hip: DQQ_P_DENSE, or the drain of a long list)
     if N >= 32: B = min(B, 130 if N == 32 else 17)
     if N > 16 and kind == 'box': B = min(B, 17)
     structure = str(rng.choice(["diag", "dense", "mixed", "nonsym"]))
@@ -35,6 +39,12 @@ for t in range(trials):
         d["P"] = (d["P"] + torch.triu(torch.rand(B, N, N, generator=gg, dtype=torch.float64), diagonal=1) * 0.05).contiguous()
     P, q, gx = d["P"].numpy(), d["q"].numpy(), d["grad_x"].numpy()
     for k, v in opts.items(): _capi.set_option(k, v)
+    if B >= 16384 and layout == 0 and kind != "box":
+        # the feedback word of dqq_set_feedback, set to anything: a "long list" sends the lane-per-problem kernel (LIST) after
+        # whatever list this batch has -- full, every other tile, empty; a hint must never change a result
+        _capi.enable_feedback(True)
+        _capi._feedback[(0 if kind == "qp" else 1) * 4 + N // 2 - 1] = (B << 32) | int(rng.choice([0, 30000, B]))
+        lane_list += 1
     g = {k: v.cuda() for k, v in d.items()}
     cache = ops.diag_cache(g["q"]) if use_cache else None
     if kind == "qp":
@@ -73,4 +83,5 @@ for t in range(trials):
         bad += 1
         print("FAIL", t, kind, N, B, structure, layout, opts, "cache", use_cache, "rel %.2e exits equal %.3f finite %s" % (rel, same.mean(), finite), flush=True)
 for k, v in {"fuse_fallback": -1, "wpb": 0, "small_bwd": 1, "dense_teams": 1, "dense_wave64": 1, "wave_qcqp_bwd": 1, "lane_bwd": 1}.items(): _capi.set_option(k, v)
-print("%d trials, %d failures, worst rel err %.2e" % (trials, bad, worst))
+print("%d trials, %d failures, worst rel err %.2e  (feedback word poked in %d trials, %d drains by the lane kernel)"
+      % (trials, bad, worst, lane_list, _capi.get_option("lane_list_drains")))
