@@ -17,6 +17,8 @@ extern std::atomic<int> g_dense_teams;
 extern std::atomic<int> g_small_bwd;
 extern std::atomic<int> g_lane_bwd;
 extern std::atomic<int> g_lane_list_drains;
+extern std::atomic<int> g_fwd_feedback;
+extern std::atomic<int> g_fwd_feedback_routes;
 extern std::atomic<int> g_small_fwd;
 extern std::atomic<int> g_wave_qcqp_bwd;
 }
@@ -44,6 +46,8 @@ Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback"
                       {"small_bwd", &dqq::g_small_bwd},
                       {"lane_bwd", &dqq::g_lane_bwd},
                       {"lane_list_drains", &dqq::g_lane_list_drains},
+                      {"fwd_feedback", &dqq::g_fwd_feedback},
+                      {"fwd_feedback_routes", &dqq::g_fwd_feedback_routes},
                       {"small_fwd", &dqq::g_small_fwd},
                       {"wave_qcqp_bwd", &dqq::g_wave_qcqp_bwd}};
 

@@ -382,6 +382,9 @@ bool fwd_diag_will_fuse(int N, long B, int layout, int fuse_opt)
            (fuse_opt < 0 ? fwd_diag_fuses_fallback(N, B) : fuse_opt != 0);
 }
 
+std::atomic<int> g_fwd_feedback{1};          // option "fwd_feedback": 0 = the forward never looks at the feedback word
+std::atomic<int> g_fwd_feedback_routes{0};   // a counter (tests): forwards the feedback word moved to four lanes per problem
+
 // lpp / wpb == 0 -> built-in choice; an lpp the kernel is not instantiated for falls back to the
 // built-in one.  *needs_fallback: the caller must launch the dense kernel in work-list mode next.
 hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fuse_opt, hipStream_t s,
@@ -393,6 +396,16 @@ hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fus
         lpp = fwd_diag_default_lpp(a.N, a.B, kind);
         // a batch declared dense takes the general solve's own mapping (N/2 lanes per problem): one pass per tile
         if (a.layout == DQQ_P_DENSE && a.N <= 8) lpp = a.N / 2;
+        // ... and so does a DQQ_P_AUTO batch when the last backward of this kind, N and B found most of its problems
+        // non-diagonal (launch.h: the feedback word of dqq_set_feedback): on two lanes per problem a non-diagonal tile of
+        // N = 8 takes TWO passes of the four-lane general solve (dense 65536 x 8, forward: QP 106 -> 77 us, QCQP 116 -> 94).
+        // The same bits either way -- an iterate does not depend on the lane layout (admm_diag_body.inc), the general
+        // solve is the four-lane one in both -- so the hint costs or saves time, nothing else.
+        if (a.layout == DQQ_P_AUTO && fuse && a.N == 8 && kind < 2 && lpp == 2 && g_fwd_feedback.load() != 0 &&
+            2 * worklist_predicted(kind, a.N, a.B) >= a.B) {
+            lpp = 4;
+            g_fwd_feedback_routes.fetch_add(1, std::memory_order_relaxed);
+        }
     }
     if (needs_fallback) *needs_fallback = (a.layout == DQQ_P_AUTO) && !fuse;
     hipError_t e = hipErrorInvalidValue;

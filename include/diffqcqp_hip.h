@@ -24,8 +24,9 @@
  *     feedback buffer of dqq_set_feedback(); with the knobs fixed, a call's results,
  *     bit for bit, are a function of its arguments alone (no history, thread-safe,
  *     any stream) -- and so are the kernels it launches unless a feedback buffer is
- *     registered, which lets ONE launch of the QP / QCQP backward of N <= 8 be chosen
- *     between two kernels with identical results (see dqq_set_feedback);
+ *     registered, which lets the QP / QCQP forward of N = 8 and one launch of the
+ *     backward of N <= 8 be chosen between two kernels (lane layouts) with identical
+ *     results (see dqq_set_feedback);
  *   - like the reference (Solver.cpp:76, :100), numerical failure is not
  *     signalled: a non-PD P or L=0 yields NaNs in the output;
  *   - `warm_start` does not appear: the reference accepts it and overwrites it
@@ -205,6 +206,9 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
  *                    evaluation-order noise of the reference's own formulas) or the reference-order kernels (0: LDS
  *                    wave kernel up to N = 42, global-memory kernel beyond -- 1e-9, 10-30x slower, and 42 < N <= 64
  *                    then needs dqq_scratch_bytes of scratch)
+ *   "fwd_feedback"   DQQ_P_AUTO forward, N = 8, QP / QCQP, with dqq_set_feedback: four lanes per problem instead of two when the
+ *                    last backward of this kind, N and B found at least half of the batch non-diagonal (1, default), or
+ *                    never look at the word (0).  Bit-identical results.  "fwd_feedback_routes" counts those launches.
  *   "lane_list_drains"  not a knob: a counter of the drain launches that dqq_set_feedback's word routed to the
  *                    lane-per-problem kernel (read with dqq_get_option, reset by setting it)
  *   "auto_fallback"  0 skips the dense-kernel launch of DQQ_P_AUTO -- measurement only: non-diagonal
@@ -218,7 +222,9 @@ int dqq_get_option(const char* name, int* value);
  * do it -- a team of lanes per problem (best for up to a few thousand such problems) and a lane per problem (2x faster once
  * they fill the chip: 65536 dense 8x8 QCQP problems 100 -> ~60 us) -- and how many there are is known on the device only.
  * With a buffer registered, that launch stores the number it found in the buffer, and the NEXT backward of the same kind, N
- * and B picks its kernel by it (a training loop presents the same kind of batch step after step).  The two kernels give
+ * and B picks its kernel by it (a training loop presents the same kind of batch step after step); the next FORWARD of that
+ * kind, N = 8 and B spreads its problems over four lanes instead of two when most of them were non-diagonal (one pass of
+ * the in-kernel general solve instead of two: dense 65536 x 8 QCQP forward 116 -> 94 us).  The two kernels give
  * the same results bit for bit on any list, so the word is a hint: stale, racy or absent, it changes the time of a call and
  * nothing else.  Nothing ever waits for the device.
  *

@@ -478,6 +478,50 @@ def test_feedback_routes_a_long_work_list_to_the_lane_kernel_same_bits(ops, kind
         _capi.enable_feedback(was_on)
 
 
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+def test_feedback_moves_a_mostly_dense_forward_to_four_lanes_same_bits(ops, kind):
+    """DQQ_P_AUTO, N = 8, a batch large enough for two lanes per problem: once the backward's drain has reported that most of
+    the batch is non-diagonal, the next forward of that kind, N and B runs on four lanes per problem -- one pass of the
+    in-kernel general solve per tile instead of two.  x and the iteration counts are the same bits, for the dense tiles
+    and for the diagonal ones (a third of this batch)."""
+    from diffqcqp_amd import _capi
+    N, B = 8, 57344 + 4096 + 21
+    d = make_problem(kind, B, N, 795, "dense")
+    d3 = make_problem(kind, B, N, 796, "diag")
+    third = (B // 3) // 64 * 64
+    d["P"][1024:1024 + third] = d3["P"][1024:1024 + third]
+    g = dev(d)
+    slot = (0 if kind == "qp" else 1) * 4 + N // 2 - 1
+    was_on = _capi._feedback is not None
+    _capi.enable_feedback(True)
+    try:
+        _capi._feedback.zero_()
+        _capi.set_option("fwd_feedback_routes", 0)
+        x2, it2 = hip_fwd(ops, kind, g)                       # nothing known: two lanes per problem
+        assert _capi.get_option("fwd_feedback_routes") == 0
+        hip_bwd(ops, kind, g, x2)
+        torch.cuda.synchronize()
+        assert _capi.feedback_words()[slot] == (B, B - third)
+        x4, it4 = hip_fwd(ops, kind, g)                       # most of the batch was non-diagonal: four lanes
+        assert _capi.get_option("fwd_feedback_routes") == 1
+        assert torch.equal(x2, x4) and torch.equal(it2, it4)
+        _capi.set_option("fwd_lpp", 4)                        # (what the hint selects is the existing four-lane instantiation)
+        xf, itf = hip_fwd(ops, kind, g)
+        _capi.set_option("fwd_lpp", 0)
+        assert torch.equal(x4, xf) and torch.equal(it4, itf)
+        _capi.set_option("fwd_feedback", 0)
+        hip_fwd(ops, kind, g)
+        assert _capi.get_option("fwd_feedback_routes") == 1   # the option keeps the forward off the word
+        _capi.set_option("fwd_feedback", 1)
+        _capi._feedback[slot] = (B << 32) | (B // 2 - 1)      # fewer than half: two lanes
+        hip_fwd(ops, kind, g)
+        assert _capi.get_option("fwd_feedback_routes") == 1
+    finally:
+        _capi.set_option("fwd_lpp", 0)
+        _capi.set_option("fwd_feedback", 1)
+        _capi.enable_feedback(was_on)
+
+
 @pytest.mark.parametrize("kind,N,B", [("qcqp", 64, 40), ("qcqp", 50, 24), ("qcqp", 44, 24), ("box", 32, 48), ("box", 22, 30)])
 def test_reference_order_backward_beyond_the_wave_kernel(oracle, ops, kind, N, B):
     """The global-memory workgroup kernel in the reference's operation order -- the default for box 21 < N <= 32, and for
