@@ -152,7 +152,12 @@ def feedback_words():
     """The registered buffer's words as (B, entries) pairs, index kind * 4 + N / 2 - 1 (a debugging view), or None."""
     if _feedback is None:
         return None
-    return [((int(w) >> 32) & 0xffffffff, int(w) & 0xffffffff) for w in _feedback.tolist()]
+    return [((int(w) >> 32) & 0x3fffffff, int(w) & 0xffffffff) for w in _feedback.tolist()]
+
+
+def feedback_streaks():
+    """Bits 62..63 of each word: consecutive earlier reports of "every problem of the batch" (saturating at 3)."""
+    return None if _feedback is None else [(int(w) >> 62) & 3 for w in _feedback.tolist()]
 
 
 def version():

@@ -490,11 +490,42 @@ static DQQ_D __attribute__((always_inline)) void qcqp_system(double (&Pm)[N][N],
     }
 }
 
+// REPORT mode (below): one call per wave.  A wave's count and its arrival travel in ONE 64-bit atomic (arrivals in the high
+// word, problems in the low one), in two levels like the exit tickets of worklist_release -- wave i on the word of cache line
+// i mod 32, the last arrival of each group on the top word -- so that no address sees more than 32 atomics and nothing needs a
+// fence (with __threadfence() between a count and a ticket, an L2 write-back per wave, the report cost 16 us of a 55 us launch).
+// The words are the idle work-list header's (no list is in use by this launch) and are left zero.
+static DQQ_D void report_nondiagonal(int* ws, int cnt, unsigned long long* fb, long B)
+{
+    const int g = (int)(blockIdx.x & 31u);
+    const unsigned long long members = (unsigned long long)(((int)gridDim.x - g + 31) >> 5);
+    unsigned long long* sub = reinterpret_cast<unsigned long long*>(ws + kWsSubTickets + g * kWsSubStride);
+    const unsigned long long one = 1ull << 32;
+    const unsigned long long before = atomicAdd(sub, one | (unsigned long long)cnt);
+    if ((before >> 32) == members - 1) {
+        *sub = 0;
+        const unsigned long long gc = (before & 0xffffffffull) + (unsigned long long)cnt;
+        unsigned long long* top = reinterpret_cast<unsigned long long*>(ws + kWsRepTop);
+        const unsigned long long groups = gridDim.x < 32u ? gridDim.x : 32u;
+        const unsigned long long tb = atomicAdd(top, one | gc);
+        if ((tb >> 32) == groups - 1) {
+            *top = 0;
+            worklist_feedback(fb, ws, B, (long)((tb & 0xffffffffull) + gc));
+        }
+    }
+}
+
 // LIST: the drain launch behind the diagonal fast path's backward (DQQ_P_AUTO) -- the problems are the entries of the
 // work-list `ws` (launch.h), 64 consecutive entries per wave; `B` is then the batch the list was drawn from.  The launch is
 // sized for B entries: a wave beyond the list leaves on one scalar load, the first one reports the list's length to the
 // host's feedback word (launch.h worklist_feedback) and the last one out re-zeroes the list's header.
-template <int KIND, int N, bool LIST>
+//
+// REPORT: a DQQ_P_AUTO batch that the feedback word says was ALL queued last time -- the diagonal fast path's launch is skipped
+// altogether and every problem solved here (a diagonal problem gets the same bits from this routine as from the fast path:
+// both follow the reference's order; tools/probe_diag_in_general_bits.py, tests).  Nothing classifies the batch then, so this
+// launch does, for the next call: each wave counts the problems the fast path WOULD have queued (whole tiles of its
+// 128 / N problems, as bwd_diag.hip pushes them) and the last wave to have counted sends the total to the feedback word.
+template <int KIND, int N, int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 1 && N > 4) ? 1 : 2))) void bwd_lane_dense_kernel(
     const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ aux0,
     const double* __restrict__ aux1, const double* __restrict__ x, const double* __restrict__ grad_x,
@@ -505,6 +536,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 
 #pragma clang fp contract(off)
     using S = LaneSys<KIND, N>;
     constexpr int M = S::M, NC = S::NC;
+    constexpr bool LIST = MODE == 1, REPORT = MODE == 2;
     const long total = LIST ? (long)ws[kWsCount] : B;   // problems of this launch
     if constexpr (LIST) {
         if (blockIdx.x == 0 && threadIdx.x == 0) worklist_feedback(feedback, ws, B, total);
@@ -548,6 +580,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 
 #pragma unroll
             for (int j = 0; j < N; ++j) Pm[i][j] = Pl[i * N + j];
         __syncthreads();   // the tile is in registers: K may overwrite it
+        if constexpr (REPORT) {
+            bool nd = false;
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    if (i != j) nd = nd || (Pm[i][j] != 0.0);
+            const unsigned long long mask = __ballot(valid && nd);
+            if (threadIdx.x == 0) {
+                constexpr int T = 128 / N;   // problems per wave tile of bwd_diag_kernel
+                int cnt = 0;
+#pragma unroll
+                for (int g0 = 0; g0 < 64; g0 += T) {
+                    const unsigned long long grp = (T == 64) ? mask : ((mask >> g0) & ((1ull << (T % 64)) - 1));
+                    const int members = nvalid - g0 < T ? nvalid - g0 : T;
+                    if (grp != 0 && members > 0) cnt += members;
+                }
+                report_nondiagonal(ws, cnt, feedback, B);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < N; i += 2) {
             const double2 a = *reinterpret_cast<const double2*>(x + prob * N + i);
@@ -672,7 +724,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 
 
 #undef DQQ_KL
 
-template <int KIND, int N, bool LIST>
+template <int KIND, int N, int MODE>
 static hipError_t launch_lane_bwd(const BwdArgs& a, hipStream_t s)
 {
     using S = LaneSys<KIND, N>;
@@ -680,13 +732,13 @@ static hipError_t launch_lane_bwd(const BwdArgs& a, hipStream_t s)
     const size_t lds = sizeof(double) * 64 * (size_t)(S::LDS_SLOTS > N * N + 1 ? S::LDS_SLOTS : N * N + 1);
     const long grid = (a.B + 63) / 64;
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_lane_dense_kernel<KIND, N, LIST>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_lane_dense_kernel<KIND, N, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    return launch(bwd_lane_dense_kernel<KIND, N, LIST>, dim3((unsigned)grid), dim3(64), lds, s, a.P, a.q, a.l_n, a.mu, a.x,
+    return launch(bwd_lane_dense_kernel<KIND, N, MODE>, dim3((unsigned)grid), dim3(64), lds, s, a.P, a.q, a.l_n, a.mu, a.x,
                   a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.epsilon, a.ir_steps, a.ws,
-                  LIST ? worklist_feedback_slot(KIND, N) : nullptr);
+                  MODE != 0 ? worklist_feedback_slot(KIND, N) : nullptr);
 }
 
 // P declared dense, QP / QCQP, N = 2, 4, 6, 8, batches that fill the chip: a lane per problem needs 64 problems per wave
@@ -704,13 +756,16 @@ bool bwd_lane_dense_supported(int kind, int N, long B)
     return (kind == kKindQP || kind == kKindQCQP) && (N == 2 || N == 4 || N == 6 || N == 8) && B >= min_b;
 }
 
-hipError_t launch_bwd_lane_dense(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)
+// mode 0: the whole batch, declared dense; 1: the entries of the work-list; 2: the whole batch of a DQQ_P_AUTO call, reporting
+hipError_t launch_bwd_lane_dense(int kind, const BwdArgs& a, int mode, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
-#define DQQ_CASE(NN)                                                                                              \
-    if (a.N == NN)                                                                                                \
-        return use_worklist ? (kind == 0 ? launch_lane_bwd<0, NN, true>(a, s) : launch_lane_bwd<1, NN, true>(a, s)) \
-                            : (kind == 0 ? launch_lane_bwd<0, NN, false>(a, s) : launch_lane_bwd<1, NN, false>(a, s));
+#define DQQ_CASE(NN)                                                                                               \
+    if (a.N == NN) {                                                                                               \
+        if (mode == 1) return kind == 0 ? launch_lane_bwd<0, NN, 1>(a, s) : launch_lane_bwd<1, NN, 1>(a, s);       \
+        if (mode == 2) return kind == 0 ? launch_lane_bwd<0, NN, 2>(a, s) : launch_lane_bwd<1, NN, 2>(a, s);       \
+        return kind == 0 ? launch_lane_bwd<0, NN, 0>(a, s) : launch_lane_bwd<1, NN, 0>(a, s);                      \
+    }
     DQQ_CASE(2) DQQ_CASE(4) DQQ_CASE(6) DQQ_CASE(8)
 #undef DQQ_CASE
     return hipErrorInvalidValue;

@@ -17,6 +17,8 @@ extern std::atomic<int> g_dense_teams;
 extern std::atomic<int> g_small_bwd;
 extern std::atomic<int> g_lane_bwd;
 extern std::atomic<int> g_lane_list_drains;
+extern std::atomic<int> g_bwd_skip_classify;
+extern std::atomic<int> g_bwd_whole_batches;
 extern std::atomic<int> g_fwd_feedback;
 extern std::atomic<int> g_fwd_feedback_routes;
 extern std::atomic<int> g_small_fwd;
@@ -46,6 +48,8 @@ Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback"
                       {"small_bwd", &dqq::g_small_bwd},
                       {"lane_bwd", &dqq::g_lane_bwd},
                       {"lane_list_drains", &dqq::g_lane_list_drains},
+                      {"bwd_skip_classify", &dqq::g_bwd_skip_classify},
+                      {"bwd_whole_batches", &dqq::g_bwd_whole_batches},
                       {"fwd_feedback", &dqq::g_fwd_feedback},
                       {"fwd_feedback_routes", &dqq::g_fwd_feedback_routes},
                       {"small_fwd", &dqq::g_small_fwd},
@@ -201,6 +205,14 @@ static int bwd_dispatch(int kind, dqq::BwdArgs& a, void* workspace, size_t works
     if (scratch > 0) a.scratch = scratch_of(workspace, a.B);
     const bool fused = dqq::bwd_diag_will_fuse(kind, a.N, a.B, a.layout, g_fuse.load());
     if (!fused && !dense_ok) return DQQ_E_UNSUPPORTED_N; // (box QP, N > 32): nothing could drain the work-list
+    // everything was queued last time (feedback word): one launch of the lane-per-problem kernel over the whole batch, which
+    // also recounts for the next call (bwd_lane_dense.hip REPORT; a diagonal problem gets the same bits there)
+    if (!fused && g_auto_fallback.load() != 0 && dqq::bwd_lane_takes_auto_batch(kind, a.N, a.B)) {
+        dqq::g_bwd_whole_batches.fetch_add(1, std::memory_order_relaxed);
+        hipError_t e2 = dqq::launch_bwd_lane_dense(kind, a, 2, s);
+        if (e2 != hipSuccess) reset_worklist(workspace, s);
+        return (int)e2;
+    }
     bool needs_fallback = true;
     hipError_t e = dqq::launch_bwd_diag(kind, a, g_wpb.load(), g_fuse.load(), s, &needs_fallback);
     if (e != hipSuccess) return (int)e;

@@ -16,6 +16,8 @@ std::atomic<int> g_small_fwd{1};   // 0: never the team-per-problem forward of N
 std::atomic<int> g_small_bwd{1};   // 0: never the statically sized team backward of N <= 8 (option "small_bwd")
 std::atomic<unsigned long long*> g_feedback_dev{nullptr};                     // dqq_set_feedback (launch.h)
 std::atomic<const volatile unsigned long long*> g_feedback_host{nullptr};
+std::atomic<int> g_bwd_skip_classify{1};  // option "bwd_skip_classify": 0 = a DQQ_P_AUTO backward always starts with the fast path's launch
+std::atomic<int> g_bwd_whole_batches{0};  // a counter (tests): DQQ_P_AUTO backwards the feedback word sent to the lane kernel whole
 std::atomic<int> g_lane_list_drains{0};   // a counter, not a knob: drain launches routed to the lane kernel by the feedback word (tests)
 std::atomic<int> g_lane_bwd{1};    // 0: never the lane-per-problem backward of N <= 8, DQQ_P_DENSE (option "lane_bwd")
 
@@ -187,6 +189,13 @@ static hipError_t launch_bwd_kind(const BwdArgs& a, bool use_worklist, hipStream
     return launch_bwd_team<KIND, 64>(a, use_worklist, s);
 }
 
+bool bwd_lane_takes_auto_batch(int kind, int N, long B)
+{
+    if (g_lane_bwd.load() == 0 || g_bwd_skip_classify.load() == 0 || !bwd_lane_dense_supported(kind, N, B)) return false;
+    int streak = 0;
+    return worklist_predicted(kind, N, B, &streak) == B && streak >= 1;   // twice running (launch.h)
+}
+
 hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)
 {
     if (a.B == 0) return hipSuccess;
@@ -194,12 +203,12 @@ hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipSt
     // Not in work-list mode unless the list is known to be long: its 512-register waves need an empty SIMD each, and an empty
     // list must cost next to nothing.
     if (!use_worklist && g_lane_bwd.load() != 0 && bwd_lane_dense_supported(kind, a.N, a.B))
-        return launch_bwd_lane_dense(kind, a, false, s);
+        return launch_bwd_lane_dense(kind, a, 0, s);
     // ... and the drain launch of a work-list that the last drain of this kind, N and B found that long (launch.h: feedback)
     if (use_worklist && g_lane_bwd.load() != 0 && bwd_lane_dense_supported(kind, a.N, a.B) &&
         bwd_lane_dense_supported(kind, a.N, worklist_predicted(kind, a.N, a.B))) {
         g_lane_list_drains.fetch_add(1, std::memory_order_relaxed);
-        return launch_bwd_lane_dense(kind, a, true, s);
+        return launch_bwd_lane_dense(kind, a, 1, s);
     }
     if (bwd_small_supported(kind, a.N) && g_small_bwd.load() != 0) return launch_bwd_small(kind, a, use_worklist, s);
     if (bwd_dense_wave64_supported(kind, a.N) && g_dense_wave64.load() != 0)

@@ -21,6 +21,7 @@ namespace dqq {
 constexpr int kWsCount = 0;
 constexpr int kWsTicket = 1;
 constexpr int kWsNext = 2; // work-list mode with dynamic pick-up: next unclaimed entry
+constexpr int kWsRepTop = 8;    // [8..9] bwd_lane_dense.hip, REPORT mode: 64-bit (groups arrived, problems counted); zero between launches
 constexpr int kWsFbShadow = 4;  // [4..7]: what this workspace's drain launches last wrote to the feedback buffer, and where (below)
 constexpr int kWsSubTickets = 32;   // first of 32 sub-tickets, kWsSubStride ints apart
 constexpr int kWsSubStride = 32;    // 128 bytes: one sub-ticket per cache line
@@ -98,25 +99,39 @@ inline unsigned long long* worklist_feedback_slot(int kind, int N)
     const int i = worklist_feedback_index(kind, N);
     return (fb != nullptr && i >= 0) ? fb + i : nullptr;
 }
-// entries the last finished drain launch of (kind, N) found, if it ran on a batch of B problems; -1: not known
-inline long worklist_predicted(int kind, int N, long B)
+// The word: bits 0..31 entries found, 32..61 B (mod 2^30), 62..63 how many times IN A ROW before this one the same
+// workspace reported "every problem of the batch" (saturating at 3).
+constexpr unsigned long long kFbBMask = 0x3fffffffULL;
+// entries the last finished drain launch of (kind, N) found, if it ran on a batch of B problems; -1: not known.
+// *streak (optional): consecutive earlier reports of count == B.
+inline long worklist_predicted(int kind, int N, long B, int* streak = nullptr)
 {
     const volatile unsigned long long* fb = g_feedback_host.load(std::memory_order_relaxed);
     const int i = worklist_feedback_index(kind, N);
+    if (streak != nullptr) *streak = 0;
     if (fb == nullptr || i < 0) return -1;
     const unsigned long long w = fb[i];
-    return (w != 0 && (long)(w >> 32) == (B & 0xffffffffL)) ? (long)(w & 0xffffffffULL) : -1;
+    if (w == 0 || ((w >> 32) & kFbBMask) != ((unsigned long long)B & kFbBMask)) return -1;
+    if (streak != nullptr) *streak = (int)(w >> 62);
+    return (long)(w & 0xffffffffULL);
 }
 #if defined(__HIPCC__)
 // Call from ONE lane of the launch.  The store goes to host memory, and a launch that has one in flight ends later
 // (headline step +0.5 us, A/B): the workspace header remembers the last word this workspace sent and where, and an unchanged
-// word -- every step of a training loop on one kind of batch -- is not sent again.
+// word -- every step of a training loop on one kind of batch -- is not sent again.  The streak (above) is what lets the host
+// skip the fast path's launch only for a caller whose batches have been all non-diagonal at least twice running: a caller
+// that alternates between kinds of batches under one (kind, N, B) never gets there.
 static DQQ_D void worklist_feedback(unsigned long long* fb, int* ws, long B, long count)
 {
     if (fb == nullptr) return;
-    const unsigned long long v = ((unsigned long long)(B & 0xffffffffL) << 32) | (unsigned long long)count;
     unsigned long long* shadow = reinterpret_cast<unsigned long long*>(ws + kWsFbShadow);   // (ws: 16-byte aligned)
-    if (shadow[0] == v && shadow[1] == reinterpret_cast<unsigned long long>(fb)) return;
+    const unsigned long long prev = shadow[0], bb = (unsigned long long)B & kFbBMask;
+    const bool same_place = shadow[1] == reinterpret_cast<unsigned long long>(fb);
+    unsigned long long streak = 0;
+    if (same_place && ((prev >> 32) & kFbBMask) == bb && (prev & 0xffffffffULL) == (unsigned long long)B && count == B)
+        streak = (prev >> 62) < 3 ? (prev >> 62) + 1 : 3;
+    const unsigned long long v = (streak << 62) | (bb << 32) | (unsigned long long)count;
+    if (prev == v && same_place) return;
     shadow[0] = v;
     shadow[1] = reinterpret_cast<unsigned long long>(fb);
     __hip_atomic_store(fb, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -404,7 +419,9 @@ hipError_t launch_bwd_any(int kind, const BwdArgs& a, bool use_worklist, hipStre
 // lane-per-problem backward for N = 2, 4, 6, 8, QP / QCQP (bwd_lane_dense.hip): whole batches declared dense, or -- when the
 // feedback word says the list is long -- the drain launch of a work-list
 bool bwd_lane_dense_supported(int kind, int N, long B);
-hipError_t launch_bwd_lane_dense(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);
+hipError_t launch_bwd_lane_dense(int kind, const BwdArgs& a, int mode, hipStream_t s);
+// a DQQ_P_AUTO backward whose every problem was queued last time (feedback word): the lane kernel on the whole batch, reporting
+bool bwd_lane_takes_auto_batch(int kind, int N, long B);
 // statically sized team backward for even N <= 16, QP / QCQP (bwd_small.hip); launch_bwd_dense routes to it
 bool bwd_small_supported(int kind, int N);
 hipError_t launch_bwd_small(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);

@@ -479,6 +479,74 @@ def test_feedback_routes_a_long_work_list_to_the_lane_kernel_same_bits(ops, kind
 
 
 @pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("N,B", [(8, 24576 + 3 * 1024 + 5), (4, 16384 + 777), (2, 16384 + 64)])
+def test_feedback_sends_an_all_dense_auto_batch_to_the_lane_kernel_whole(ops, kind, N, B):
+    """DQQ_P_AUTO, every problem non-diagonal, the same kind / N / B step after step: the third backward skips the diagonal fast
+    path's launch and its work-list altogether -- ONE launch of the lane-per-problem kernel over the batch, which recounts
+    the non-diagonal problems for the call after it (bwd_lane_dense.hip REPORT).  Same bits as the two-launch route; the
+    workspace header is left clean; when the batch then stops being all non-diagonal -- a third of it diagonal, all of it
+    diagonal -- the stale hint still gives the right bits (a diagonal problem gets the same bits from the general routine
+    as from the fast path) and is corrected by that very launch."""
+    from diffqcqp_amd import _capi
+    d = make_problem(kind, B, N, 797 + N, "dense")
+    g = dev(d)
+    x = hip_fwd(ops, kind, g)[0]
+    slot = (0 if kind == "qp" else 1) * 4 + N // 2 - 1
+    was_on = _capi._feedback is not None
+    _capi.enable_feedback(False)
+    ref = hip_bwd(ops, kind, g, x)                              # no hint: fast path's launch + team drain
+    _capi.enable_feedback(True)
+    same = lambda a, b: all(torch.equal(u, v) for u, v in zip(a[0], b[0])) and torch.equal(a[1], b[1])
+    try:
+        _capi._feedback.zero_()
+        _capi.set_option("bwd_whole_batches", 0)
+        for expect_whole, expect_streak in ((0, 0), (0, 1), (1, 2), (2, 3), (3, 3)):
+            out = hip_bwd(ops, kind, g, x)
+            torch.cuda.synchronize()
+            assert same(ref, out)
+            assert _capi.get_option("bwd_whole_batches") == expect_whole
+            assert _capi.feedback_words()[slot] == (B, B) and _capi.feedback_streaks()[slot] == expect_streak
+            for ws in ops._workspaces.values():
+                assert header_is_clean(ws)
+        # a third of the batch turns diagonal (whole tiles): the hint is stale for one call
+        d3 = make_problem(kind, B, N, 798 + N, "diag")
+        third = (B // 3) // 64 * 64
+        d["P"][512:512 + third] = d3["P"][512:512 + third]
+        g = dev(d)
+        x = hip_fwd(ops, kind, g)[0]
+        _capi.enable_feedback(False)
+        ref = hip_bwd(ops, kind, g, x)
+        _capi.enable_feedback(True)
+        _capi._feedback[slot] = (1 << 62) | (B << 32) | B        # (a fresh buffer: what the calls above had left in the old one)
+        out = hip_bwd(ops, kind, g, x)
+        torch.cuda.synchronize()
+        assert same(ref, out) and _capi.get_option("bwd_whole_batches") == 4
+        assert _capi.feedback_words()[slot] == (B, B - third) and _capi.feedback_streaks()[slot] == 0
+        out = hip_bwd(ops, kind, g, x)                          # corrected: the fast path's launch again
+        torch.cuda.synchronize()
+        assert same(ref, out) and _capi.get_option("bwd_whole_batches") == 4
+        # ... and a wholly diagonal batch behind a stale "all non-diagonal, twice running"
+        g = dev(d3)
+        x = hip_fwd(ops, kind, g)[0]
+        _capi.enable_feedback(False)
+        ref = hip_bwd(ops, kind, g, x)
+        _capi.enable_feedback(True)
+        _capi._feedback[slot] = ((2 << 62) | (B << 32) | B) - (1 << 64)   # (as a signed 64-bit integer)
+        out = hip_bwd(ops, kind, g, x)
+        torch.cuda.synchronize()
+        assert same(ref, out) and _capi.get_option("bwd_whole_batches") == 5
+        assert _capi.feedback_words()[slot] == (B, 0)
+        _capi.set_option("bwd_skip_classify", 0)                # the option keeps the fast path's launch in front
+        _capi._feedback[slot] = ((2 << 62) | (B << 32) | B) - (1 << 64)   # (as a signed 64-bit integer)
+        out = hip_bwd(ops, kind, g, x)
+        torch.cuda.synchronize()
+        assert same(ref, out) and _capi.get_option("bwd_whole_batches") == 5
+    finally:
+        _capi.set_option("bwd_skip_classify", 1)
+        _capi.enable_feedback(was_on)
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
 def test_feedback_moves_a_mostly_dense_forward_to_four_lanes_same_bits(ops, kind):
     """DQQ_P_AUTO, N = 8, a batch large enough for two lanes per problem: once the backward's drain has reported that most of
     the batch is non-diagonal, the next forward of that kind, N and B runs on four lanes per problem -- one pass of the

@@ -15,6 +15,7 @@ trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad, worst, lane_list = 0, 0.0, 0
 _capi.set_option("lane_list_drains", 0)
+_capi.set_option("bwd_whole_batches", 0)
 for t in range(trials):
     kind = str(rng.choice(["qp", "qcqp", "box"]))
     LANE = len(sys.argv) > 3 and sys.argv[3] == "lane"
@@ -43,7 +44,8 @@ for t in range(trials):
         # the feedback word of dqq_set_feedback, set to anything: a "long list" sends the lane-per-problem kernel (LIST) after
         # whatever list this batch has -- full, every other tile, empty; a hint must never change a result
         _capi.enable_feedback(True)
-        _capi._feedback[(0 if kind == "qp" else 1) * 4 + N // 2 - 1] = (B << 32) | int(rng.choice([0, 30000, B]))
+        word = (int(rng.integers(4)) << 62) | (B << 32) | int(rng.choice([0, 30000, B, B]))   # (streak, B, entries): launch.h
+        _capi._feedback[(0 if kind == "qp" else 1) * 4 + N // 2 - 1] = word - (1 << 64) if word >= (1 << 63) else word
         lane_list += 1
     g = {k: v.cuda() for k, v in d.items()}
     cache = ops.diag_cache(g["q"]) if use_cache else None
@@ -83,5 +85,5 @@ for t in range(trials):
         bad += 1
         print("FAIL", t, kind, N, B, structure, layout, opts, "cache", use_cache, "rel %.2e exits equal %.3f finite %s" % (rel, same.mean(), finite), flush=True)
 for k, v in {"fuse_fallback": -1, "wpb": 0, "small_bwd": 1, "dense_teams": 1, "dense_wave64": 1, "wave_qcqp_bwd": 1, "lane_bwd": 1}.items(): _capi.set_option(k, v)
-print("%d trials, %d failures, worst rel err %.2e  (feedback word poked in %d trials, %d drains by the lane kernel)"
-      % (trials, bad, worst, lane_list, _capi.get_option("lane_list_drains")))
+print("%d trials, %d failures, worst rel err %.2e  (feedback word poked in %d trials: %d drains by the lane kernel, %d whole batches)"
+      % (trials, bad, worst, lane_list, _capi.get_option("lane_list_drains"), _capi.get_option("bwd_whole_batches")))

@@ -27,9 +27,13 @@ for kind, N in (("qcqp", 8), ("qp", 8), ("qcqp", 6), ("qcqp", 4)):
                 rund = lambda: ops.qcqp_backward(d["P"], d["q"], d["l_n"], d["mu"], x, d["grad_x"], out=out, layout=1)
             _capi.enable_feedback(False); ops._feedback_tried = True
             off = t(run)
-            _capi.enable_feedback(True); _capi.set_option("lane_list_drains", 0)
+            _capi.enable_feedback(True); _capi.set_option("lane_list_drains", 0); _capi.set_option("bwd_whole_batches", 0)
+            _capi.set_option("bwd_skip_classify", 0)
             on = t(run)
             n = _capi.get_option("lane_list_drains")
+            _capi.set_option("bwd_skip_classify", 1)
+            whole = t(run)
+            nw = _capi.get_option("bwd_whole_batches")
             dd = t(rund) if structure == "dense" else float("nan")
-            print("%-5s N=%d B=%6d %-5s  AUTO backward: no feedback %.1f us, feedback %.1f us (%d lane drains of 45)   declared dense %.1f"
-                  % (kind, N, B, structure, off, on, n, dd), flush=True)
+            print("%-5s N=%d B=%6d %-5s  AUTO backward: no feedback %.1f us, feedback %.1f us (%d lane drains of 45), whole batch %.1f us (%d of 45)   declared dense %.1f"
+                  % (kind, N, B, structure, off, on, n, whole, nw, dd), flush=True)
