@@ -19,9 +19,14 @@ __global__ __launch_bounds__(256, (SmallSys<KIND, N>::M > 16 ? 1 : 2)) void bwd_
     // anything else: with the exit below the lane / team arithmetic the compiler had put a register spill (a scratch store by each
     // of the 4096 waves) in front of it, and the headline step paid 4.5 us for it (round 4, A/B of the builds).
     const long count = use_worklist ? (long)ws[kWsCount] : B;
-    if (use_worklist && blockIdx.x == 0 && threadIdx.x == 0) worklist_feedback(feedback, ws, B, count);   // (launch.h: a hint for the next call)
     if (count == 0) return;
     asm volatile("" ::: "memory");
+    // launch.h: a hint for the next call -- how long the list was.  Only BEHIND the exit above: with the report in front of it
+    // (an empty list reported too) the first workgroup read the workspace's shadow word behind the count, two dependent
+    // round trips instead of one in a launch that does nothing else, and each empty drain took 0.6 us longer (headline step
+    // 58.0 -> 59.5 us, A/B of the builds on one box).  Nothing is lost: a stale "long" in front of an empty list sends the
+    // lane-per-problem kernel, and THAT reports the 0 (bwd_lane_dense.hip).
+    if (use_worklist && blockIdx.x == 0 && threadIdx.x == 0) worklist_feedback(feedback, ws, B, count);
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int team = lane / T, tl = lane % T;

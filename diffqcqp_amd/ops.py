@@ -60,7 +60,7 @@ def feedback_default():
     if os.environ.get("DQQ_FEEDBACK", "1") != "0" and torch.cuda.is_available():
         try:
             _capi.enable_feedback(True)
-        except (RuntimeError, ValueError):
+        except (RuntimeError, ValueError, AttributeError):
             pass
 
 
