@@ -207,7 +207,7 @@ static int bwd_dispatch(int kind, dqq::BwdArgs& a, void* workspace, size_t works
     if (!fused && !dense_ok) return DQQ_E_UNSUPPORTED_N; // (box QP, N > 32): nothing could drain the work-list
     // everything was queued last time (feedback word): one launch of the lane-per-problem kernel over the whole batch, which
     // also recounts for the next call (bwd_lane_dense.hip REPORT; a diagonal problem gets the same bits there)
-    if (!fused && g_auto_fallback.load() != 0 && dqq::bwd_lane_takes_auto_batch(kind, a.N, a.B)) {
+    if (!fused && g_auto_fallback.load() != 0 && dqq::bwd_lane_takes_auto_batch(kind, a.N, a.B, s)) {
         dqq::g_bwd_whole_batches.fetch_add(1, std::memory_order_relaxed);
         hipError_t e2 = dqq::launch_bwd_lane_dense(kind, a, 2, s);
         if (e2 != hipSuccess) reset_worklist(workspace, s);

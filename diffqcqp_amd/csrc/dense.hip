@@ -189,11 +189,11 @@ static hipError_t launch_bwd_kind(const BwdArgs& a, bool use_worklist, hipStream
     return launch_bwd_team<KIND, 64>(a, use_worklist, s);
 }
 
-bool bwd_lane_takes_auto_batch(int kind, int N, long B)
+bool bwd_lane_takes_auto_batch(int kind, int N, long B, hipStream_t s)
 {
     if (g_lane_bwd.load() == 0 || g_bwd_skip_classify.load() == 0 || !bwd_lane_dense_supported(kind, N, B)) return false;
     int streak = 0;
-    return worklist_predicted(kind, N, B, &streak) == B && streak >= 1;   // twice running (launch.h)
+    return worklist_predicted(kind, N, B, &streak) == B && streak >= 1 && hint_allowed_on(s);   // twice running (launch.h)
 }
 
 hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)
@@ -206,7 +206,7 @@ hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipSt
         return launch_bwd_lane_dense(kind, a, 0, s);
     // ... and the drain launch of a work-list that the last drain of this kind, N and B found that long (launch.h: feedback)
     if (use_worklist && g_lane_bwd.load() != 0 && bwd_lane_dense_supported(kind, a.N, a.B) &&
-        bwd_lane_dense_supported(kind, a.N, worklist_predicted(kind, a.N, a.B))) {
+        bwd_lane_dense_supported(kind, a.N, worklist_predicted(kind, a.N, a.B)) && hint_allowed_on(s)) {
         g_lane_list_drains.fetch_add(1, std::memory_order_relaxed);
         return launch_bwd_lane_dense(kind, a, 1, s);
     }

@@ -402,7 +402,7 @@ hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fus
         // The same bits either way -- an iterate does not depend on the lane layout (admm_diag_body.inc), the general
         // solve is the four-lane one in both -- so the hint costs or saves time, nothing else.
         if (a.layout == DQQ_P_AUTO && fuse && a.N == 8 && kind < 2 && lpp == 2 && g_fwd_feedback.load() != 0 &&
-            2 * worklist_predicted(kind, a.N, a.B) >= a.B) {
+            2 * worklist_predicted(kind, a.N, a.B) >= a.B && hint_allowed_on(s)) {
             lpp = 4;
             g_fwd_feedback_routes.fetch_add(1, std::memory_order_relaxed);
         }

@@ -115,6 +115,13 @@ inline long worklist_predicted(int kind, int N, long B, int* streak = nullptr)
     if (streak != nullptr) *streak = (int)(w >> 62);
     return (long)(w & 0xffffffffULL);
 }
+// A hint may change a route only OUTSIDE stream capture: a captured graph is replayed on batches the word knows nothing about,
+// so what goes into it is the argument-determined route (asked only when a hint is about to be followed: one runtime call).
+inline bool hint_allowed_on(hipStream_t s)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusNone;
+}
 #if defined(__HIPCC__)
 // Call from ONE lane of the launch.  The store goes to host memory, and a launch that has one in flight ends later
 // (headline step +0.5 us, A/B): the workspace header remembers the last word this workspace sent and where, and an unchanged
@@ -421,7 +428,7 @@ hipError_t launch_bwd_any(int kind, const BwdArgs& a, bool use_worklist, hipStre
 bool bwd_lane_dense_supported(int kind, int N, long B);
 hipError_t launch_bwd_lane_dense(int kind, const BwdArgs& a, int mode, hipStream_t s);
 // a DQQ_P_AUTO backward whose every problem was queued last time (feedback word): the lane kernel on the whole batch, reporting
-bool bwd_lane_takes_auto_batch(int kind, int N, long B);
+bool bwd_lane_takes_auto_batch(int kind, int N, long B, hipStream_t s);
 // statically sized team backward for even N <= 16, QP / QCQP (bwd_small.hip); launch_bwd_dense routes to it
 bool bwd_small_supported(int kind, int N);
 hipError_t launch_bwd_small(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);

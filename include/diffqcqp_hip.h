@@ -232,7 +232,8 @@ int dqq_get_option(const char* name, int* value);
  * predecessors found EVERY problem non-diagonal skips the classifying launch: one launch of the lane-per-problem kernel
  * over the batch, which recounts for the call after it.  The two kernels give
  * the same results bit for bit on any list, so the word is a hint: stale, racy or absent, it changes the time of a call and
- * nothing else.  Nothing ever waits for the device.
+ * nothing else.  Nothing ever waits for the device.  A call on a stream that is being CAPTURED ignores the word: what goes
+ * into a graph is the route its arguments determine.
  *
  * `host_buffer`: DQQ_FEEDBACK_BYTES of zero-initialised host memory that the device can write (hipHostMalloc /
  * hipHostRegister, or torch's pin_memory()), 8-byte aligned, valid until replaced or the process ends; NULL unregisters.

@@ -80,6 +80,51 @@ def test_forward_backward_captured_into_a_graph_and_replayed(oracle, ops, kind, 
     assert np.abs(replayed["x"].cpu().numpy() - xo).max() <= 1e-6
 
 
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+def test_a_captured_call_ignores_the_feedback_word(ops, kind):
+    """dqq_set_feedback: the word may move a call to another lane layout or kernel -- never inside a stream capture, where the
+    route must be the one the arguments determine (a graph is replayed on batches the word knows nothing about)."""
+    from diffqcqp_amd import _capi
+    N, B = 8, 57344 + 2048
+    d = make_problem(kind, B, N, 8300, "dense")
+    keys = [k for k in ("P", "q", "grad_x", "l_n", "mu") if k in d]
+    t = {k: d[k].cuda().clone() for k in keys}
+    e = lambda *shape: torch.empty(*shape, device="cuda", dtype=torch.float64)
+    t.update(x=e(B, N, 1), gP=e(B, N, N), gq=e(B, N, 1), gl=e(B, N // 2, 1), gm=e(B, N // 2, 1))
+    outs = ("x", "gP", "gq") + (("gl", "gm") if kind == "qcqp" else ())
+    slot = (0 if kind == "qp" else 1) * 4 + N // 2 - 1
+    was_on = _capi._feedback is not None
+    _capi.enable_feedback(True)
+    try:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(4):                      # the word learns: all non-diagonal, three times running
+                _run(ops, kind, t, 0)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        assert _capi.feedback_words()[slot] == (B, B) and _capi.feedback_streaks()[slot] >= 2
+        eager = {k: t[k].clone() for k in outs}
+        for name in ("fwd_feedback_routes", "bwd_whole_batches", "lane_list_drains"):
+            _capi.set_option(name, 0)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            _run(ops, kind, t, 0)
+        assert [_capi.get_option(n) for n in ("fwd_feedback_routes", "bwd_whole_batches", "lane_list_drains")] == [0, 0, 0]
+        for k in outs:
+            t[k].zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        for k in outs:
+            assert torch.equal(t[k], eager[k])      # the hinted routes and the captured ones: the same bits
+        with torch.cuda.stream(s):
+            _run(ops, kind, t, 0)                   # outside the capture the word is followed again
+        torch.cuda.synchronize()
+        assert _capi.get_option("fwd_feedback_routes") == 1 and _capi.get_option("bwd_whole_batches") == 1
+    finally:
+        _capi.enable_feedback(was_on)
+
+
 def test_output_buffers_of_the_wrong_type_are_refused(ops):
     d = make_problem("qp", 16, 8, 8500)
     P, q = d["P"].cuda(), d["q"].cuda()
