@@ -723,6 +723,17 @@ def dense_p_record(args, ctx):
     rec = {"auto": condensed(measure(6, args, ctx, light=True)), "dense": condensed(measure(7, args, ctx, light=True))}
     rec["auto_ms_per_fwd_bwd"], rec["dense_ms_per_fwd_bwd"] = rec["auto"]["ms_per_step"], rec["dense"]["ms_per_step"]
     rec["auto_over_dense"] = rec["auto_ms_per_fwd_bwd"] / rec["dense_ms_per_fwd_bwd"]
+    # "auto" above is the steady state of a caller that presents this kind of batch step after step: from the third step on
+    # the feedback word (dqq_set_feedback) has moved the forward to four lanes per problem and the backward to
+    # one launch of the lane-per-problem kernel.  The same through the routes the arguments alone determine (a first call,
+    # a captured graph, DQQ_FEEDBACK=0):
+    capi = ctx["capi"]
+    if capi._feedback is not None:
+        capi.enable_feedback(False)
+        try:
+            rec["auto_no_hint_ms_per_fwd_bwd"] = measure(6, args, ctx, light=True)["ms_per_step"]
+        finally:
+            capi.enable_feedback(True)   # (a fresh, zeroed buffer: the sub-records after this one start without a hint, like a new caller)
     return rec
 
 
@@ -884,6 +895,9 @@ def main():
             out["dense_p_n8"] = dense_p_record(args, ctx)
             out["config"].update(flat_summary("dense8_auto", out["dense_p_n8"]["auto"]))
             out["config"].update(flat_summary("dense8_dense", out["dense_p_n8"]["dense"]))
+            out["config"]["dense8_auto_over_dense"] = out["dense_p_n8"]["auto_over_dense"]
+            if "auto_no_hint_ms_per_fwd_bwd" in out["dense_p_n8"]:
+                out["config"]["dense8_auto_no_hint_ms_per_step"] = out["dense_p_n8"]["auto_no_hint_ms_per_fwd_bwd"]
             out["survey_8d_extras"] = survey_extras_record(args, ctx)
             ex = out["survey_8d_extras"]
             out["config"].update({"stress_p_u01_qp_fwd_ms": ex["stress_p_u(0,1)_qp_fwd"]["ms_per_call"],
