@@ -396,13 +396,16 @@ hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fus
         lpp = fwd_diag_default_lpp(a.N, a.B, kind);
         // a batch declared dense takes the general solve's own mapping (N/2 lanes per problem): one pass per tile
         if (a.layout == DQQ_P_DENSE && a.N <= 8) lpp = a.N / 2;
-        // ... and so does a DQQ_P_AUTO batch when the last backward of this kind, N and B found most of its problems
+        // ... and so does a DQQ_P_AUTO batch when the last backward of this kind, N and B found ANY of its problems
         // non-diagonal (launch.h: the feedback word of dqq_set_feedback): on two lanes per problem a non-diagonal tile of
-        // N = 8 takes TWO passes of the four-lane general solve (dense 65536 x 8, forward: QP 106 -> 77 us, QCQP 116 -> 94).
-        // The same bits either way -- an iterate does not depend on the lane layout (admm_diag_body.inc), the general
-        // solve is the four-lane one in both -- so the hint costs or saves time, nothing else.
+        // N = 8 takes TWO passes of the four-lane general solve, and the launch lasts as long as its slowest wave -- one such
+        // problem in 1000 is enough (65536 x 8, forward, two / four lanes, tools/probe_sparse_dense_lpp.py: none 24.7 / 26.3 us
+        // QP, 29.9 / 34.2 QCQP; one in 1000: 66 / 44, 79 / 51; one in 10: 97 / 71, 112 / 86; all: 106 / 77, 116 / 94; the same
+        // order at 131072 and 262144).  The same bits either way -- an iterate does not depend on the lane layout
+        // (admm_diag_body.inc, admm_diag_prologue.inc), the general solve is the four-lane one in both -- so the hint costs
+        // or saves time, nothing else.
         if (a.layout == DQQ_P_AUTO && fuse && a.N == 8 && kind < 2 && lpp == 2 && g_fwd_feedback.load() != 0 &&
-            2 * worklist_predicted(kind, a.N, a.B) >= a.B && hint_allowed_on(s)) {
+            worklist_predicted(kind, a.N, a.B) > 0 && hint_allowed_on(s)) {
             lpp = 4;
             g_fwd_feedback_routes.fetch_add(1, std::memory_order_relaxed);
         }

@@ -547,8 +547,8 @@ def test_feedback_sends_an_all_dense_auto_batch_to_the_lane_kernel_whole(ops, ki
 
 
 @pytest.mark.parametrize("kind", ["qp", "qcqp"])
-def test_feedback_moves_a_mostly_dense_forward_to_four_lanes_same_bits(ops, kind):
-    """DQQ_P_AUTO, N = 8, a batch large enough for two lanes per problem: once the backward's drain has reported that most of
+def test_feedback_moves_a_forward_with_dense_tiles_to_four_lanes_same_bits(ops, kind):
+    """DQQ_P_AUTO, N = 8, a batch large enough for two lanes per problem: once the backward's drain has reported that some of
     the batch is non-diagonal, the next forward of that kind, N and B runs on four lanes per problem -- one pass of the
     in-kernel general solve per tile instead of two.  x and the iteration counts are the same bits, for the dense tiles
     and for the diagonal ones (a third of this batch)."""
@@ -581,9 +581,12 @@ def test_feedback_moves_a_mostly_dense_forward_to_four_lanes_same_bits(ops, kind
         hip_fwd(ops, kind, g)
         assert _capi.get_option("fwd_feedback_routes") == 1   # the option keeps the forward off the word
         _capi.set_option("fwd_feedback", 1)
-        _capi._feedback[slot] = (B << 32) | (B // 2 - 1)      # fewer than half: two lanes
+        _capi._feedback[slot] = (B << 32) | 16                # a single non-diagonal tile last time is enough ...
+        x1, it1 = hip_fwd(ops, kind, g)
+        assert _capi.get_option("fwd_feedback_routes") == 2 and torch.equal(x1, x2) and torch.equal(it1, it2)
+        _capi._feedback[slot] = (B << 32) | 0                 # ... none: two lanes
         hip_fwd(ops, kind, g)
-        assert _capi.get_option("fwd_feedback_routes") == 1
+        assert _capi.get_option("fwd_feedback_routes") == 2
     finally:
         _capi.set_option("fwd_lpp", 0)
         _capi.set_option("fwd_feedback", 1)
