@@ -42,21 +42,22 @@ namespace dqq {
 // signs (KIND 2, 3; may be null otherwise).
 // valid = false: the lane only keeps the wave's control flow company.
 // Returns the number of ADMM iterations executed (Solver.cpp:79 / :538 loop).
-// Reciprocals of E positive numbers.  E >= 8: from ONE reciprocal (of their product) and 3(E-1) multiplications; each
+// Reciprocals of E positive numbers.  E > 8: from ONE reciprocal (of their product) and 3(E-1) multiplications; each
 // result then carries ~3 roundings instead of 1, and a product that leaves the double range (entries beyond ~1e75) or
-// a non-positive factor falls back to one reciprocal per entry.  E <= 4: one reciprocal per entry -- with the range
+// a non-positive factor falls back to one reciprocal per entry.  E <= 8 (every instantiation of the fast path): one
+// reciprocal per entry -- with the range
 // test and its branch the shared reciprocal saved nothing there (11 against 10 VALU instructions per pair), and the
 // result must not depend on how a problem's coordinates are grouped into lanes (admm_fwd_diag_respread moves problems
-// from E = 4 to E = 2 in mid-solve).
+// from E = 4 to E = 2 in mid-solve; round 4: the forward picks among one, two and four lanes per problem at N = 8 by a hint).
 template <int E>
 DQQ_HD void rcp_all(const double (&m)[E], double (&inv)[E])
 {
-    if constexpr (E <= 4) {
+    if constexpr (E <= 8) {
 #pragma unroll
         for (int e = 0; e < E; ++e) inv[e] = fast_rcp(m[e]);
         return;
     }
-    // (E >= 8 from here on)
+    // (E > 8 from here on)
     double pre[E];
     pre[0] = m[0];
 #pragma unroll

@@ -239,8 +239,12 @@ struct LaneGroup {
             p40 = odd ? other : mine;
             p15 = odd ? mine : other;
         } else {
-            p40 = pow(x, .4);
-            p15 = pow(x, .15);
+            // the same pow() as above -- the one with an exponent the compiler does not know: with the literal the
+            // library call is specialised and the last bit differs (round 4: a result must not depend on the layout)
+            double e40 = .4, e15 = .15;
+            asm volatile("" : "+v"(e40), "+v"(e15));
+            p40 = pow(x, e40);
+            p15 = pow(x, e15);
         }
     }
     static DQQ_D double sum(double v)

@@ -30,9 +30,11 @@
 namespace dqq {
 
 // N = 8, two lanes per problem (the bench shape), fused: four waves per SIMD (128 VGPRs) so that the forwards of two
-// problem families -- or a forward and a backward -- are co-resident on a SIMD
+// problem families -- or a forward and a backward -- are co-resident on a SIMD.  One lane per problem
+// (round 4: the layout for batches that are mostly non-diagonal, below) is the opposite trade: a problem's whole matrix in
+// its lane's registers, one wave per SIMD.
 #define DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE) \
-    __attribute__((amdgpu_waves_per_eu(((FUSE) && (N) == 8 && (LPP) <= 2 && (KIND) < 2) ? 4 : 1, 8)))
+    __attribute__((amdgpu_waves_per_eu(((FUSE) && (N) == 8 && (LPP) == 2 && (KIND) < 2) ? 4 : 1, 8)))
 
 // Option "fwd_respread": once at most this many (0..16) of a wave's 32 problems are still iterating, they move onto
 // twice the lanes (admm_core.h admm_fwd_diag_respread; N = 8, two lanes per problem, QP / QCQP).  0 = never.
@@ -79,7 +81,8 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
     // FUSE, N <= 8: a non-diagonal tile is solved by this wave, 64/LD problems at a time with LD = max(N/2, LPP) lanes
     // per problem (group_dense.h): two rows of the matrices per lane keep the general solve inside the register
     // budget of the diagonal arithmetic
-    constexpr int LD = (N / 2 > LPP) ? N / 2 : LPP;
+    // (one lane per problem, QP / QCQP: the general solve on the caller's mapping too -- a lane per problem, LD == LPP)
+    constexpr int LD = (N == 8 && LPP == 1 && KIND < 2) ? 1 : ((N / 2 > LPP) ? N / 2 : LPP);
     constexpr bool GD = FUSE && N <= 8 && LD <= 4 && group_dense_supported(KIND, N, LD);
     [[maybe_unused]] bool dense_tile = false; // CMP: some tile of this workgroup is not diagonal
 
@@ -404,10 +407,17 @@ hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fus
         // order at 131072 and 262144).  The same bits either way -- an iterate does not depend on the lane layout
         // (admm_diag_body.inc, admm_diag_prologue.inc), the general solve is the four-lane one in both -- so the hint costs
         // or saves time, nothing else.
-        if (a.layout == DQQ_P_AUTO && fuse && a.N == 8 && kind < 2 && lpp == 2 && g_fwd_feedback.load() != 0 &&
-            worklist_predicted(kind, a.N, a.B) > 0 && hint_allowed_on(s)) {
-            lpp = 4;
-            g_fwd_feedback_routes.fetch_add(1, std::memory_order_relaxed);
+        // Half of the batch or more non-diagonal: ONE lane per problem -- the same general solve with a problem's whole matrix
+        // in its lane's registers (no gathers: 65536 x 8 all dense, QP 77 -> 59 us, QCQP 94 -> 77; from one problem in 10 on
+        // it beats four lanes at every batch size measured, below that it loses: a lone non-diagonal tile is then 64 problems
+        // on one wave).  Also the same bits: the sums of group_dense.h and of the diagonal arithmetic are taken over one tree
+        // on one, two and four lanes, and the reciprocals, pow() and every fused multiply-add are the same instructions.
+        if (a.layout == DQQ_P_AUTO && fuse && a.N == 8 && kind < 2 && lpp == 2 && g_fwd_feedback.load() != 0) {
+            const long pred = worklist_predicted(kind, a.N, a.B);
+            if (pred > 0 && hint_allowed_on(s)) {
+                lpp = (2 * pred >= a.B) ? 1 : 4;
+                g_fwd_feedback_routes.fetch_add(1, std::memory_order_relaxed);
+            }
         }
     }
     if (needs_fallback) *needs_fallback = (a.layout == DQQ_P_AUTO) && !fuse;

@@ -28,6 +28,7 @@ namespace dqq {
 // as without it); the box kinds carry three more vectors and get half of that
 constexpr bool group_dense_supported(int kind, int n, int lpp)
 {
+    if (kind < 2 && n == 8 && lpp == 1) return true;   // a lane per problem, the whole matrix in its registers: one wave per SIMD (fwd_diag.hip)
     return lpp <= 4 && n % lpp == 0 && (n / lpp) * n <= (kind < 2 ? 32 : 16);
 }
 
@@ -67,9 +68,26 @@ struct GroupRows {
         for (int e = 0; e < E; ++e) {
             double t = 0.0;
 #pragma unroll
-            for (int c = 0; c < N; ++c) t += A[e][c] * full[c];
+            for (int c = 0; c < N; ++c) t = __builtin_fma(A[e][c], full[c], t);   // (written out: see dot() below)
             y[e] = t;
         }
+    }
+    // sum_i a_i b_i over the problem's N coordinates: every product rounded, then ONE binary tree in coordinate order --
+    // within the lane here, across the lanes in G::sum.  Round 4: the general solve runs on four lanes per problem or on
+    // one (fwd_diag.hip picks by a hint), and a result must not depend on which; for the same reason every fused
+    // multiply-add of this file is written out instead of being left to the compiler's contraction.
+    static DQQ_D double dot(const double (&a)[E], const double (&b)[E])
+    {
+#pragma clang fp contract(off)
+        static_assert((E & (E - 1)) == 0, "rows per lane: a power of two");
+        double pr[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) pr[e] = a[e] * b[e];
+#pragma unroll
+        for (int w = 1; w < E; w *= 2)
+#pragma unroll
+            for (int e = 0; e + w < E; e += 2 * w) pr[e] = pr[e] + pr[e + w];
+        return LaneGroup<LPP>::sum(pr[0]);
     }
     // rows s*E.. of the matrix as stored
     static DQQ_D void load_rows(const double* __restrict__ Pg, int s, double (&A)[E][N])
@@ -126,7 +144,7 @@ struct GroupRows {
                 const double f = A[e][k];
 #pragma unroll
                 for (int c = 0; c < N; ++c) {
-                    const double upd = (c == k) ? -(f * pinv) : A[e][c] - f * rk[c];
+                    const double upd = (c == k) ? -(f * pinv) : __builtin_fma(-f, rk[c], A[e][c]);
                     A[e][c] = (e == ek && owner) ? rk[c] : upd;
                 }
             }
@@ -180,10 +198,7 @@ DQQ_D int group_dense_fwd(const double* __restrict__ Pg, const double (&q)[N / L
             for (int k = 0; k < 10; ++k) {
                 double Av[E];
                 R::matvec(A, v, Av);
-                double t = 0.0;
-#pragma unroll
-                for (int e = 0; e < E; ++e) t += Av[e] * Av[e];
-                t = G::sum(t);
+                const double t = R::dot(Av, Av);
                 const double inv = t > 0 ? fast_rsqrt(t) : 1.0; // normalised every step (Solver.cpp:53)
 #pragma unroll
                 for (int e = 0; e < E; ++e) v[e] = Av[e] * inv;
@@ -201,7 +216,7 @@ DQQ_D int group_dense_fwd(const double* __restrict__ Pg, const double (&q)[N / L
 #pragma unroll
                     for (int e = 0; e < E; ++e)
 #pragma unroll
-                        for (int c = 0; c < N; ++c) T2[e][c] = (k == 0) ? A[e][0] * rowk[c] : T2[e][c] + A[e][k] * rowk[c];
+                        for (int c = 0; c < N; ++c) T2[e][c] = (k == 0) ? A[e][0] * rowk[c] : __builtin_fma(A[e][k], rowk[c], T2[e][c]);
                 }
                 double dmax = 0.0;
 #pragma unroll
@@ -228,10 +243,7 @@ DQQ_D int group_dense_fwd(const double* __restrict__ Pg, const double (&q)[N / L
                     for (int e = 0; e < E; ++e) v[e] = ldexp(Av[e], -ev);
                 }
             }
-            double t = 0.0;
-#pragma unroll
-            for (int e = 0; e < E; ++e) t += v[e] * v[e];
-            t = G::sum(t);
+            const double t = R::dot(v, v);
             const double inv = t > 0 ? fast_rsqrt(t) : 1.0;
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] = v[e] * inv;
@@ -239,10 +251,7 @@ DQQ_D int group_dense_fwd(const double* __restrict__ Pg, const double (&q)[N / L
         }
         double Pv[E];
         R::matvec(A, v, Pv);
-        double t = 0.0;
-#pragma unroll
-        for (int e = 0; e < E; ++e) t += v[e] * Pv[e];
-        L = G::sum(t);
+        L = R::dot(v, Pv);
     }
 
     // ---- Solver.cpp:72-77 / 531-536

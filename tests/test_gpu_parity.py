@@ -550,8 +550,9 @@ def test_feedback_sends_an_all_dense_auto_batch_to_the_lane_kernel_whole(ops, ki
 def test_feedback_moves_a_forward_with_dense_tiles_to_four_lanes_same_bits(ops, kind):
     """DQQ_P_AUTO, N = 8, a batch large enough for two lanes per problem: once the backward's drain has reported that some of
     the batch is non-diagonal, the next forward of that kind, N and B runs on four lanes per problem -- one pass of the
-    in-kernel general solve per tile instead of two.  x and the iteration counts are the same bits, for the dense tiles
-    and for the diagonal ones (a third of this batch)."""
+    in-kernel general solve per tile instead of two -- and, when it was half of the batch or more, on ONE lane per problem
+    (a problem's whole matrix in its lane's registers).  x and the iteration counts are the same bits on one, two and four
+    lanes, for the dense tiles and for the diagonal ones (a third of this batch)."""
     from diffqcqp_amd import _capi
     N, B = 8, 57344 + 4096 + 21
     d = make_problem(kind, B, N, 795, "dense")
@@ -570,18 +571,19 @@ def test_feedback_moves_a_forward_with_dense_tiles_to_four_lanes_same_bits(ops, 
         hip_bwd(ops, kind, g, x2)
         torch.cuda.synchronize()
         assert _capi.feedback_words()[slot] == (B, B - third)
-        x4, it4 = hip_fwd(ops, kind, g)                       # most of the batch was non-diagonal: four lanes
+        x4, it4 = hip_fwd(ops, kind, g)                       # most of the batch was non-diagonal: one lane per problem
         assert _capi.get_option("fwd_feedback_routes") == 1
         assert torch.equal(x2, x4) and torch.equal(it2, it4)
-        _capi.set_option("fwd_lpp", 4)                        # (what the hint selects is the existing four-lane instantiation)
-        xf, itf = hip_fwd(ops, kind, g)
+        for lpp in (1, 4):                                    # (what the hint selects are the instantiations of option fwd_lpp)
+            _capi.set_option("fwd_lpp", lpp)
+            xf, itf = hip_fwd(ops, kind, g)
+            assert torch.equal(x4, xf) and torch.equal(it4, itf)
         _capi.set_option("fwd_lpp", 0)
-        assert torch.equal(x4, xf) and torch.equal(it4, itf)
         _capi.set_option("fwd_feedback", 0)
         hip_fwd(ops, kind, g)
         assert _capi.get_option("fwd_feedback_routes") == 1   # the option keeps the forward off the word
         _capi.set_option("fwd_feedback", 1)
-        _capi._feedback[slot] = (B << 32) | 16                # a single non-diagonal tile last time is enough ...
+        _capi._feedback[slot] = (B << 32) | 16                # a single non-diagonal tile last time is enough for four lanes ...
         x1, it1 = hip_fwd(ops, kind, g)
         assert _capi.get_option("fwd_feedback_routes") == 2 and torch.equal(x1, x2) and torch.equal(it1, it2)
         _capi._feedback[slot] = (B << 32) | 0                 # ... none: two lanes

@@ -15,8 +15,8 @@ for kind in ("qp", "qcqp"):
     run = (lambda **kw: ops.qp_forward(d["P"], d["q"], 1e-7, 1000, out=xo, **kw)) if kind == "qp" else (lambda **kw: ops.qcqp_forward(d["P"], d["q"], d["l_n"], d["mu"], 1e-7, 1000, out=xo, **kw))
     res = {}
     outs = {}
-    for lpp in (0, 2, 4):
-        for wpb in (0, 1, 2, 4):
+    for lpp in (0, 1, 2, 4):
+        for wpb in (0, 1):
             _capi.set_option("fwd_lpp", lpp); _capi.set_option("wpb", wpb)
             res[(lpp, wpb)] = t(lambda: run(layout=0))
             outs[(lpp, wpb)] = run(layout=0).clone()

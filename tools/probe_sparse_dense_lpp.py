@@ -16,7 +16,7 @@ def t(fn, n=30, reps=3):
 for kind in ("qp", "qcqp"):
     for B in (65536, 131072, 262144):
         dd = make_problem(kind, B, 8, 4251, "dense")
-        for every in (0, 100000, 1000, 100, 10):
+        for every in (0, 100000, 1000, 100, 10, 4, 2, 1):
             d = make_problem(kind, B, 8, 4250, "diag")
             if every:
                 idx = torch.arange(every // 2, B, every)
@@ -25,7 +25,7 @@ for kind in ("qp", "qcqp"):
             xo = torch.empty(B, 8, 1, dtype=torch.float64, device="cuda")
             run = (lambda: ops.qp_forward(g["P"], g["q"], 1e-7, 1000, out=xo)) if kind == "qp" else (lambda: ops.qcqp_forward(g["P"], g["q"], g["l_n"], g["mu"], 1e-7, 1000, out=xo))
             res = []
-            for lpp in (2, 4):
+            for lpp in (2, 4, 1):
                 _capi.set_option("fwd_lpp", lpp); res.append(t(run))
             _capi.set_option("fwd_lpp", 0)
-            print("%-5s B=%6d one non-diagonal problem in %6d: two lanes %.1f us, four lanes %.1f us" % (kind, B, every, res[0], res[1]), flush=True)
+            print("%-5s B=%6d one non-diagonal problem in %6d: two lanes %.1f us, four lanes %.1f us, one lane %.1f us" % (kind, B, every, res[0], res[1], res[2]), flush=True)
