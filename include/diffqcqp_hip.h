@@ -207,7 +207,8 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
  *                    wave kernel up to N = 42, global-memory kernel beyond -- 1e-9, 10-30x slower, and 42 < N <= 64
  *                    then needs dqq_scratch_bytes of scratch)
  *   "fwd_feedback"   DQQ_P_AUTO forward, N = 8, QP / QCQP, with dqq_set_feedback: four lanes per problem instead of two when the
- *                    last backward of this kind, N and B found any non-diagonal problem (1, default), or
+ *                    last backward of this kind, N and B found any non-diagonal problem, one lane per problem when it found
+ *                    half of the batch or more (1, default), or
  *                    never look at the word (0).  Bit-identical results.  "fwd_feedback_routes" counts those launches.
  *   "bwd_skip_classify"  DQQ_P_AUTO backward, N <= 8, QP / QCQP, with dqq_set_feedback: when the last two backwards of this
  *                    kind, N and B found EVERY problem non-diagonal, skip the fast path's launch and solve the whole batch
@@ -229,7 +230,7 @@ int dqq_get_option(const char* name, int* value);
  * and B picks its kernel by it (a training loop presents the same kind of batch step after step); the next FORWARD of that
  * kind, N = 8 and B spreads its problems over four lanes instead of two when any of them was non-diagonal (one pass of
  * the in-kernel general solve per tile instead of two: 65536 x 8 QCQP forward, all dense 116 -> 94 us, one dense problem in
- * 1000 79 -> 51 us); and a backward whose last two
+ * 1000 79 -> 51 us), or gives every problem one lane when half of the batch or more was non-diagonal (all dense: 77 us); and a backward whose last two
  * predecessors found EVERY problem non-diagonal skips the classifying launch: one launch of the lane-per-problem kernel
  * over the batch, which recounts for the call after it.  The two kernels give
  * the same results bit for bit on any list, so the word is a hint: stale, racy or absent, it changes the time of a call and
