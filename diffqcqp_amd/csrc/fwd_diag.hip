@@ -207,7 +207,9 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
     int it = 0;
     bool solved = false;
     if constexpr (GD) {
-        if (dense_tile) {
+        // (unlikely: the block is placed behind the diagonal path's code -- the two-stream headline step reads 0.3 us less, A/B
+        // of the builds at 100-step regions, five alternations: two ~30 KB forwards share the CUs' instruction caches)
+        if (__builtin_expect(dense_tile, 0)) {
             if constexpr (LD == LPP) {
                 it = group_dense_fwd<KIND, N, LPP>(P + (first + pl) * (long)(N * N), qv, rad, eps, mu_prox, max_iter,
                                                    adaptive, valid, xv, lo, hi, sg, gdefer);
