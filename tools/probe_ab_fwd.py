@@ -1,6 +1,6 @@
 import os, sys, time, hashlib, torch
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8"); os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
-ROOT = "/root/repo"; sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import bench
 from diffqcqp_amd import _capi, ops
 dev = torch.device("cuda", 0)
