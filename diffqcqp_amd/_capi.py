@@ -158,7 +158,7 @@ def feedback_words():
 
 
 def feedback_streaks():
-    """Bits 62..63 of each word: consecutive earlier reports of "every problem of the batch" (saturating at 3)."""
+    """Bits 62..63 of each word: consecutive earlier reports of "three quarters of the batch or more" (saturating at 3)."""
     return None if _feedback is None else [(int(w) >> 62) & 3 for w in _feedback.tolist()]
 
 

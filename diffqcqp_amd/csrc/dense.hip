@@ -193,7 +193,10 @@ bool bwd_lane_takes_auto_batch(int kind, int N, long B, hipStream_t s)
 {
     if (g_lane_bwd.load() == 0 || g_bwd_skip_classify.load() == 0 || !bwd_lane_dense_supported(kind, N, B)) return false;
     int streak = 0;
-    return worklist_predicted(kind, N, B, &streak) == B && streak >= 1 && hint_allowed_on(s);   // twice running (launch.h)
+    // three quarters of the batch or more queued, twice running (launch.h): one launch of the lane kernel over everything costs
+    // what its waves cost (B / 64 of them, whatever their problems are); classifying first costs a launch that queues the
+    // entries through one atomic per workgroup (14 us per 65536) plus the same waves for the queued part
+    return 4 * worklist_predicted(kind, N, B, &streak) >= 3 * B && streak >= 1 && hint_allowed_on(s);
 }
 
 hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)

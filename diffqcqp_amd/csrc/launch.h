@@ -100,10 +100,10 @@ inline unsigned long long* worklist_feedback_slot(int kind, int N)
     return (fb != nullptr && i >= 0) ? fb + i : nullptr;
 }
 // The word: bits 0..31 entries found, 32..61 B (mod 2^30), 62..63 how many times IN A ROW before this one the same
-// workspace reported "every problem of the batch" (saturating at 3).
+// workspace reported "three quarters of the batch or more" (saturating at 3).
 constexpr unsigned long long kFbBMask = 0x3fffffffULL;
 // entries the last finished drain launch of (kind, N) found, if it ran on a batch of B problems; -1: not known.
-// *streak (optional): consecutive earlier reports of count == B.
+// *streak (optional): consecutive earlier reports of count >= 3/4 B.
 inline long worklist_predicted(int kind, int N, long B, int* streak = nullptr)
 {
     const volatile unsigned long long* fb = g_feedback_host.load(std::memory_order_relaxed);
@@ -135,7 +135,7 @@ static DQQ_D void worklist_feedback(unsigned long long* fb, int* ws, long B, lon
     const unsigned long long prev = shadow[0], bb = (unsigned long long)B & kFbBMask;
     const bool same_place = shadow[1] == reinterpret_cast<unsigned long long>(fb);
     unsigned long long streak = 0;
-    if (same_place && ((prev >> 32) & kFbBMask) == bb && (prev & 0xffffffffULL) == (unsigned long long)B && count == B)
+    if (same_place && ((prev >> 32) & kFbBMask) == bb && 4 * (long)(prev & 0xffffffffULL) >= 3 * B && 4 * count >= 3 * B)
         streak = (prev >> 62) < 3 ? (prev >> 62) + 1 : 3;
     const unsigned long long v = (streak << 62) | (bb << 32) | (unsigned long long)count;
     if (prev == v && same_place) return;

@@ -211,7 +211,7 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
  *                    half of the batch or more (1, default), or
  *                    never look at the word (0).  Bit-identical results.  "fwd_feedback_routes" counts those launches.
  *   "bwd_skip_classify"  DQQ_P_AUTO backward, N <= 8, QP / QCQP, with dqq_set_feedback: when the last two backwards of this
- *                    kind, N and B found EVERY problem non-diagonal, skip the fast path's launch and solve the whole batch
+ *                    kind, N and B found three quarters of the batch or more non-diagonal, skip the fast path's launch and solve the whole batch
  *                    with the lane-per-problem kernel, which recounts (1, default), or never (0).  Bit-identical results.
  *                    "bwd_whole_batches" counts those calls.
  *   "lane_list_drains"  not a knob: a counter of the drain launches that dqq_set_feedback's word routed to the
@@ -231,7 +231,7 @@ int dqq_get_option(const char* name, int* value);
  * kind, N = 8 and B spreads its problems over four lanes instead of two when any of them was non-diagonal (one pass of
  * the in-kernel general solve per tile instead of two: 65536 x 8 QCQP forward, all dense 116 -> 94 us, one dense problem in
  * 1000 79 -> 51 us), or gives every problem one lane when half of the batch or more was non-diagonal (all dense: 77 us); and a backward whose last two
- * predecessors found EVERY problem non-diagonal skips the classifying launch: one launch of the lane-per-problem kernel
+ * predecessors found at least three quarters of the batch non-diagonal skips the classifying launch: one launch of the lane-per-problem kernel
  * over the batch, which recounts for the call after it.  The two kernels give
  * the same results bit for bit on any list, so the word is a hint: stale, racy or absent, it changes the time of a call and
  * nothing else.  Nothing ever waits for the device.  A call on a stream that is being CAPTURED ignores the word: what goes

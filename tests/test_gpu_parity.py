@@ -406,15 +406,16 @@ def test_lane_per_problem_backward_is_the_team_kernel_bit_for_bit(oracle, ops, k
 
 
 @pytest.mark.parametrize("kind", ["qp", "qcqp"])
-@pytest.mark.parametrize("N,B", [(8, 24576 + 2048 + 13), (4, 16384 + 2048 + 500)])
-def test_feedback_routes_a_long_work_list_to_the_lane_kernel_same_bits(ops, kind, N, B):
+@pytest.mark.parametrize("N,B,ndiag", [(8, 24576 + 10240 + 13, 10240), (4, 16384 + 6144 + 500, 6144)])
+def test_feedback_routes_a_long_work_list_to_the_lane_kernel_same_bits(ops, kind, N, B, ndiag):
     """DQQ_P_AUTO, a batch that is (almost) all dense: the drain launch behind the diagonal backward reports the length of its
     work-list to the feedback word (dqq_set_feedback); the next backward of the same kind, N and B drains with the
     lane-per-problem kernel (bwd_lane_dense.hip, LIST) instead of the team kernel.  Same bits, whichever drains; the
     work-list header is left clean (a third call); a stale word (the list has become short, or empty) costs time only."""
     from diffqcqp_amd import _capi
     d = make_problem(kind, B, N, 790 + N, "dense")
-    ndiag = 2048                                    # a diagonal stretch (whole tiles) in the middle: those take the fast path
+    # ndiag: a diagonal stretch (whole tiles) in the middle -- those take the fast path; more than a quarter of the batch, so
+    # that the list stays the route (from three quarters non-diagonal on, twice running, the lane kernel takes the batch whole)
     for i in range(N):
         for j in range(N):
             if i != j:

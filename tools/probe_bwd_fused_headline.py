@@ -29,7 +29,8 @@ def step_time(k=100, reps=9):
         side.synchronize(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / k * 1e6)
     return sorted(ts)[len(ts) // 2]
 for rnd in range(2):
-    for name, fuse, fb in (("two launches (default)", -1, 1), ("no drain (unsafe, measurement)", -1, 0), ("fused backward, one launch", 1, 1)):
+    for name, fuse, fb in (("two launches (default)", -1, 1), ("no drain (unsafe, measurement)", -1, 0), ("fused backward, one launch", 1, 1),
+                           ("nothing fused: lean forwards + their drains", 0, 1), ("lean forwards, no drains at all (unsafe)", 0, 0)):
         _capi.set_option("fuse_fallback", fuse); _capi.set_option("auto_fallback", fb)
         try:
             qb = b2b(lambda: chains[0].launch(1, st[0])); cb = b2b(lambda: chains[1].launch(1, st[0]))
