@@ -173,3 +173,33 @@ def test_rank_deficient_batches(oracle, ops, family, N, kind):
     ref = _oracle_bwd(oracle, kind, d, xo, nthreads=nt)
     check_case(oracle, ops, kind, d, xo, ito, ref, 1e-7, 1000, _reference_order(kind, N), max_flip=0.4,
                label="%s %s N=%d" % (family, kind, N))
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("family", ["lowrank", "duprows", "psd_eps"])
+def test_rank_deficient_batches_on_one_two_and_four_lanes_per_problem(ops, family, kind):
+    """The forward picks its lane layout at N = 8 by batch size and by a hint (dqq_set_feedback); x and the iteration counts
+    must be the same bits on every layout -- also on singular P, where a third of the QPs run into max_iter and some
+    factorisations fail (NaN outputs: compared as bit patterns).  A third of the batch is made diagonal: both branches of
+    the fused kernel run in every layout."""
+    from diffqcqp_amd import _capi
+    B, N = 3000, 8
+    t = R.rank_deficient(kind, B, N, 7100, family)
+    P = t["P"].clone()
+    idx = torch.arange(64 * 7, 64 * 7 + 960)
+    P[idx] = torch.diag_embed(torch.diagonal(P[idx], dim1=1, dim2=2).abs() + 0.05)
+    g = {k: v.cuda() for k, v in t.items()}
+    g["P"] = P.cuda()
+    out = {}
+    try:
+        for lpp in (1, 2, 4):
+            _capi.set_option("fwd_lpp", lpp)
+            if kind == "qp":
+                out[lpp] = ops.qp_forward(g["P"], g["q"], 1e-7, 1000, return_iters=True)
+            else:
+                out[lpp] = ops.qcqp_forward(g["P"], g["q"], g["l_n"], g["mu"], 1e-7, 1000, return_iters=True)
+    finally:
+        _capi.set_option("fwd_lpp", 0)
+    for lpp in (1, 4):
+        assert torch.equal(out[lpp][0].view(torch.int64), out[2][0].view(torch.int64)), "x differs on %d lanes" % lpp
+        assert torch.equal(out[lpp][1], out[2][1]), "iteration counts differ on %d lanes" % lpp
