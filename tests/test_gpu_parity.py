@@ -596,6 +596,34 @@ def test_feedback_moves_a_forward_with_dense_tiles_to_four_lanes_same_bits(ops, 
         _capi.enable_feedback(was_on)
 
 
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("N,B", [(8, 30000), (4, 20000), (2, 17000)])
+def test_a_diagonal_problem_gets_the_fast_paths_bits_from_the_general_backward(ops, kind, N, B):
+    """bwd_diag.hip queues whole tiles, so diagonal problems do land in the general kernels; and a DQQ_P_AUTO batch that was
+    (almost) all non-diagonal twice running is sent to the lane-per-problem kernel WHOLE, without a look at P (launch.h:
+    feedback).  Both rest on this: the general backward kernels -- team and lane per problem -- give a diagonal problem the
+    very bits of the diagonal fast path.  Checked on the ill-conditioned diagonals of the reference's figure workload
+    (exp(U(-10, 10))) with singular coordinates mixed in."""
+    from diffqcqp_amd import _capi
+    gen = torch.Generator().manual_seed(5 + N)
+    p = torch.exp(torch.rand(B, N, generator=gen, dtype=torch.float64) * 20 - 10)
+    p[::7, 0] = 0.0
+    r = lambda *s: torch.rand(*s, generator=gen, dtype=torch.float64)
+    g = dev({"P": torch.diag_embed(p).contiguous(), "q": 2 * r(B, N, 1) - 1, "l_n": r(B, N // 2, 1), "mu": r(B, N // 2, 1),
+             "grad_x": torch.randn(B, N, 1, generator=gen, dtype=torch.float64)})
+    x = hip_fwd(ops, kind, g)[0]
+    fast = hip_bwd(ops, kind, g, x, layout=_capi.P_AUTO)
+    bits = lambda t: t.view(torch.int64) if t.dtype is torch.float64 else t
+    try:
+        for lane in (1, 0):
+            _capi.set_option("lane_bwd", lane)
+            general = hip_bwd(ops, kind, g, x, layout=_capi.P_DENSE)
+            for a, b in zip(fast[0] + [fast[1]], general[0] + [general[1]]):
+                assert torch.equal(bits(a), bits(b))
+    finally:
+        _capi.set_option("lane_bwd", 1)
+
+
 @pytest.mark.parametrize("kind,N,B", [("qcqp", 64, 40), ("qcqp", 50, 24), ("qcqp", 44, 24), ("box", 32, 48), ("box", 22, 30)])
 def test_reference_order_backward_beyond_the_wave_kernel(oracle, ops, kind, N, B):
     """The global-memory workgroup kernel in the reference's operation order -- the default for box 21 < N <= 32, and for

@@ -203,3 +203,33 @@ def test_rank_deficient_batches_on_one_two_and_four_lanes_per_problem(ops, famil
     for lpp in (1, 4):
         assert torch.equal(out[lpp][0].view(torch.int64), out[2][0].view(torch.int64)), "x differs on %d lanes" % lpp
         assert torch.equal(out[lpp][1], out[2][1]), "iteration counts differ on %d lanes" % lpp
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("family", ["lowrank", "duprows"])
+def test_rank_deficient_backward_lane_kernel_is_the_team_kernel_bit_for_bit(ops, family, kind):
+    """The lane-per-problem backward (declared dense, and the routes the feedback word opens through DQQ_P_AUTO) against the
+    team kernel on singular P at a batch size that selects it: K = A A^T + 1e-7 I with cond ~1e9, refinement loops that leave
+    at 1 ... 5 bodies -- every output and every step count the same bits (NaNs compared as bit patterns)."""
+    from diffqcqp_amd import _capi
+    B, N = 24576 + 192, 8
+    t = R.rank_deficient(kind, B, N, 7200, family)
+    g = {k: v.cuda() for k, v in t.items()}
+    g["grad_x"] = torch.randn(B, N, 1, dtype=torch.float64, generator=torch.Generator().manual_seed(7201)).cuda()
+    if kind == "qp":
+        x = ops.qp_forward(g["P"], g["q"], 1e-7, 1000, layout=1)
+        run = lambda: ops.qp_backward(g["P"], g["q"], x, g["grad_x"], layout=1, return_steps=True)
+    else:
+        x = ops.qcqp_forward(g["P"], g["q"], g["l_n"], g["mu"], 1e-7, 1000, layout=1)
+        run = lambda: ops.qcqp_backward(g["P"], g["q"], g["l_n"], g["mu"], x, g["grad_x"], layout=1, return_steps=True)
+    out = {}
+    try:
+        for opt in (1, 0):
+            _capi.set_option("lane_bwd", opt)
+            out[opt] = run()
+    finally:
+        _capi.set_option("lane_bwd", 1)
+    for a, b in zip(out[1], out[0]):
+        a64 = a.view(torch.int64) if a.dtype is torch.float64 else a
+        b64 = b.view(torch.int64) if b.dtype is torch.float64 else b
+        assert torch.equal(a64, b64)
