@@ -163,7 +163,9 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
                                             : stream_tile_diag<N, NCH, true, true>(Pw, limit, sd, lane);
         const bool tile_dense = __any(nz != 0); // wave-uniform
         if constexpr (CMP) wg_dense = __syncthreads_or(tile_dense) != 0;
-        if (tile_dense && flags_out != nullptr && valid && (lane % LPP) == 0) flags_out[first + pl] = 2; // seen, not diagonal
+        if constexpr (!GD) {   // (GD: problem by problem, below)
+            if (tile_dense && flags_out != nullptr && valid && (lane % LPP) == 0) flags_out[first + pl] = 2; // seen, not diagonal
+        }
         if constexpr (GD) {
             dense_tile = tile_dense;
         } else if constexpr (FUSE) {
@@ -205,44 +207,54 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
         }
     }
     int it = 0;
-    bool solved = false;
+    // `mine`: this lane's problem is solved by the diagonal arithmetic below.  A tile with non-diagonal problems hands THOSE
+    // to the general solve, problem by problem (round 4, late): which routine solves a problem -- and with it the last
+    // bits of its x -- must not depend on its neighbours or on how many lanes a problem has (the layout follows the batch
+    // size and a hint, dqq_set_feedback; routed by whole wave tiles, the diagonal neighbours of a non-diagonal problem took
+    // the general solve on two lanes per problem and the diagonal arithmetic on four: 1e-14 apart).
+    bool mine = valid;
+    [[maybe_unused]] unsigned long long dmask = 0;   // the lanes whose problem is non-diagonal (wave-uniform)
     if constexpr (GD) {
-        // (unlikely: the block is placed behind the diagonal path's code -- the two-stream headline step reads 0.3 us less, A/B
-        // of the builds at 100-step regions, five alternations: two ~30 KB forwards share the CUs' instruction caches)
+        // (unlikely: the blocks are placed behind the diagonal path's code -- the two-stream headline step reads 0.3 us less,
+        // A/B of the builds at 100-step regions, five alternations: two ~30 KB forwards share the CUs' instruction caches.
+        // The general solve itself comes LAST, when nothing of the diagonal arithmetic is live any more: between the
+        // classification and the diagonal solve it kept that state alive across itself and the spills landed on the path
+        // every tile takes, headline step 56 -> 69 us.)
         if (__builtin_expect(dense_tile, 0)) {
-            if constexpr (LD == LPP) {
-                it = group_dense_fwd<KIND, N, LPP>(P + (first + pl) * (long)(N * N), qv, rad, eps, mu_prox, max_iter,
-                                                   adaptive, valid, xv, lo, hi, sg, gdefer);
-                solved = true;
-            } else {
-                group_dense_tile<KIND, N, LD, PPW>(P, q, l_n, mu_c, v_sign, x, iters, first, nvalid, eps, mu_prox, max_iter,
-                                                   adaptive, lane, gdefer);
-                DQQ_TL(5);
-                return; // x / iters written in the general solve's own mapping; no barrier follows
-            }
+            bool densep = valid;   // declared dense: every problem
+            if (layout != DQQ_P_DENSE)
+                densep = GroupRows<N, LPP>::not_diagonal(P + (first + pl) * (long)(N * N), lane % LPP, valid);
+            if (flags_out != nullptr && densep && (lane % LPP) == 0) flags_out[first + pl] = 2; // seen, not diagonal
+            dmask = __ballot(densep);
+            mine = valid && !densep;
+            // the diagonal of the problems that stay: from P itself (the stream of a large tile stops at the first group of
+            // chunks with a non-zero off-diagonal, stream_tile.h: the staging buffer may be incomplete)
+            const double* Pg = P + (first + pl) * (long)(N * N) + ((lane % LPP) * E) * (N + 1);
+#pragma unroll
+            for (int e = 0; e < E; ++e) p[e] = mine ? Pg[e * (N + 1)] : 1.0;
         }
     }
     // N = 8 on two lanes per problem: the tail of the tile moves onto four lanes per problem (admm_core.h)
     constexpr bool RSP = fwd_diag_respreads(KIND, N, LPP) && !CMP;
     [[maybe_unused]] bool moved = false; // this lane's problem was finished (and stored) in the re-spread layout
-    if (!solved) {
+    if (__builtin_expect(!GD || !dense_tile || __any(mine), 1)) {   // (a tile that is all non-diagonal: nothing for it)
         if constexpr (RSP)
-            it = admm_fwd_diag_respread<KIND>(p, qv, rad, eps, mu_prox, max_iter, adaptive, valid, xv, respread_at,
+            it = admm_fwd_diag_respread<KIND>(p, qv, rad, eps, mu_prox, max_iter, adaptive, mine, xv, respread_at,
                                               respread2_at, s_diag[wave], x + first * N, iters ? iters + first : nullptr, moved);
         else
-            it = admm_fwd_diag<KIND, E, LaneGroup<LPP>>(p, qv, rad, N, eps, mu_prox, max_iter, adaptive, valid, xv, lo,
+            it = admm_fwd_diag<KIND, E, LaneGroup<LPP>>(p, qv, rad, N, eps, mu_prox, max_iter, adaptive, mine, xv, lo,
                                                         hi, sg);
     }
 #ifdef DQQ_TIMELINE
     {
-        int m = valid ? it : 0, s = valid ? it : 0;
+        int m = mine ? it : 0, s = mine ? it : 0;
         for (int o = 32; o; o >>= 1) { m = max(m, __shfl_xor(m, o)); s += __shfl_xor(s, o); }
         DQQ_TL_VAL(6, (unsigned long long)m);
         DQQ_TL_VAL(7, (unsigned long long)s);
     }
 #endif
 
-    if (valid) {
+    if (mine) {
         if (!moved) {
             double* xx = x + first * N + lane * E;
 #pragma unroll
@@ -250,12 +262,19 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
             if (iters != nullptr && (lane % LPP) == 0) iters[first + pl] = it;
         }
         // hand the verified diagonal to the backward of the same problems (it then skips the P stream)
-        if (flags_out != nullptr && (lane % LPP) == 0 && !dense_tile) flags_out[first + pl] = 1;
-        if (pdiag_out != nullptr && !dense_tile) {
+        if (flags_out != nullptr && (lane % LPP) == 0) flags_out[first + pl] = 1;
+        if (pdiag_out != nullptr) {
             double* pp = pdiag_out + first * N + lane * E;
 #pragma unroll
             for (int e = 0; e < E; e += 2) *reinterpret_cast<double2*>(pp + e) = make_double2(p[e], p[e + 1]);
         }
+    }
+    if constexpr (GD) {
+        // the tile's non-diagonal problems: the general solve on LD lanes per problem, 64 / LD problems per pass; it reads its
+        // inputs and writes x / iters itself, in its own mapping
+        if (__builtin_expect(dense_tile, 0))
+            group_dense_tile<KIND, N, LD, PPW>(P, q, l_n, mu_c, v_sign, x, iters, first, nvalid, eps, mu_prox, max_iter,
+                                               adaptive, lane, gdefer, dmask, LPP);
     }
     DQQ_TL(5);
 }
@@ -401,23 +420,17 @@ hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fus
         lpp = fwd_diag_default_lpp(a.N, a.B, kind);
         // a batch declared dense takes the general solve's own mapping (N/2 lanes per problem): one pass per tile
         if (a.layout == DQQ_P_DENSE && a.N <= 8) lpp = a.N / 2;
-        // ... and so does a DQQ_P_AUTO batch when the last backward of this kind, N and B found ANY of its problems
-        // non-diagonal (launch.h: the feedback word of dqq_set_feedback): on two lanes per problem a non-diagonal tile of
-        // N = 8 takes TWO passes of the four-lane general solve, and the launch lasts as long as its slowest wave -- one such
-        // problem in 1000 is enough (65536 x 8, forward, two / four lanes, tools/probe_sparse_dense_lpp.py: none 24.7 / 26.3 us
-        // QP, 29.9 / 34.2 QCQP; one in 1000: 66 / 44, 79 / 51; one in 10: 97 / 71, 112 / 86; all: 106 / 77, 116 / 94; the same
-        // order at 131072 and 262144).  The same bits either way -- an iterate does not depend on the lane layout
-        // (admm_diag_body.inc, admm_diag_prologue.inc), the general solve is the four-lane one in both -- so the hint costs
-        // or saves time, nothing else.
-        // Half of the batch or more non-diagonal: ONE lane per problem -- the same general solve with a problem's whole matrix
-        // in its lane's registers (no gathers: 65536 x 8 all dense, QP 77 -> 59 us, QCQP 94 -> 77; from one problem in 10 on
-        // it beats four lanes at every batch size measured, below that it loses: a lone non-diagonal tile is then 64 problems
-        // on one wave).  Also the same bits: the sums of group_dense.h and of the diagonal arithmetic are taken over one tree
-        // on one, two and four lanes, and the reciprocals, pow() and every fused multiply-add are the same instructions.
+        // A DQQ_P_AUTO batch of which the last backward of this kind, N and B found half or more non-diagonal (launch.h: the
+        // feedback word of dqq_set_feedback) runs on ONE lane per problem: the general solve with a problem's whole matrix
+        // in its lane's registers instead of four lanes exchanging rows (65536 x 8 all non-diagonal, forward: QP 106 -> 65 us,
+        // QCQP 116 -> 84; one problem in 10: 95 -> 68, 109 -> 82; tools/probe_sparse_dense_lpp.py).  Below that share two
+        // lanes stay: since non-diagonal problems are handed to the general solve one by one (the kernel above), a sparse
+        // few cost one pass of it per affected 16-problem block -- one in 1000: 46 / 52 us, what four lanes per problem took.
+        // The same bits either way: neither the diagonal arithmetic nor the general solve depends on the lane layout, and
+        // which of the two a problem gets depends on the problem alone.
         if (a.layout == DQQ_P_AUTO && fuse && a.N == 8 && kind < 2 && lpp == 2 && g_fwd_feedback.load() != 0) {
-            const long pred = worklist_predicted(kind, a.N, a.B);
-            if (pred > 0 && hint_allowed_on(s)) {
-                lpp = (2 * pred >= a.B) ? 1 : 4;
+            if (2 * worklist_predicted(kind, a.N, a.B) >= a.B && hint_allowed_on(s)) {
+                lpp = 1;
                 g_fwd_feedback_routes.fetch_add(1, std::memory_order_relaxed);
             }
         }

@@ -101,6 +101,25 @@ struct GroupRows {
                 A[e][c + 1] = t.y;
             }
     }
+    // does this problem have an off-diagonal entry that is not +-0?  (lane s looks at its rows; the verdict is the group's)
+    static DQQ_D bool not_diagonal(const double* __restrict__ Pg, int s, bool valid)
+    {
+        unsigned nz = 0;
+        if (valid) {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+#pragma unroll
+                for (int c = 0; c < N; c += 2) {
+                    const double2 t = *reinterpret_cast<const double2*>(Pg + (s * E + e) * N + c);
+#pragma unroll
+                    for (int j = 0; j < LPP; ++j) {   // (the row's own column is a compile-time constant per lane of the group)
+                        const int g = j * E + e;
+                        if (s == j) nz |= (c == g ? 0u : nonzero_bits(t.x)) | (c + 1 == g ? 0u : nonzero_bits(t.y));
+                    }
+                }
+        }
+        return LaneGroup<LPP>::max(nz != 0 ? 1.0 : 0.0) > 0.0;
+    }
     // rows s*E.. of the symmetric matrix the LOWER triangle of P defines (what llt() factorises), diagonal `md`.
     // Entry (g, c) is P[g][c] for c <= g and P[c][g] beyond: both the row g and the column g are loaded, from ONE
     // per-lane pointer each with compile-time offsets, and the side is chosen per entry.  (Indexed as
@@ -333,8 +352,10 @@ template <int KIND, int N, int LD, int TILE>
 DQQ_D void group_dense_tile(const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ l_n,
                             const double* __restrict__ mu_c, const double* __restrict__ v_sign, double* __restrict__ x,
                             int* __restrict__ iters, long first, int nvalid, double eps, double mu, int max_iter,
-                            int adaptive, int lane, int defer = 4)
+                            int adaptive, int lane, int defer = 4, unsigned long long dmask = ~0ull, int mask_stride = 0)
 {
+    // dmask / mask_stride: only the problems j of the tile with bit j * mask_stride of dmask set are solved here (the caller's
+    // ballot over ITS lanes, mask_stride lanes per problem); mask_stride = 0: all of them
     constexpr int E = N / LD, PPP = 64 / LD; // coordinates per lane, problems per pass
     static_assert(E >= 2 && E % 2 == 0 && TILE % PPP == 0, "whole contacts per lane, whole passes per tile");
     constexpr int EB = (KIND >= 2) ? E : 1;
@@ -343,7 +364,8 @@ DQQ_D void group_dense_tile(const double* __restrict__ P, const double* __restri
     for (int pass = 0; pass < TILE / PPP; ++pass) {
         const int pj = pass * PPP + lane / LD;
         if (pass * PPP >= nvalid) break;            // wave-uniform
-        const bool valid = pj < nvalid;
+        const bool valid = pj < nvalid && (mask_stride == 0 || ((dmask >> (pj * mask_stride)) & 1ull) != 0);
+        if (!__any(valid)) continue;                // (none of this pass's problems is non-diagonal)
         const long prob = first + pj;
         double qv[E], xv[E], rad[E / 2], lo[EB], hi[EB], sg[EB];
 #pragma unroll

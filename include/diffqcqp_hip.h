@@ -206,9 +206,8 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
  *                    evaluation-order noise of the reference's own formulas) or the reference-order kernels (0: LDS
  *                    wave kernel up to N = 42, global-memory kernel beyond -- 1e-9, 10-30x slower, and 42 < N <= 64
  *                    then needs dqq_scratch_bytes of scratch)
- *   "fwd_feedback"   DQQ_P_AUTO forward, N = 8, QP / QCQP, with dqq_set_feedback: four lanes per problem instead of two when the
- *                    last backward of this kind, N and B found any non-diagonal problem, one lane per problem when it found
- *                    half of the batch or more (1, default), or
+ *   "fwd_feedback"   DQQ_P_AUTO forward, N = 8, QP / QCQP, with dqq_set_feedback: one lane per problem instead of two when the
+ *                    last backward of this kind, N and B found half of the batch or more non-diagonal (1, default), or
  *                    never look at the word (0).  Bit-identical results.  "fwd_feedback_routes" counts those launches.
  *   "bwd_skip_classify"  DQQ_P_AUTO backward, N <= 8, QP / QCQP, with dqq_set_feedback: when the last two backwards of this
  *                    kind, N and B found three quarters of the batch or more non-diagonal, skip the fast path's launch and solve the whole batch
@@ -228,9 +227,9 @@ int dqq_get_option(const char* name, int* value);
  * they fill the chip: 65536 dense 8x8 QCQP problems 100 -> ~60 us) -- and how many there are is known on the device only.
  * With a buffer registered, that launch stores the number it found in the buffer, and the NEXT backward of the same kind, N
  * and B picks its kernel by it (a training loop presents the same kind of batch step after step); the next FORWARD of that
- * kind, N = 8 and B spreads its problems over four lanes instead of two when any of them was non-diagonal (one pass of
- * the in-kernel general solve per tile instead of two: 65536 x 8 QCQP forward, all dense 116 -> 94 us, one dense problem in
- * 1000 79 -> 51 us), or gives every problem one lane when half of the batch or more was non-diagonal (all dense: 77 us); and a backward whose last two
+ * kind, N = 8 and B gives every problem one lane instead of two when half of the batch or more was non-diagonal (the
+ * in-kernel general solve with a problem's whole matrix in one lane's registers: all dense 126 -> 84 us per 65536 QCQPs);
+ * and a backward whose last two
  * predecessors found at least three quarters of the batch non-diagonal skips the classifying launch: one launch of the lane-per-problem kernel
  * over the batch, which recounts for the call after it.  The two kernels give
  * the same results bit for bit on any list, so the word is a hint: stale, racy or absent, it changes the time of a call and
