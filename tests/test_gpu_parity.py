@@ -623,6 +623,38 @@ def test_a_diagonal_problem_gets_the_fast_paths_bits_from_the_general_backward(o
 
 
 @pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("N", [8, 4, 2])
+def test_a_problems_result_does_not_depend_on_its_neighbours_or_the_batch_size(ops, kind, N):
+    """DQQ_P_AUTO, N <= 8: which routine solves a problem -- the diagonal arithmetic or the in-kernel general solve -- is decided
+    problem by problem, and neither depends on the lane layout; the backward's general kernels give a diagonal problem the bits
+    of its fast path.  So the same problems, shuffled among each other and cut into batches of other sizes (other layouts:
+    four lanes per problem below 57344 problems at N = 8, two above), give the same x, iteration counts, gradients and
+    refinement step counts, bit for bit."""
+    B = 60000
+    dense, diag = make_problem(kind, B, N, 821, "dense"), make_problem(kind, B, N, 822, "diag")
+    gen = torch.Generator().manual_seed(823)
+    pick = torch.rand(B, generator=gen) < 0.07                  # 7 % non-diagonal, scattered
+    d = {k: torch.where(pick.view(-1, *([1] * (v.dim() - 1))), dense[k], diag[k]) for k, v in diag.items()}
+    perm = torch.randperm(B, generator=gen)
+    bits = lambda t: t.view(torch.int64) if t.dtype is torch.float64 else t
+
+    def run(t):
+        g = dev(t)
+        x, it = hip_fwd(ops, kind, g)
+        gr, st = hip_bwd(ops, kind, g, x)
+        return [x, it] + gr + [st]
+
+    ref = run(d)
+    shuffled = run({k: v[perm].contiguous() for k, v in d.items()})
+    for a, b in zip(ref, shuffled):
+        assert torch.equal(bits(a[perm]), bits(b))
+    for lo, hi in ((0, 777), (777, 777 + 20011), (30000, 60000)):
+        part = run({k: v[lo:hi].contiguous() for k, v in d.items()})
+        for a, b in zip(ref, part):
+            assert torch.equal(bits(a[lo:hi]), bits(b))
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
 def test_racing_hints_never_change_a_result(ops, kind):
     """Two streams, each with its own workspace, alternate dense, mixed and diagonal batches of ONE (kind, N, B) without ever
     waiting for each other: the feedback word is written and read in every order the hardware produces, most hints are
