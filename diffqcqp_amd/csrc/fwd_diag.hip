@@ -222,8 +222,12 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
         // every tile takes, headline step 56 -> 69 us.)
         if (__builtin_expect(dense_tile, 0)) {
             bool densep = valid;   // declared dense: every problem
-            if (layout != DQQ_P_DENSE)
-                densep = GroupRows<N, LPP>::not_diagonal(P + (first + pl) * (long)(N * N), lane % LPP, valid);
+            if (layout != DQQ_P_DENSE) {
+                int* pf = reinterpret_cast<int*>(s_diag[wave]);   // (the staged diagonals are not needed any more, below)
+                tile_problem_flags<N, NCH, PPW>(P + first * (long)(N * N), nvalid * N * N, pf, lane);
+                densep = valid && pf[pl] != 0;
+                wave_lds_fence();
+            }
             if (flags_out != nullptr && densep && (lane % LPP) == 0) flags_out[first + pl] = 2; // seen, not diagonal
             dmask = __ballot(densep);
             mine = valid && !densep;

@@ -101,25 +101,6 @@ struct GroupRows {
                 A[e][c + 1] = t.y;
             }
     }
-    // does this problem have an off-diagonal entry that is not +-0?  (lane s looks at its rows; the verdict is the group's)
-    static DQQ_D bool not_diagonal(const double* __restrict__ Pg, int s, bool valid)
-    {
-        unsigned nz = 0;
-        if (valid) {
-#pragma unroll
-            for (int e = 0; e < E; ++e)
-#pragma unroll
-                for (int c = 0; c < N; c += 2) {
-                    const double2 t = *reinterpret_cast<const double2*>(Pg + (s * E + e) * N + c);
-#pragma unroll
-                    for (int j = 0; j < LPP; ++j) {   // (the row's own column is a compile-time constant per lane of the group)
-                        const int g = j * E + e;
-                        if (s == j) nz |= (c == g ? 0u : nonzero_bits(t.x)) | (c + 1 == g ? 0u : nonzero_bits(t.y));
-                    }
-                }
-        }
-        return LaneGroup<LPP>::max(nz != 0 ? 1.0 : 0.0) > 0.0;
-    }
     // rows s*E.. of the symmetric matrix the LOWER triangle of P defines (what llt() factorises), diagonal `md`.
     // Entry (g, c) is P[g][c] for c <= g and P[c][g] beyond: both the row g and the column g are loaded, from ONE
     // per-lane pointer each with compile-time offsets, and the side is chosen per entry.  (Indexed as

@@ -65,4 +65,33 @@ static DQQ_D unsigned stream_tile_diag(const double* __restrict__ Pw, int limit,
     return nz;
 }
 
+// Which problems of a tile are not diagonal?  The tile streamed once more, coalesced (it has just been read: L2), each chunk's
+// verdict dropped into flags[problem] (LDS, `nflags` ints, zeroed here).  Only tiles that stream_tile_diag found non-diagonal come
+// here (fwd_diag.hip): reading a lane's own matrix instead -- N*N*8 bytes from its neighbour's, 64 cache lines per load
+// instruction -- cost an all-dense 65536 x 8 forward on one lane per problem 4 us more.
+template <int N, int NCH, int PPW>
+static DQQ_D void tile_problem_flags(const double* __restrict__ Pw, int limit, int* flags, int lane)
+{
+    if (lane < PPW) flags[lane] = 0;
+    wave_lds_fence();
+    constexpr int U = NCH < 8 ? NCH : 8;
+    for (int k0 = 0; k0 < NCH; k0 += U) {
+        double2 v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int f = (k0 + j) * 128 + 2 * lane;
+            v[j] = f < limit ? *reinterpret_cast<const double2*>(Pw + f) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int f = (k0 + j) * 128 + 2 * lane;
+            const int row = f / N, r = row % N, c = f % N;
+            const unsigned b0 = nonzero_bits(v[j].x), b1 = nonzero_bits(v[j].y);
+            const unsigned b = (c == r) ? b1 : (c + 1 == r) ? b0 : (b0 | b1);
+            if (b != 0) flags[row / N] = 1;
+        }
+    }
+    wave_lds_fence();
+}
+
 } // namespace dqq
