@@ -693,6 +693,60 @@ def test_racing_hints_never_change_a_result(ops, kind):
         _capi.enable_feedback(was_on)
 
 
+def test_two_host_threads_two_streams_same_bits(ops):
+    """The entry points are re-entrant (include/diffqcqp_hip.h): two host threads, each on its own stream with its own
+    workspace, run QP and QCQP forward + backward on dense, mixed and diagonal batches at the same time, the feedback word
+    shared between them.  Every result is the single-threaded, hint-free run's, bit for bit."""
+    import threading
+    from diffqcqp_amd import _capi
+    N, B = 8, 57344 + 1024 + 11
+    data = {}
+    for kind in ("qp", "qcqp"):
+        dense, diag = make_problem(kind, B, N, 831, "dense"), make_problem(kind, B, N, 832, "diag")
+        mixed = {k: v.clone() for k, v in diag.items()}
+        mixed["P"][777:790] = dense["P"][777:790]
+        data[kind] = [dev(b) for b in (dense, diag, mixed)]
+    was_on = _capi._feedback is not None
+    _capi.enable_feedback(False)
+    ref = {}
+    for kind, batches in data.items():
+        for i, g in enumerate(batches):
+            x, it = hip_fwd(ops, kind, g)
+            ref[kind, i] = (x, it, hip_bwd(ops, kind, g, x))
+    torch.cuda.synchronize()
+    _capi.enable_feedback(True)
+    got, errors = [], []
+
+    def worker(kind, order):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for i in order:
+                    g = data[kind][i]
+                    x, it = hip_fwd(ops, kind, g)
+                    got.append((kind, i, x, it, hip_bwd(ops, kind, g, ref[kind, i][0])))
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:  # noqa: BLE001  (reported by the main thread)
+            errors.append(e)
+
+    try:
+        threads = [threading.Thread(target=worker, args=("qp", [0, 0, 0, 1, 2, 0, 1, 1, 2, 0, 0, 0])),
+                   threading.Thread(target=worker, args=("qcqp", [1, 0, 0, 0, 2, 2, 1, 0, 0, 0, 1, 2]))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        torch.cuda.synchronize()
+        assert not errors, errors
+        assert len(got) == 24
+        for kind, i, x, it, bw in got:
+            assert torch.equal(x, ref[kind, i][0]) and torch.equal(it, ref[kind, i][1])
+            for u, v in zip(bw[0] + [bw[1]], ref[kind, i][2][0] + [ref[kind, i][2][1]]):
+                assert torch.equal(u, v)
+    finally:
+        _capi.enable_feedback(was_on)
+
+
 @pytest.mark.parametrize("kind,N,B", [("qcqp", 64, 40), ("qcqp", 50, 24), ("qcqp", 44, 24), ("box", 32, 48), ("box", 22, 30)])
 def test_reference_order_backward_beyond_the_wave_kernel(oracle, ops, kind, N, B):
     """The global-memory workgroup kernel in the reference's operation order -- the default for box 21 < N <= 32, and for
