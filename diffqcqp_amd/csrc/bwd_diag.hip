@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : (KIND == 1 ? 4 :
     if (first >= B) return; // whole wave leaves; no workgroup barrier is used below
     const int nvalid = (B - first) < T ? (int)(B - first) : T;
     const int pl = lane / HL, j = lane % HL;
-    const bool valid = pl < nvalid;
+    bool valid = pl < nvalid;   // (narrowed below to the problems this kernel solves itself)
     double *pd = s_pd[wave], *dlv = s_dl[wave], *xs = s_x[wave], *rs = s_rs[wave];
     const int limit = nvalid * N * N;
 
@@ -67,11 +67,17 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : (KIND == 1 ? 4 :
     // A tile all of whose problems the forward saw in non-diagonal tiles (flag 2) is queued without a look at P
     // (for N >= 32 the forward's tiles are this kernel's, so that is the decision the stream would reach; below, a
     // diagonal problem that lands in the general kernel this way gets the same bits: both follow the reference's order).
-    bool have_diag = false, known_dense = false;
+    // A tile with BOTH kinds, every problem classified (round 4, late: the fused forward of N <= 8 classifies problem by
+    // problem): only the flag-2 problems are queued, the others take the fast path with the forward's diagonal -- a batch
+    // with a few non-diagonal problems no longer sends 16 problems to the general kernel for each of them.  (The same bits
+    // either way, see above.)
+    bool have_diag = false, known_dense = false, by_problem = false;
+    int f = -1;
     if (pdiag != nullptr && flags != nullptr && layout == DQQ_P_AUTO) {
-        const int f = valid ? flags[first + pl] : -1;
+        f = valid ? flags[first + pl] : -1;
         have_diag = __all(f == 1 || f == -1);
         known_dense = __all(f == 2 || f == -1);
+        by_problem = !FUSE && !worklist_segmented(N) && !have_diag && !known_dense && __all(f == 1 || f == 2 || f == -1);
     }
     constexpr bool AGG = !FUSE && WPB > 1; // queue non-diagonal tiles with ONE atomic per workgroup (see launch.h)
     __shared__ int s_cnt[2];
@@ -83,8 +89,8 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : (KIND == 1 ? 4 :
         bool tile_dense = known_dense;
         if (known_dense) {
             pv = make_double2(1.0, 1.0);
-        } else if (have_diag) {
-            pv = valid ? *reinterpret_cast<const double2*>(pdiag + first * N + 2 * lane) : make_double2(1.0, 1.0);
+        } else if (have_diag || by_problem) {
+            pv = (valid && f == 1) ? *reinterpret_cast<const double2*>(pdiag + first * N + 2 * lane) : make_double2(1.0, 1.0);
         } else {
             const double* Pw = P + first * (long)(N * N);
             const unsigned nz = (nvalid == T) ? stream_tile_diag<N, N, false>(Pw, limit, pd, lane)
@@ -99,10 +105,18 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : (KIND == 1 ? 4 :
                 return;
             }
         } else if (layout == DQQ_P_AUTO) {
-            worklist_push<AGG, worklist_segmented(N)>(ws, B, first, tile_dense ? nvalid : 0, lane, s_cnt);
-            if (tile_dense) return;
+            if (by_problem) {
+                const bool queued = f == 2 && j == 0;                          // one lane per queued problem
+                const unsigned long long qm = __ballot(queued);
+                worklist_push_entries<AGG, worklist_segmented(N)>(ws, B, __popcll(qm), queued,
+                                                                  __popcll(qm & ((1ull << lane) - 1)), (int)(first + pl), lane, s_cnt);
+                valid = valid && f == 1;
+            } else {
+                worklist_push<AGG, worklist_segmented(N)>(ws, B, first, tile_dense ? nvalid : 0, lane, s_cnt);
+                if (tile_dense) return;
+            }
         }
-        if (!have_diag) {
+        if (!have_diag && !by_problem) {
             wave_lds_fence();
             pv = valid ? *reinterpret_cast<const double2*>(pd + 2 * lane) : make_double2(1.0, 1.0);
         }

@@ -173,8 +173,10 @@ static inline hipError_t launch(void (*kernel)(KArgs...), dim3 grid, dim3 block,
 // barriers; waves that already ended are not waited for).  s_cnt: two ints of LDS.
 // SEG: the segmented list (see kWsSegCounts): the counter and the slots of segment blockIdx.x mod 32.
 template <bool AGG, bool SEG = false>
-static DQQ_D void worklist_push(int* __restrict__ ws, long B, long first, int n, int lane, int* s_cnt)
+static DQQ_D void worklist_push_entries(int* __restrict__ ws, long B, int n, bool writes, int rank, int entry, int lane,
+                                        int* s_cnt)
 {
+    // n (wave-uniform) entries from this wave; the lanes with `writes` hold them: `entry` goes to slot base + rank
     int* counter = SEG ? ws + kWsSegCounts + (int)(blockIdx.x & 31u) * kWsSubStride : ws + kWsCount;
     int* slots = SEG ? ws + kWsEntries + (long)(blockIdx.x & 31u) * kWsSegCap(B) : ws + kWsEntries;
     if constexpr (!AGG) {
@@ -185,7 +187,7 @@ static DQQ_D void worklist_push(int* __restrict__ ws, long B, long first, int n,
                 if (SEG) ws[kWsCount] = 1;
             }
             base = __shfl(base, 0, 64);
-            if (lane < n) slots[base + lane] = (int)(first + lane);
+            if (writes) slots[base + rank] = entry;
         }
     } else {
         if (threadIdx.x == 0) s_cnt[0] = 0;
@@ -200,9 +202,14 @@ static DQQ_D void worklist_push(int* __restrict__ ws, long B, long first, int n,
         __syncthreads();
         if (n > 0) {
             const int base = s_cnt[1] + __shfl(local, 0, 64);
-            if (lane < n) slots[base + lane] = (int)(first + lane);
+            if (writes) slots[base + rank] = entry;
         }
     }
+}
+template <bool AGG, bool SEG = false>
+static DQQ_D void worklist_push(int* __restrict__ ws, long B, long first, int n, int lane, int* s_cnt)
+{
+    worklist_push_entries<AGG, SEG>(ws, B, n, lane < n, lane, (int)(first + lane), lane, s_cnt);
 }
 
 // Readers of the work-list for the kernels that drain it with a fixed stride (the kernels behind tuning options and

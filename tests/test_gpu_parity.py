@@ -231,11 +231,16 @@ def test_ragged_and_empty_batches(oracle, ops, kind, B):
 
 @pytest.mark.parametrize("kind", ["qp", "qcqp"])
 @pytest.mark.parametrize("N,B,structure", [(8, 2051, "diag"), (8, 700, "mixed"), (32, 131, "diag"), (32, 61, "mixed"),
-                                           (2, 777, "diag"), (64, 20, "diag")])
+                                           (2, 777, "diag"), (64, 20, "diag"), (8, 20011, "mixed"), (4, 20011, "mixed"),
+                                           (2, 20011, "mixed"), (8, 20011, "sparse")])
 def test_backward_with_the_forwards_diagonal_cache_is_identical(oracle, ops, kind, N, B, structure):
     """The forward can leave the verified diagonal of P for the backward of the same problems (which then
     skips the P stream); non-diagonal tiles are flagged and still read P.  Results must be bit-identical."""
-    d = make_problem(kind, B, N, 420 + N, structure)
+    if structure == "sparse":   # one non-diagonal problem in 97
+        d, dd = make_problem(kind, B, N, 420 + N, "diag"), make_problem(kind, B, N, 421 + N, "dense")
+        d["P"][5::97] = dd["P"][5::97]
+    else:
+        d = make_problem(kind, B, N, 420 + N, structure)
     g = dev(d)
     cache = ops.diag_cache(g["q"])
     cache[1].fill_(1)  # stale flags must be overwritten by the forward, not trusted
@@ -253,6 +258,13 @@ def test_backward_with_the_forwards_diagonal_cache_is_identical(oracle, ops, kin
     offdiag = (d["P"] - torch.diag_embed(torch.diagonal(d["P"], dim1=1, dim2=2))).abs().amax((1, 2)).numpy() > 0
     assert (flags[offdiag] == 2).all(), "a non-diagonal problem must be flagged 2 (seen, not diagonal)"
     assert np.isin(flags, (1, 2)).all(), "the forward examines every problem"
+    if N <= 8:   # problem by problem: a diagonal problem next to a non-diagonal one is still handed over as diagonal, and the
+        # backward (B large enough for the work-list route) queues only the flag-2 problems of such a tile
+        assert (flags[~offdiag] == 1).all()
+        assert torch.equal(cache[0][torch.from_numpy(~offdiag).cuda()],
+                           torch.diagonal(g["P"], dim1=1, dim2=2)[torch.from_numpy(~offdiag).cuda()])
+    for ws in ops._workspaces.values():
+        assert header_is_clean(ws)
     if structure == "diag":
         assert flags.all()
         assert torch.equal(cache[0], torch.diagonal(g["P"], dim1=1, dim2=2))
