@@ -154,7 +154,7 @@ def feedback_words():
     """The registered buffer's words as (B, entries) pairs, index kind * 4 + N / 2 - 1 (a debugging view), or None."""
     if _feedback is None:
         return None
-    return [((int(w) >> 32) & 0x3fffffff, int(w) & 0xffffffff) for w in _feedback.tolist()]
+    return [((int(w) >> 32) & 0x3fffffff, int(w) & 0x7fffffff) for w in _feedback.tolist()]   # (bit 31: entries are single problems)
 
 
 def feedback_streaks():

@@ -110,6 +110,7 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : (KIND == 1 ? 4 :
                 const unsigned long long qm = __ballot(queued);
                 worklist_push_entries<AGG, worklist_segmented(N)>(ws, B, __popcll(qm), queued,
                                                                   __popcll(qm & ((1ull << lane) - 1)), (int)(first + pl), lane, s_cnt);
+                if (lane == 0 && qm != 0) ws[kWsPerProblem] = 1;   // (launch.h: how the drain's report is to be read)
                 valid = valid && f == 1;
             } else {
                 worklist_push<AGG, worklist_segmented(N)>(ws, B, first, tile_dense ? nvalid : 0, lane, s_cnt);

@@ -433,7 +433,7 @@ hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fus
         // The same bits either way: neither the diagonal arithmetic nor the general solve depends on the lane layout, and
         // which of the two a problem gets depends on the problem alone.
         if (a.layout == DQQ_P_AUTO && fuse && a.N == 8 && kind < 2 && lpp == 2 && g_fwd_feedback.load() != 0) {
-            if (2 * worklist_predicted(kind, a.N, a.B) >= a.B && hint_allowed_on(s)) {
+            if (2 * worklist_predicted_in_blocks(kind, a.N, a.B) >= a.B && hint_allowed_on(s)) {
                 lpp = 1;
                 g_fwd_feedback_routes.fetch_add(1, std::memory_order_relaxed);
             }

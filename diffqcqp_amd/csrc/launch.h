@@ -23,6 +23,7 @@ constexpr int kWsTicket = 1;
 constexpr int kWsNext = 2; // work-list mode with dynamic pick-up: next unclaimed entry
 constexpr int kWsRepTop = 8;    // [8..9] bwd_lane_dense.hip, REPORT mode: 64-bit (groups arrived, problems counted); zero between launches
 constexpr int kWsFbShadow = 4;  // [4..7]: what this workspace's drain launches last wrote to the feedback buffer, and where (below)
+constexpr int kWsPerProblem = 11; // bwd_diag.hip: 1 = this list holds single problems of classified mixed tiles (not whole tiles); cleared by the drain
 constexpr int kWsSubTickets = 32;   // first of 32 sub-tickets, kWsSubStride ints apart
 constexpr int kWsSubStride = 32;    // 128 bytes: one sub-ticket per cache line
 // N >= 32 (one to sixteen problems per workgroup of the fast kernel: a dense batch through DQQ_P_AUTO queues from
@@ -67,6 +68,7 @@ static DQQ_D void worklist_release(int* ws, long count, int participants)
                 ws[kWsCount] = 0;
                 ws[kWsTicket] = 0;
                 ws[kWsNext] = 0;
+                ws[kWsPerProblem] = 0;
                 for (int h = 0; h < 32; ++h) {  // (segmented list, N >= 32)
                     ws[kWsSegCounts + h * kWsSubStride] = 0;
                     ws[kWsSegNext + h * kWsSubStride] = 0;
@@ -99,21 +101,37 @@ inline unsigned long long* worklist_feedback_slot(int kind, int N)
     const int i = worklist_feedback_index(kind, N);
     return (fb != nullptr && i >= 0) ? fb + i : nullptr;
 }
-// The word: bits 0..31 entries found, 32..61 B (mod 2^30), 62..63 how many times IN A ROW before this one the same
-// workspace reported "three quarters of the batch or more" (saturating at 3).
-constexpr unsigned long long kFbBMask = 0x3fffffffULL;
+// The word: bits 0..30 entries found, bit 31 "the entries are single problems" (with the forward's hand-off the fast path
+// queues only the non-diagonal problems of a classified tile; otherwise whole tiles of 128 / N), 32..61 B (mod 2^30),
+// 62..63 how many times IN A ROW before this one the same workspace reported "three quarters of the batch or more"
+// (saturating at 3).
+constexpr unsigned long long kFbBMask = 0x3fffffffULL, kFbCountMask = 0x7fffffffULL, kFbPerProblem = 0x80000000ULL;
 // entries the last finished drain launch of (kind, N) found, if it ran on a batch of B problems; -1: not known.
 // *streak (optional): consecutive earlier reports of count >= 3/4 B.
-inline long worklist_predicted(int kind, int N, long B, int* streak = nullptr)
+inline long worklist_predicted(int kind, int N, long B, int* streak = nullptr, bool* per_problem = nullptr)
 {
     const volatile unsigned long long* fb = g_feedback_host.load(std::memory_order_relaxed);
     const int i = worklist_feedback_index(kind, N);
     if (streak != nullptr) *streak = 0;
+    if (per_problem != nullptr) *per_problem = false;
     if (fb == nullptr || i < 0) return -1;
     const unsigned long long w = fb[i];
     if (w == 0 || ((w >> 32) & kFbBMask) != ((unsigned long long)B & kFbBMask)) return -1;
     if (streak != nullptr) *streak = (int)(w >> 62);
-    return (long)(w & 0xffffffffULL);
+    if (per_problem != nullptr) *per_problem = (w & kFbPerProblem) != 0;
+    return (long)(w & kFbCountMask);
+}
+// problems that sit in a 16-problem block with a non-diagonal one (what the fused forward of N = 8 pays for: one pass of its
+// general solve per such block), from the word: the count itself when whole tiles were queued, an estimate for scattered
+// problems when single problems were
+inline long worklist_predicted_in_blocks(int kind, int N, long B)
+{
+    bool per_problem = false;
+    const long c = worklist_predicted(kind, N, B, nullptr, &per_problem);
+    if (c <= 0 || !per_problem) return c;
+    double stay = 1.0 - (double)c / (double)B, p = stay;
+    for (int k = 0; k < 4; ++k) p *= p;   // (1 - c/B)^16
+    return (long)((double)B * (1.0 - p));
 }
 // A hint may change a route only OUTSIDE stream capture: a captured graph is replayed on batches the word knows nothing about,
 // so what goes into it is the argument-determined route (asked only when a hint is about to be followed: one runtime call).
@@ -130,14 +148,16 @@ inline bool hint_allowed_on(hipStream_t s)
 // that alternates between kinds of batches under one (kind, N, B) never gets there.
 static DQQ_D void worklist_feedback(unsigned long long* fb, int* ws, long B, long count)
 {
+    const bool per_problem = ws[kWsPerProblem] != 0;   // (set by the fast path that filled this list; this launch drains it)
+    if (per_problem) ws[kWsPerProblem] = 0;
     if (fb == nullptr) return;
     unsigned long long* shadow = reinterpret_cast<unsigned long long*>(ws + kWsFbShadow);   // (ws: 16-byte aligned)
     const unsigned long long prev = shadow[0], bb = (unsigned long long)B & kFbBMask;
     const bool same_place = shadow[1] == reinterpret_cast<unsigned long long>(fb);
     unsigned long long streak = 0;
-    if (same_place && ((prev >> 32) & kFbBMask) == bb && 4 * (long)(prev & 0xffffffffULL) >= 3 * B && 4 * count >= 3 * B)
+    if (same_place && ((prev >> 32) & kFbBMask) == bb && 4 * (long)(prev & kFbCountMask) >= 3 * B && 4 * count >= 3 * B)
         streak = (prev >> 62) < 3 ? (prev >> 62) + 1 : 3;
-    const unsigned long long v = (streak << 62) | (bb << 32) | (unsigned long long)count;
+    const unsigned long long v = (streak << 62) | (bb << 32) | (per_problem ? kFbPerProblem : 0ULL) | (unsigned long long)count;
     if (prev == v && same_place) return;
     shadow[0] = v;
     shadow[1] = reinterpret_cast<unsigned long long>(fb);

@@ -667,6 +667,48 @@ def test_a_problems_result_does_not_depend_on_its_neighbours_or_the_batch_size(o
 
 
 @pytest.mark.parametrize("kind", ["qp", "qcqp"])
+@pytest.mark.parametrize("every,one_lane", [(8, True), (100, False)])
+def test_forward_hint_with_the_hand_off_counts_blocks_not_problems(ops, kind, every, one_lane):
+    """With the forward's hand-off the backward queues single problems, and the word says so (bit 31): the forward's hint --
+    which pays per 16-problem block with a non-diagonal problem, not per problem -- estimates the blocks from the count.
+    One problem in 8, scattered: nearly every block has one, one lane per problem; one in 100: two lanes stay.  Same bits."""
+    from diffqcqp_amd import _capi
+    N, B = 8, 57344 + 2048 + 5
+    d, dd = make_problem(kind, B, N, 841, "diag"), make_problem(kind, B, N, 842, "dense")
+    d["P"][3::every] = dd["P"][3::every]
+    g = dev(d)
+    ndense = len(range(3, B, every))
+    slot = (0 if kind == "qp" else 1) * 4 + N // 2 - 1
+    was_on = _capi._feedback is not None
+    _capi.enable_feedback(True)
+    try:
+        _capi._feedback.zero_()
+        _capi.set_option("fwd_feedback_routes", 0)
+        cache = ops.diag_cache(g["q"])
+        if kind == "qp":
+            fwd = lambda: ops.qp_forward(g["P"], g["q"], 1e-7, 1000, cache=cache, return_iters=True)
+            bwd = lambda x: ops.qp_backward(g["P"], g["q"], x, g["grad_x"], cache=cache)
+        else:
+            fwd = lambda: ops.qcqp_forward(g["P"], g["q"], g["l_n"], g["mu"], 1e-7, 1000, cache=cache, return_iters=True)
+            bwd = lambda x: ops.qcqp_backward(g["P"], g["q"], g["l_n"], g["mu"], x, g["grad_x"], cache=cache)
+        x2, it2 = fwd()
+        b2 = bwd(x2)
+        torch.cuda.synchronize()
+        assert _capi.get_option("fwd_feedback_routes") == 0
+        assert _capi.feedback_words()[slot] == (B, ndense)                      # single problems ...
+        assert (int(_capi._feedback[slot]) >> 31) & 1 == 1                      # ... and the word says so
+        x1, it1 = fwd()
+        b1 = bwd(x1)
+        torch.cuda.synchronize()
+        assert _capi.get_option("fwd_feedback_routes") == (1 if one_lane else 0)
+        assert torch.equal(x1, x2) and torch.equal(it1, it2)
+        for u, v in zip(b1, b2):
+            assert torch.equal(u, v)
+    finally:
+        _capi.enable_feedback(was_on)
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
 def test_racing_hints_never_change_a_result(ops, kind):
     """Two streams, each with its own workspace, alternate dense, mixed and diagonal batches of ONE (kind, N, B) without ever
     waiting for each other: the feedback word is written and read in every order the hardware produces, most hints are
