@@ -20,13 +20,19 @@ Workloads (`--config k` = k-th entry of BASELINE.json `configs`, 1-based as in B
             RCCL all-gather of x in every step (behind the forward, beside the backward), the rates without it and
             with it serialised behind the backward are reported alongside
   5         B=65536 N=64 dense-P QP forward+backward (P = S S^T/64 + 0.1 I), through DQQ_P_AUTO as QPFn2 calls it
+  8         `qp_pair`: B=65536 N=8 QP forward+backward, ONE stream -- north_star's target sentence ("N = 8 QP fwd+bwd
+            solves/s on 1 x MI355X with its HBM fraction") as one timed step;   9  `qp_pair_large`: the same at
+            B=1048576, the batch size that fills the chip
 Timing: W warm-up steps, then R regions of EXACTLY K steps, each bracketed by barrier + torch.cuda.synchronize()
 on both sides and reduced with MAX over the ranks; `ms_per_step` / `value` are the MEDIAN region (min / max in
 `repeats`), so a short K is not a single sub-millisecond sample.
 
-Default run (no --config): on ONE GPU the headline step, followed by short runs of BASELINE configs 2, 3, 4, 5
-(`per_config`: 3 regions each, dominant kernel, roofline fractions, CPU baseline) and the dense-P check (`dense_p_n8`),
-so that one driver-run line carries every workload.  Under torch.distributed.run (WORLD_SIZE set; any number of
+Default run (no --config): on ONE GPU the headline step, followed by short runs of the two qp_pair workloads, BASELINE
+configs 2, 3, 4, 5 (`per_config`: 3 regions each, dominant kernel, roofline fractions, CPU baseline) and the dense-P check
+(`dense_p_n8`), so that one driver-run line carries every workload.  Fractions: every key WITHOUT `algorithmic` in its name
+is computed from the bytes the launches really move (the backward takes the forward's 8N-byte verified diagonal instead of
+re-reading the 8N^2-byte P) and is physically bounded by 6.29 / 8.0 = 0.79; SURVEY.md 8(d)'s algorithmic bytes (which
+count that read) give the `*_algorithmic*` keys, which can exceed 1.  Under torch.distributed.run (WORLD_SIZE set; any number of
 ranks) the line is the SAME headline step on every rank (weak scaling, no data-path collective: value(N) / (N value(1)) is
 the scaling efficiency); `with_gather` = the same step with the path's optional exchange step -- the RCCL all-gather of both
 families' x, behind their forwards, beside their backwards --, and configs[3], the batch SPLIT over the ranks (strong
@@ -36,8 +42,11 @@ Rank 0 prints ONE JSON line.  Besides the contract keys:
   roofline      the launch with the largest mean duration: algorithmic bytes / its duration from
                 HIP events on the launch stream vs 8 TB/s; `moved` = the bytes that launch really reads + writes
                 (the backward takes the 64-byte verified diagonal from the forward instead of the 512-byte P);
-                for the compute-bound config 5 also the FP64 figure (`fp64`)
-  cpu_baseline  the oracle (C port of the reference algorithm) on this box's host cores, bounded sample
+                `traffic` = HBM bytes of that launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) that THIS run
+                spawns over its own launches (`traffic_source` says so; the committed profiles/pmc_latest*.json is the
+                fall-back); for the compute-bound config 5 also the FP64 figure (`fp64`)
+  cpu_baseline  the oracle (C port of the reference algorithm) on this box's host cores, bounded sample; also the
+                reference's execution model -- a Python loop with one FFI call per problem (`python_loop_value`)
   kernels       per-launch breakdown;   cold   the same step over rotating input/output sets (> 256 MiB cache)
   environment   clocks / power cap (rocm-smi) and GPU_MAX_HW_QUEUES of this box; single_stream = the same step on one
                 stream -- boxes of the pool differ by up to ~9 %, compare rounds on both figures
@@ -230,6 +239,11 @@ WORKLOADS = {
         [("qcqp", 8, "dense", True, 0)], 65536, "weak", 16384),
     7: ("dense-P B=65536 N=8 QCQP forward+backward, P declared dense (DQQ_P_DENSE)",
         [("qcqp", 8, "dense", True, 1)], 65536, "weak", 16384),
+    # north_star's target sentence as ONE timed step: N = 8 QP forward+backward on one stream
+    8: ("qp_pair: B=65536 N=8 diagonal-P (dense (B,8,8) layout) QP forward+backward on one stream [BASELINE configs[1] + its "
+        "backward]", [("qp", 8, "diag", True)], 65536, "weak", 16384),
+    9: ("qp_pair_large: B=1048576 N=8 diagonal-P (dense (B,8,8) layout) QP forward+backward on one stream (the batch that "
+        "fills the chip)", [("qp", 8, "diag", True)], 1048576, "weak", 16384),
 }
 
 
@@ -261,6 +275,91 @@ def gpu_environment():
     return env
 
 
+def _pmc_bench_key(name):
+    """bench.py launch name of a kernel from its demangled name: <family>_<pass>; the family is the KIND template argument
+    (0 qp, 1 qcqp) -- the same mapping tools/summarize_prof.py uses for the committed summaries."""
+    import re
+    m = re.search(r"dqq::(\w+)<([^>]*)>", name)
+    if not m:
+        return None, name[:80]
+    s = "%s<%s>" % (m.group(1), m.group(2).replace(" ", ""))
+    if not s.startswith(("fwd_", "bwd_")):
+        return None, s
+    k = re.search(r"<(\d)", s)
+    fam = {"0": "qp", "1": "qcqp"}.get(k.group(1) if k else "0")
+    if "_qp_kernel" in s:
+        fam = "qp"
+    return (None if fam is None else "%s_%s" % (fam, s[:3])), s
+
+
+def live_pmc(cfg, timeout=240):
+    """HBM traffic of this workload's launches, measured now: two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE: they do not fit
+    one pass -- MI355X_MICROARCH.md counter table -- and are collected with --kernel-trace only, never with other trace
+    domains) over a CHILD process that issues each C-ABI call of the workload a few times (`--pmc-child`).  Returns
+    {launch name: {"hbm_bytes_per_launch", "kernels", ...}}, {"_error": ...} or None (rocprofv3 not there)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="dqq_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DQQ_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    per = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--", sys.executable,
+                                os.path.abspath(__file__), "--pmc-child", str(cfg)], capture_output=True, text=True,
+                               timeout=timeout, cwd="/tmp", env=env)
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith("_results.db")]
+            if r.returncode != 0 or not dbs:
+                return {"_error": "rocprofv3 --pmc %s: rc %d, %s" % (counter, r.returncode, (r.stderr or "")[-300:])}
+            c = sqlite3.connect(dbs[0])
+            for name, val, n in c.execute("select kernel_name, avg(value), count(*) from counters_collection "
+                                          "where counter_name = ? group by kernel_name", (counter,)):
+                per.setdefault(name, {})[counter] = (val, n)
+            c.close()
+    except Exception as e:  # noqa: BLE001
+        return {"_error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for name, v in per.items():
+        key, short = _pmc_bench_key(name)
+        if key is None or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+            continue
+        e = res.setdefault(key, {"hbm_bytes_per_launch": 0.0, "hbm_read_bytes_per_launch": 0.0,
+                                 "hbm_write_bytes_per_launch": 0.0, "kernels": [], "dispatches_sampled": 0})
+        e["hbm_read_bytes_per_launch"] += 2.0 * v["FETCH_SIZE"][0] * 1024
+        e["hbm_write_bytes_per_launch"] += v["WRITE_SIZE"][0] * 1024
+        e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
+        e["kernels"].append(short)
+        e["dispatches_sampled"] = max(e["dispatches_sampled"], int(v["FETCH_SIZE"][1]))
+    return res
+
+
+def pmc_child(cfg):
+    """`--pmc-child CFG`: issue every C-ABI call of workload CFG five times on one stream and exit -- the process the
+    counter passes of live_pmc() profile.  Prints nothing."""
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from diffqcqp_amd import _capi, ops
+    _capi.lib()
+    ops.feedback_default()
+    _, families, B_total, _, _ = WORKLOADS[cfg]
+    chains = [Chain(f[0], B_total, f[1], f[2], f[3], dev, 1000 + 17 * (0 if cfg >= 8 else min(cfg, 6)) + 31 * i,
+                    layout=(f[4] if len(f) > 4 else 0)) for i, f in enumerate(families)]
+    sh = torch.cuda.current_stream().cuda_stream
+    for _ in range(5):
+        for c in chains:
+            c.run(sh)
+    torch.cuda.synchronize()
+
+
 def measure(cfg, args, ctx, light=False):
     """One workload -> its record (rank 0; None on the other ranks).  light: a per_config sub-record -- 3 regions, no
     cold set, no single-stream context."""
@@ -284,9 +383,9 @@ def measure(cfg, args, ctx, light=False):
     if cfg == 4 and args.steps == 100:
         steps = 20
     if light:
-        steps, repeats, warmup = {2: 50, 3: 50, 4: 10, 5: 3, 0: 50, 6: 10, 7: 10}[cfg], 3, 3
+        steps, repeats, warmup = {2: 50, 3: 50, 4: 10, 5: 3, 0: 50, 6: 10, 7: 10, 8: 50, 9: 10}[cfg], 3, 3
 
-    chains = [Chain(f[0], B_rank, f[1], f[2], f[3], dev, 1000 + 17 * min(cfg, 6) + 7919 * rank + 31 * i,
+    chains = [Chain(f[0], B_rank, f[1], f[2], f[3], dev, 1000 + 17 * (0 if cfg >= 8 else min(cfg, 6)) + 7919 * rank + 31 * i,
                     layout=(f[4] if len(f) > 4 else 0)) for i, f in enumerate(families)]
     main_stream = torch.cuda.current_stream()
     sh = main_stream.cuda_stream
@@ -382,74 +481,44 @@ def measure(cfg, args, ctx, light=False):
 
     timed = step_and_gather if gather else step
 
-    # ---- per-launch pass FIRST (round 4): HIP events around every launch, then the back-to-back drain figures -- about
-    # 10 ms of GPU work.  After an idle spell the chip takes 10-20 ms to come back to its clocks (tools/probe_region_gap.py: 10 ms of
-    # idleness before a region cost 6 us per step over the NEXT 100 steps), and a driver run with --warmup 5 --steps 20 has only
-    # 0.3 ms of warm-up before 12 ms of timed regions: run behind the diagnostics, the timed regions measure the kernels, not the ramp.
-    # ---- roofline pass: HIP events around every launch of the step, on the launch stream.  The work-list launch
-    # behind an all-diagonal DQQ_P_AUTO batch is switched off here so that each bracket holds exactly one kernel.
-    all_diag = all(c.structure == "diag" for c in chains)
-    nrep = 5 if cfg == 5 else (20 if cfg == 4 else (30 if light else 100))
+    # ---- per-launch pass FIRST (round 4): HIP events around every C-ABI call of the step, then runs of each call back to
+    # back -- about 10 ms of GPU work.  After an idle spell the chip takes 10-20 ms to come back to its clocks
+    # (tools/probe_region_gap.py: 10 ms of idleness before a region cost 6 us per step over the NEXT 100 steps), and a driver
+    # run with --warmup 5 --steps 20 has only 0.3 ms of warm-up before 12 ms of timed regions: run behind the diagnostics,
+    # the timed regions measure the kernels, not the ramp.
+    # A bracket holds one C-ABI CALL: one kernel for the N = 8 forwards (non-diagonal tiles are solved inside the kernel);
+    # the kernel plus the launch that drains its work-list -- empty on a diagonal batch, ~2.6 us -- for the backwards and
+    # for N >= 16 (round 5: the measurement-only knob that used to switch the drain launch off is gone from the library;
+    # rocprofv3's per-kernel durations, profiles/, are the kernel-alone figures).
+    nrep = 5 if cfg == 5 else (20 if cfg in (4, 9) else (30 if light else 100))
     launches = [(c, w) for c in chains for w in range(len(c.names))]
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in launches]
           for _ in range(nrep)]
     for c, w in launches:       # (first launches: module load, function attributes, workspace -- not part of any figure)
         c.launch(w, sh)
     torch.cuda.synchronize()
-    try:
-        if all_diag:
-            _capi.set_option("auto_fallback", 0)   # process-wide: restored whatever happens below
-        for r in range(nrep):
-            for j, (c, w) in enumerate(launches):
-                ev[r][j][0].record(main_stream)
-                c.launch(w, sh)
-                ev[r][j][1].record(main_stream)
-        torch.cuda.synchronize()
-        # the same launches in RUNS: nrep launches of one kernel back to back between two events.  A bracket around a single
-        # launch also times the two event packets (~3 us on a 10-30 us kernel, which is why rocprofv3 read 2-3 us less than this
-        # line did: VERDICT r3); a run's mean is the kernel plus its launch gap and agrees with rocprofv3 to ~2 %
-        # (three runs per kernel, the median counts: one run in a few hundred catches a multi-millisecond stall of the box)
-        runs = []
-        for c, w in launches:
-            trio = []
-            for _ in range(3):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(main_stream)
-                for _ in range(nrep):
-                    c.launch(w, sh)
-                e1.record(main_stream)
-                trio.append((e0, e1))
-            runs.append(trio)
-        torch.cuda.synchronize()
-    finally:
-        _capi.set_option("auto_fallback", 1)
-    # the empty work-list launch behind every DQQ_P_AUTO backward of a diagonal batch: 50 backward calls back to back on
-    # one stream, with and without it (rocprofv3 read 5.5 us per empty launch where DESIGN said 2.5).
-    # Back-to-back figures are ~3 us below the event-bracketed ones above (no event packets between the launches).
-    drain_us = None
-    if all_diag and any(c.backward for c in chains) and not light:
-        drain_us = {}
-
-        def b2b(c):
+    for r in range(nrep):
+        for j, (c, w) in enumerate(launches):
+            ev[r][j][0].record(main_stream)
+            c.launch(w, sh)
+            ev[r][j][1].record(main_stream)
+    torch.cuda.synchronize()
+    # the same launches in RUNS: nrep launches of one kernel back to back between two events.  A bracket around a single
+    # launch also times the two event packets (~3 us on a 10-30 us kernel, which is why rocprofv3 read 2-3 us less than this
+    # line did: VERDICT r3); a run's mean is the kernel plus its launch gap and agrees with rocprofv3 to ~2 %
+    # (three runs per kernel, the median counts: one run in a few hundred catches a multi-millisecond stall of the box)
+    runs = []
+    for c, w in launches:
+        trio = []
+        for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            c.launch(1, sh)
-            torch.cuda.synchronize()
             e0.record(main_stream)
-            for _ in range(50):
-                c.launch(1, sh)
+            for _ in range(nrep):
+                c.launch(w, sh)
             e1.record(main_stream)
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / 50 * 1e3
-        for c in chains:
-            if not c.backward:
-                continue
-            with_drain = b2b(c)
-            try:
-                _capi.set_option("auto_fallback", 0)
-                without = b2b(c)
-            finally:
-                _capi.set_option("auto_fallback", 1)
-            drain_us[c.names[1]] = (without, with_drain)
+            trio.append((e0, e1))
+        runs.append(trio)
+    torch.cuda.synchronize()
     kernels = {}
     for j, (c, w) in enumerate(launches):
         ts = sorted(ev[r][j][0].elapsed_time(ev[r][j][1]) for r in range(nrep))
@@ -458,8 +527,8 @@ def measure(cfg, args, ctx, light=False):
         kernels[c.names[w]] = {"mean_us": mean_ms * 1e3, "bracketed_mean_us": sum(ts) / len(ts) * 1e3,
                                "bracketed_median_us": ts[len(ts) // 2] * 1e3,
                                "bracketed_min_us": ts[0] * 1e3, "bracketed_max_us": ts[-1] * 1e3,
-                               "algo_bytes_per_launch": ab, "algo_GBps": ab / (mean_ms * 1e-3) / 1e9,
-                               "moved_bytes_per_launch": mb, "moved_GBps": mb / (mean_ms * 1e-3) / 1e9}
+                               "moved_bytes_per_launch": mb, "moved_GBps": mb / (mean_ms * 1e-3) / 1e9,
+                               "algorithmic_bytes_per_launch": ab, "algorithmic_GBps": ab / (mean_ms * 1e-3) / 1e9}
     # ---- warm-up (also warms RCCL's all-gather)
     for _ in range(warmup):
         timed()
@@ -537,53 +606,53 @@ def measure(cfg, args, ctx, light=False):
         torch.cuda.empty_cache()
 
     dom = max(kernels, key=lambda k: kernels[k]["mean_us"])
-    step_algo = sum(k["algo_bytes_per_launch"] for k in kernels.values())
+    step_algo = sum(k["algorithmic_bytes_per_launch"] for k in kernels.values())
     step_moved = sum(k["moved_bytes_per_launch"] for k in kernels.values())
     step_s = elapsed / steps
+    # Key order matters: the driver's record keeps the first ~24 scalars of `roofline` and of `config`.
+    # Naming rule: a fraction WITHOUT `algorithmic` in its name is computed from bytes that move and cannot exceed
+    # 6.29 / 8.0 = 0.79; `frac` / `achieved` (the contract's keys: SURVEY 8(d) algorithmic bytes of the dominant launch) obey
+    # it too because the dominant launch is a forward, whose algorithmic bytes are fewer than the bytes it moves.
     roofline = {
-        "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["algo_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": kernels[dom]["algo_GBps"] / HBM_PEAK_GBS, "traffic": None,
-        "moved_GBps": kernels[dom]["moved_GBps"], "moved_frac": kernels[dom]["moved_GBps"] / HBM_PEAK_GBS,
-        "frac_vs_measured_copy_bw_6290": kernels[dom]["algo_GBps"] / 6290.0,
-        "step_algo_GBps_kernels_alone": step_algo / (sum(k["mean_us"] for k in kernels.values()) * 1e-6) / 1e9,
-        "step_algo_GBps_as_timed": step_algo / step_s / 1e9,
-        "step_frac_as_timed": step_algo / step_s / 1e9 / HBM_PEAK_GBS,
-        # the same with the bytes that really move (the backward takes the forward's verified diagonal instead of P):
-        # the physical figure -- the algorithmic one can exceed 1
-        "step_moved_GBps_as_timed": step_moved / step_s / 1e9,
+        "bound": "hbm", "kernel": dom, "achieved": kernels[dom]["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": kernels[dom]["algorithmic_GBps"] / HBM_PEAK_GBS, "traffic": None,
+        "moved_frac": kernels[dom]["moved_GBps"] / HBM_PEAK_GBS,
+        # the whole step with the bytes that really move (the backward takes the forward's verified diagonal instead of P)
         "step_moved_frac": step_moved / step_s / 1e9 / HBM_PEAK_GBS,
-        "timing": "HIP events on the launch stream around a run of %d back-to-back launches of the kernel (mean)" % nrep,
-        # flat scalars: the driver's record keeps the scalar entries of `roofline` and `config`
+        "step_moved_GBps": step_moved / step_s / 1e9,
+        "moved_GBps": kernels[dom]["moved_GBps"],
+        "step_algorithmic_frac": step_algo / step_s / 1e9 / HBM_PEAK_GBS,
+        "step_algorithmic_GBps": step_algo / step_s / 1e9,
+        "step_algorithmic_GBps_kernels_alone": step_algo / (sum(k["mean_us"] for k in kernels.values()) * 1e-6) / 1e9,
+        "timing": "HIP events on the launch stream around a run of %d back-to-back C-ABI calls of the launch (mean)" % nrep,
         "host_enqueue_us_per_step": host_enqueue_us,
         "kernels_sum_us": sum(k["mean_us"] for k in kernels.values()),
     }
     for k, v in kernels.items():
         roofline["kernel_us_" + k] = v["mean_us"]
-    if drain_us:
-        for k, (without, with_drain) in drain_us.items():
-            roofline["b2b_us_" + k] = without
-            roofline["b2b_us_" + k + "_with_empty_drain"] = with_drain
     if region_fit:
         roofline.update(region_fit)
-    # HBM traffic and VALU instruction counts are PMC measurements of a separate rocprofv3 run (tools/profile.sh):
-    # quoted from the committed summary of the same workload, with its provenance, never measured by this run
-    tag = {0: "", 2: "_cfg2", 3: "_cfg3", 4: "_cfg4", 5: "_cfg5", 6: "_cfg6", 7: "_cfg7"}[cfg]
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest%s.json" % tag)
-    if os.path.exists(pmc_path):
+    # HBM traffic: measured by THIS run when it can (live_pmc: two rocprofv3 --pmc passes over a child process that issues
+    # this workload's launches); the VALU instruction counts and, as a fall-back, the traffic come from the committed
+    # summary of the same workload (tools/profile.sh), with their provenance
+    tag = {0: "", 2: "_cfg2", 3: "_cfg3", 4: "_cfg4", 5: "_cfg5", 6: "_cfg6", 7: "_cfg7", 8: "_cfg2", 9: None}[cfg]
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest%s.json" % tag) if tag is not None else None
+    if pmc_path and os.path.exists(pmc_path):
         try:
             allp = json.load(open(pmc_path))
             pmc = allp.get(dom, {})
+            src = "profiles/%s (rocprofv3 --pmc passes of tools/profile.sh, tag %s; not measured by this run)" % (
+                os.path.basename(pmc_path), allp.get("_tag", "?"))
             roofline["traffic"] = pmc.get("hbm_bytes_per_launch")
-            roofline["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tag %s; not " \
-                                         "measured by this run)" % (os.path.basename(pmc_path), allp.get("_tag", "?"))
+            roofline["traffic_source"] = src
             if "SQ_INSTS_VALU" in pmc:
                 floor_us = pmc["SQ_INSTS_VALU"] / 1024.0 * 2.08e-3
-                # the N = 8 forward kernels are bound by FP64 VALU issue, not by HBM (DESIGN.md 3.1): the binding
+                # the N = 8 forward kernels are bound by FP64 VALU issue, not by HBM (DESIGN.md): the binding
                 # roofline is reported next to the nominal one
                 roofline["fp64_valu_issue"] = {
                     "bound": "fp64_valu_issue", "valu_insts_per_launch": pmc["SQ_INSTS_VALU"],
                     "issue_floor_ns_per_wave_inst": 2.08, "floor_us": floor_us,
-                    "frac": floor_us / kernels[dom]["mean_us"], "source": roofline["traffic_source"]}
+                    "frac": floor_us / kernels[dom]["mean_us"], "source": src}
                 roofline["fp64_valu_issue_floor_us"] = floor_us
                 roofline["fp64_valu_issue_frac"] = floor_us / kernels[dom]["mean_us"]
                 if floor_us / kernels[dom]["mean_us"] > roofline["frac"]:
@@ -593,6 +662,18 @@ def measure(cfg, args, ctx, light=False):
                     roofline["pmc_" + k] = pmc[k]
         except Exception:
             pass
+    if ctx.get("live_pmc") and rank == 0 and world == 1 and not light:
+        live = live_pmc(cfg)
+        if live and dom in live:
+            roofline["traffic"] = live[dom]["hbm_bytes_per_launch"]
+            roofline["traffic_source"] = "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) spawned " \
+                                         "by this run over its own launches; HBM bytes = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB " \
+                                         "(MI355X_MICROARCH.md gfx950 correction), mean per launch"
+            roofline["traffic_kernels"] = live[dom]["kernels"]
+            roofline["traffic_over_algorithmic"] = live[dom]["hbm_bytes_per_launch"] / kernels[dom]["algorithmic_bytes_per_launch"]
+            roofline["live_pmc"] = live
+        elif live is not None:
+            roofline["live_pmc_error"] = live.get("_error", "dominant launch not found in the counter pass")
     if cfg == 5:
         # compute-bound: FP64 flops with the reference's cost profile: per problem 2N^2 per mat-vec
         # (iterations + 11 power-iteration products), 2.33 N^3 per factorisation + explicit inverse (3.5 per solve
@@ -655,7 +736,7 @@ def measure(cfg, args, ctx, light=False):
     out.update(extra)
     if not args.no_check:
         out["parity_max_abs_err_vs_oracle_sample"] = {c.names[0][:-4]: c.check(256 if c.N >= 32 else 2048) for c in chains}
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and cfg != 9:   # (cfg 9 is cfg 8's family at another batch size)
         from oracle import oracle as O
         cores = O.max_threads()
         n = min(cpu_n, chains[0].B)
@@ -672,10 +753,45 @@ def measure(cfg, args, ctx, light=False):
             "sample": "oracle/diffqcqp_oracle.c (dense C port of the reference algorithm, OpenMP over the batch), best of "
                       "2 passes over the first %d problems of each family of this workload" % n,
             "single_thread_value": one, "single_thread_sample": "same, 1 thread, first %d problems" % n1}
+        if not light:
+            out["cpu_baseline"].update(python_loop_baseline(chains))
         out["gpu_over_cpu_all_cores"] = out["value"] / tot
     del chains
     torch.cuda.empty_cache()
     return out
+
+
+def python_loop_baseline(chains, n=2048):
+    """The reference's EXECUTION MODEL: a Python `for i in range(B)` with one FFI call per problem --
+    qcqp.py:29-31 (solveQP per item) and :45-47 (solveDerivativesQP per item) --, here over the oracle's single-problem
+    functions (ctypes instead of pybind11), one thread, the first n problems of each family.  What the C port's
+    single-thread figure leaves out is exactly this interpreter + marshalling overhead per problem."""
+    from oracle import oracle as O
+    t_tot, n_tot = 0.0, 0
+    for c in chains:
+        h = c.host_sample(min(n, c.B))
+        m = h["q"].shape[0]
+        ws = np.zeros(c.N)
+        t0 = time.perf_counter()
+        if c.kind == "qp":
+            for i in range(m):
+                x = O.solveQP(h["P"][i], h["q"][i], ws, EPS, MU_PROX, MAX_ITER)
+                if c.backward:
+                    O.solveDerivativesQP(h["P"][i], h["q"][i], x, h["g"][i])
+        else:
+            for i in range(m):
+                x = O.solveQCQP(h["P"][i], h["q"][i], h["l_n"][i], h["mu"][i], ws, EPS, MU_PROX, MAX_ITER)
+                if c.backward:
+                    O.solveDerivativesQCQP(h["P"][i], h["q"][i], h["l_n"][i], h["mu"][i], x, h["g"][i])
+        t_tot += time.perf_counter() - t0
+        n_tot += m
+    return {"python_loop_value": n_tot / t_tot,
+            "python_loop_sample": "Python for-loop, one ctypes call per problem into the oracle's solveQP/solveQCQP + "
+                                  "solveDerivatives* (reference qcqp.py:29-31, 45-47, 149-151, 167-172), 1 thread, first %d "
+                                  "problems of each family" % min(n, chains[0].B),
+            "reference_published": "qcqp_runtime.png (README): QCQP N=8, B=1, ~9e-5 s forward / ~2.7e-4 s backward per "
+                                   "problem on the authors' CPU => ~1.1e4 forward/s, ~2.7e3 forward+backward solves/s per "
+                                   "core through the reference's Python path (other hardware; context only)"}
 
 
 def condensed(rec):
@@ -686,12 +802,16 @@ def condensed(rec):
            "ms_per_step_min_max": [rec["repeats"]["ms_per_step_min"], rec["repeats"]["ms_per_step_max"]],
            "dominant_kernel": rl["kernel"],
            "kernels_us": {k: round(v["mean_us"], 2) for k, v in rec["kernels"].items()},
+           # (GB/s, not fractions of the HBM peak: a 10 us backward whose 55 MB sit in the 256 MiB Infinity Cache from the
+           # forward before it reads above what HBM itself can deliver)
+           "kernels_moved_GBps": {k: round(v["moved_GBps"], 1) for k, v in rec["kernels"].items()},
            "host_enqueue_us_per_step": rl["host_enqueue_us_per_step"],
-           "roofline": {"bound": rl.get("binding", "hbm"), "hbm_frac": rl["frac"], "hbm_achieved_GBps": rl["achieved"],
-                        "moved_GBps": rl["moved_GBps"], "moved_frac": rl["moved_frac"],
-                        "step_hbm_frac_as_timed": rl["step_frac_as_timed"], "step_moved_frac": rl["step_moved_frac"],
-                        "traffic": rl.get("traffic")}}
-    for k in ("fp64_frac", "fp64_TFLOPs", "fp64_valu_issue_frac", "pmc_valu_lane_utilisation"):
+           "roofline": {"bound": rl.get("binding", "hbm"), "frac": rl["frac"], "achieved_GBps": rl["achieved"],
+                        "moved_frac": rl["moved_frac"], "moved_GBps": rl["moved_GBps"],
+                        "step_moved_frac": rl["step_moved_frac"], "step_moved_GBps": rl["step_moved_GBps"],
+                        "step_algorithmic_frac": rl["step_algorithmic_frac"],
+                        "traffic": rl.get("traffic"), "traffic_source": rl.get("traffic_source")}}
+    for k in ("fp64_frac", "fp64_TFLOPs", "fp64_valu_issue_frac", "pmc_valu_lane_utilisation", "traffic_over_algorithmic"):
         if k in rl:
             out["roofline"][k] = rl[k]
     for k in ("without_gather", "gather_after_backward", "parity_max_abs_err_vs_oracle_sample", "gpu_over_cpu_all_cores"):
@@ -703,16 +823,32 @@ def condensed(rec):
 
 
 def flat_summary(prefix, rec):
-    """Scalar entries for `config` (the driver's record keeps the scalars of `config` and `roofline`)."""
+    """Scalar entries for `config` / `roofline` (the driver's record keeps the first ~24 scalars of each): the step time
+    and the STEP's fraction of the HBM peak on the bytes that move (cfg 4: 0.70 -- the algorithmic 0.99 counts an 8 KiB
+    read of P per problem that the backward does not perform)."""
     rl = rec["roofline"]
-    out = {prefix + "_ms_per_step": rec["ms_per_step"], prefix + "_hbm_frac": rl["hbm_frac"],
-           prefix + "_moved_frac": rl["moved_frac"], prefix + "_step_moved_frac": rl["step_moved_frac"]}
-    for k, v in rec["kernels_us"].items():
-        out[prefix + "_us_" + k] = v
+    out = {prefix + "_ms_per_step": rec["ms_per_step"], prefix + "_moved_frac": rl["step_moved_frac"]}
     if "fp64_frac" in rl:
         out[prefix + "_fp64_frac"] = rl["fp64_frac"]
+    return out
+
+
+def flat_details(prefix, rec):
+    """The rest of a sub-record's scalars (behind the kept ones)."""
+    rl = rec["roofline"]
+    out = {prefix + "_dominant_launch_frac": rl["frac"], prefix + "_dominant_launch_moved_frac": rl["moved_frac"],
+           prefix + "_step_algorithmic_frac": rl["step_algorithmic_frac"]}
+    for k, v in rec["kernels_us"].items():
+        out[prefix + "_us_" + k] = v
     if "cpu_baseline" in rec:
         out[prefix + "_cpu_solves_per_s"] = rec["cpu_baseline"]["value"]
+    return out
+
+
+def reordered(d, first):
+    """d with the keys of `first` (those present) in front, in that order."""
+    out = {k: d[k] for k in first if k in d}
+    out.update({k: v for k, v in d.items() if k not in out})
     return out
 
 
@@ -817,7 +953,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, default=None, choices=(0, 2, 3, 4, 5, 6, 7),
+    ap.add_argument("--config", type=int, default=None, choices=(0, 2, 3, 4, 5, 6, 7, 8, 9),
                     help="BASELINE.json configs entry (1-based); 0 = the headline step (configs 2'+3).  Default: the "
                          "headline (distributed: on every rank, weak scaling; with_gather = with the RCCL all-gather of x) and "
                          "configs[3] (the batch split over the ranks) as the sub-record strong_config4")
@@ -828,7 +964,12 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-cold", action="store_true")
     ap.add_argument("--no-per-config", action="store_true", help="default run only: skip the per_config sub-records")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not spawn the two rocprofv3 counter passes that measure roofline.traffic (then quoted from profiles/)")
+    ap.add_argument("--pmc-child", type=int, default=None, help=argparse.SUPPRESS)   # the process live_pmc() profiles
     args = ap.parse_args()
+    if args.pmc_child is not None:
+        return pmc_child(args.pmc_child)
 
     # Everything the native libraries print on stdout (RCCL prints its version banner there) goes to
     # stderr; the one JSON line is written to the real stdout at the end.
@@ -867,7 +1008,9 @@ def main():
     from diffqcqp_amd import ops as _ops
     _ops.feedback_default()   # what ops.*_backward does on its first DQQ_P_AUTO call (the chains below call the C ABI directly)
     ctx = {"rank": rank, "world": world, "dev": dev, "use_dist": use_dist, "dist": dist, "parallel": parallel,
-           "capi": _capi, "side": torch.cuda.Stream()}
+           "capi": _capi, "side": torch.cuda.Stream(),
+           # the counter passes run for a plain one-GPU run of a whole workload (not for sub-records, not under RCCL)
+           "live_pmc": world == 1 and not use_dist and not args.no_live_pmc}
 
     default_run = args.config is None
     # No --config: the headline step, on one GPU and on N (round 4: ONE workload across the driver's N = 1, 2, 4, 8 lines, so
@@ -884,27 +1027,63 @@ def main():
                 out["strong_config4"]["note"] = "BASELINE configs[3]: B=262144 N=32 split over the ranks, all-gather of x " \
                                                 "behind the forward (strong scaling); N=1 reference: per_config.config_4 of a plain run"
                 out["config"].update(flat_summary("strong_cfg4", out["strong_config4"]))
+                out["config"].update(flat_details("strong_cfg4", out["strong_config4"]))
         elif not args.no_per_config:
-            per = {}
+            cfgk, rlk = {}, {}     # scalars for `config` / `roofline`, most important first (the driver keeps ~24 of each)
+            # north_star's target sentence, measured: N = 8 QP forward+backward as ONE step on one stream, at the bench
+            # batch and at the batch that fills the chip; fractions on the bytes that move (1538 B per pair)
+            pairs = {}
+            for name, cfg in (("qp_pair", 8), ("qp_pair_large", 9)):
+                rec = measure(cfg, args, ctx, light=True)
+                c = pairs[name] = condensed(rec)
+                rlk[name + "_ms_per_step"] = c["ms_per_step"]
+                rlk[name + "_solves_per_s"] = c["value"]
+                rlk[name + "_moved_frac"] = c["roofline"]["step_moved_frac"]
+                if name == "qp_pair":
+                    rlk[name + "_algorithmic_frac"] = c["roofline"]["step_algorithmic_frac"]
+                c["bytes_per_pair"] = {"moved": moved_bytes("qp", 8, "fwd", True) + moved_bytes("qp", 8, "bwd", True),
+                                       "algorithmic": algo_bytes("qp", 8, "fwd") + algo_bytes("qp", 8, "bwd")}
+            out["qp_pair"], out["qp_pair_large"] = pairs["qp_pair"], pairs["qp_pair_large"]
+            per, details = {}, {}
             for cfg in (2, 3, 4, 5):
                 per["config_%d" % cfg] = condensed(measure(cfg, args, ctx, light=True))
-                out["config"].update(flat_summary("cfg%d" % cfg, per["config_%d" % cfg]))
+                cfgk.update(flat_summary("cfg%d" % cfg, per["config_%d" % cfg]))
+                details.update(flat_details("cfg%d" % cfg, per["config_%d" % cfg]))
             out["per_config"] = per
             out["per_config_note"] = "BASELINE.json configs 2-5 (1-based) measured by THIS run, 3 regions each; config_4 " \
-                                     "is the whole B=262144 batch on this one GPU"
+                                     "is the whole B=262144 batch on this one GPU; cfgK_moved_frac = the STEP's bytes that " \
+                                     "move / step time / 8 TB/s"
             out["dense_p_n8"] = dense_p_record(args, ctx)
-            out["config"].update(flat_summary("dense8_auto", out["dense_p_n8"]["auto"]))
-            out["config"].update(flat_summary("dense8_dense", out["dense_p_n8"]["dense"]))
-            out["config"]["dense8_auto_over_dense"] = out["dense_p_n8"]["auto_over_dense"]
-            if "auto_no_hint_ms_per_fwd_bwd" in out["dense_p_n8"]:
-                out["config"]["dense8_auto_no_hint_ms_per_step"] = out["dense_p_n8"]["auto_no_hint_ms_per_fwd_bwd"]
+            d8 = out["dense_p_n8"]
+            cfgk["dense8_auto_ms_per_step"] = d8["auto"]["ms_per_step"]
+            if "auto_no_hint_ms_per_fwd_bwd" in d8:
+                cfgk["dense8_auto_no_hint_ms_per_step"] = d8["auto_no_hint_ms_per_fwd_bwd"]
+            cfgk["dense8_dense_ms_per_step"] = d8["dense"]["ms_per_step"]
+            cfgk["dense8_auto_over_dense"] = d8["auto_over_dense"]
+            if d8["auto"]["roofline"].get("traffic"):
+                cfgk["dense8_auto_traffic_over_algorithmic"] = d8["auto"]["roofline"]["traffic"] / (algo_bytes("qcqp", 8, "fwd") * 65536)
+            details.update(flat_details("dense8_auto", d8["auto"]))
+            details.update(flat_details("dense8_dense", d8["dense"]))
             out["survey_8d_extras"] = survey_extras_record(args, ctx)
             ex = out["survey_8d_extras"]
-            out["config"].update({"stress_p_u01_qp_fwd_ms": ex["stress_p_u(0,1)_qp_fwd"]["ms_per_call"],
-                                  "ref_figure_qp_fwd_ms": ex["reference_figure_workload"]["qp_fwd_ms"],
-                                  "ref_figure_qcqp_fwd_ms": ex["reference_figure_workload"]["qcqp_fwd_ms"],
-                                  "ref_figure_qp_fwd_ms_bench_eps": ex["reference_figure_workload"]["qp_fwd_ms_eps1e-7_maxiter1000"],
-                                  "ref_figure_qcqp_fwd_ms_bench_eps": ex["reference_figure_workload"]["qcqp_fwd_ms_eps1e-7_maxiter1000"]})
+            cfgk.update({"stress_p_u01_qp_fwd_ms": ex["stress_p_u(0,1)_qp_fwd"]["ms_per_call"],
+                         "ref_figure_qp_fwd_ms": ex["reference_figure_workload"]["qp_fwd_ms"],
+                         "ref_figure_qcqp_fwd_ms": ex["reference_figure_workload"]["qcqp_fwd_ms"]})
+            details.update({"ref_figure_qp_fwd_ms_bench_eps": ex["reference_figure_workload"]["qp_fwd_ms_eps1e-7_maxiter1000"],
+                            "ref_figure_qcqp_fwd_ms_bench_eps": ex["reference_figure_workload"]["qcqp_fwd_ms_eps1e-7_maxiter1000"]})
+            out["config"].update(cfgk)
+            out["config"].update(details)
+            out["roofline"].update(rlk)
+            out["config"] = reordered(out["config"], ["workload", "baseline_config", "B_total", "rccl_world"] + list(cfgk))
+    if rank == 0:
+        # the driver's record keeps the first ~24 scalars of `roofline`: the contract's seven, what binds the dominant
+        # kernel, the cold step, north_star's sentence (qp_pair*), the physical fractions, the four kernel durations
+        out["roofline"] = reordered(out["roofline"], [
+            "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "binding", "fp64_valu_issue_frac",
+            "pmc_valu_lane_utilisation", "cold_ms_per_step", "qp_pair_ms_per_step", "qp_pair_solves_per_s",
+            "qp_pair_moved_frac", "qp_pair_algorithmic_frac", "qp_pair_large_ms_per_step", "qp_pair_large_solves_per_s",
+            "qp_pair_large_moved_frac", "moved_frac", "step_moved_frac", "kernel_us_qp_fwd", "kernel_us_qp_bwd",
+            "kernel_us_qcqp_fwd", "kernel_us_qcqp_bwd", "traffic_over_algorithmic", "single_stream_ms_per_step"])
     if rank == 0:
         out["scaling_note"] = ("`value` = the headline step on every rank (weak scaling, no collective; with_gather = with the "
                                "all-gather of x); configs[3] split over the ranks (strong scaling) = strong_config4 (N>1) / "

@@ -10,9 +10,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*flags):
+def _run(*flags, live_pmc=False):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
-                        "--repeats", "2", "--no-cold", *flags], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--repeats", "2", "--no-cold", *(() if live_pmc else ("--no-live-pmc",)), *flags],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, "exactly one line on stdout"
@@ -52,13 +53,12 @@ def test_headline_line_names_host_enqueue_and_every_kernel_inside_the_driver_pre
     rl = d["roofline"]
     for k in ("host_enqueue_us_per_step", "single_stream_ms_per_step", "kernels_sum_us", "kernel_us_qp_fwd", "kernel_us_qp_bwd",
               "kernel_us_qcqp_fwd", "kernel_us_qcqp_bwd", "region_fixed_us", "us_per_step_steady_state",
-              "ms_per_step_long_region", "step_moved_frac", "moved_frac", "b2b_us_qcqp_bwd", "b2b_us_qcqp_bwd_with_empty_drain"):
+              "ms_per_step_long_region", "step_moved_frac", "moved_frac", "step_algorithmic_frac"):
         assert isinstance(rl.get(k), float), k
     # (sanity of the values only: a 3-step run on a shared box is no place for timing relations -- the process gets
     # descheduled for tens of milliseconds now and then, tools/probe_stall.py)
     assert 0 < rl["host_enqueue_us_per_step"] < 1e5
-    assert 0 < rl["step_moved_frac"] < 1 and 0 < rl["moved_frac"] < 1
-    assert rl["b2b_us_qcqp_bwd_with_empty_drain"] > 0 and rl["b2b_us_qcqp_bwd"] > 0
+    assert 0 < rl["step_moved_frac"] < 0.79 and 0 < rl["moved_frac"] < 0.79
 
 
 def test_rccl_branch_with_one_rank():
@@ -104,3 +104,52 @@ def test_distributed_default_line_is_the_headline_with_the_gather():
     s4 = d["strong_config4"]
     assert s4["without_gather"]["rccl_world"] == 1 and s4["gather_after_backward"]["ms_per_step"] > 0
     assert d["config"]["strong_cfg4_ms_per_step"] == s4["ms_per_step"]
+
+
+KEPT = 24   # scalars of `roofline` / `config` the driver's record keeps (BENCH_r04.json: 24 of each)
+
+
+def test_default_line_answers_the_north_star_sentence_inside_the_driver_kept_keys():
+    """VERDICT r4 #1, #5, #6, #13.  The full default line (what the driver runs): the first KEPT scalars of `roofline` carry
+    north_star's target sentence -- N = 8 QP forward+backward solves/s on one GPU with its HBM fraction, at B = 65536 and
+    at the chip-filling B = 1048576 -- plus what binds the dominant kernel and the cold step; the first KEPT scalars of
+    `config` carry every BASELINE config's step time and physical fraction and the dense 8 x 8 figures.  No fraction
+    without `algorithmic` in its name exceeds 6.29 / 8.0 (the measured copy rate over the spec peak); `traffic` was measured
+    by the run itself (two rocprofv3 counter passes over its own launches)."""
+    d = _run(live_pmc=True)
+    rl, cf = d["roofline"], d["config"]
+    scal = lambda m: [k for k, v in m.items() if not isinstance(v, (dict, list))]
+    first_rl, first_cf = scal(rl)[:KEPT], scal(cf)[:KEPT]
+    for k in ("frac", "traffic", "binding", "fp64_valu_issue_frac", "pmc_valu_lane_utilisation", "qp_pair_ms_per_step",
+              "qp_pair_solves_per_s", "qp_pair_moved_frac", "qp_pair_algorithmic_frac", "qp_pair_large_ms_per_step",
+              "qp_pair_large_moved_frac", "moved_frac", "step_moved_frac", "kernel_us_qcqp_fwd"):
+        assert k in first_rl, (k, first_rl)
+    for k in ("cfg2_ms_per_step", "cfg2_moved_frac", "cfg3_ms_per_step", "cfg3_moved_frac", "cfg4_ms_per_step",
+              "cfg4_moved_frac", "cfg5_ms_per_step", "cfg5_moved_frac", "dense8_auto_ms_per_step",
+              "dense8_auto_no_hint_ms_per_step", "dense8_dense_ms_per_step"):
+        assert k in first_cf, (k, first_cf)
+    assert not any(k.startswith("b2b_") or "6290" in k for k in rl)
+    # the sentence itself: >= 1e6 N = 8 QP fwd+bwd solves/s (by three orders of magnitude), with a physical HBM fraction
+    assert rl["qp_pair_solves_per_s"] > 1e8 and rl["qp_pair_large_solves_per_s"] > 1e8
+    assert abs(rl["qp_pair_solves_per_s"] - 65536 / (rl["qp_pair_ms_per_step"] * 1e-3)) < 1e-6 * rl["qp_pair_solves_per_s"]
+    assert abs(rl["qp_pair_moved_frac"] - 1538 * 65536 / (rl["qp_pair_ms_per_step"] * 1e-3) / 8e12) < 1e-9
+    assert abs(rl["qp_pair_algorithmic_frac"] / rl["qp_pair_moved_frac"] - 1920 / 1538) < 1e-9
+    assert d["qp_pair"]["bytes_per_pair"] == {"moved": 1538, "algorithmic": 1920}
+    # physical bound on everything that does not say `algorithmic`
+    def walk(m, path=""):
+        for k, v in m.items():
+            if isinstance(v, dict):
+                yield from walk(v, path + k + ".")
+            elif isinstance(v, float) and "frac" in k and "algorithmic" not in k and "fp64" not in k and "valu" not in k \
+                    and "flip" not in k and "SQ_" not in k:
+                yield path + k, v
+    over = [(k, v) for k, v in walk(d) if v > 0.79]
+    assert not over, over
+    assert 0.3 < cf["cfg4_moved_frac"] < 0.79
+    # traffic: measured by this run
+    assert "live" in rl["traffic_source"] and rl["traffic"] > 0.5 * 704 * 65536, rl.get("traffic_source")
+    assert 0.8 < rl["traffic_over_algorithmic"] < 2.0
+    # the reference's execution model beside the C port
+    cb = d["cpu_baseline"]
+    assert cb["python_loop_value"] > 0 and cb["python_loop_value"] < cb["single_thread_value"] * 1.5
+    assert "qcqp.py:29-31" in cb["python_loop_sample"] and "1.1e4" in cb["reference_published"]
