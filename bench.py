@@ -332,13 +332,17 @@ def live_pmc(cfg, timeout=240):
         key, short = _pmc_bench_key(name)
         if key is None or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
             continue
-        e = res.setdefault(key, {"hbm_bytes_per_launch": 0.0, "hbm_read_bytes_per_launch": 0.0,
-                                 "hbm_write_bytes_per_launch": 0.0, "kernels": [], "dispatches_sampled": 0})
-        e["hbm_read_bytes_per_launch"] += 2.0 * v["FETCH_SIZE"][0] * 1024
-        e["hbm_write_bytes_per_launch"] += v["WRITE_SIZE"][0] * 1024
-        e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
+        # bytes per launch (one C-ABI call = the kernels it enqueues): dispatch-weighted sum over the kernels that served
+        # this launch name / the dispatches of the most frequent one (a route taken once does not count as if always taken)
+        e = res.setdefault(key, {"rd": 0.0, "wr": 0.0, "kernels": [], "dispatches_sampled": 0})
+        n = int(v["FETCH_SIZE"][1])
+        e["rd"] += 2.0 * v["FETCH_SIZE"][0] * 1024 * n
+        e["wr"] += v["WRITE_SIZE"][0] * 1024 * int(v["WRITE_SIZE"][1])
         e["kernels"].append(short)
-        e["dispatches_sampled"] = max(e["dispatches_sampled"], int(v["FETCH_SIZE"][1]))
+        e["dispatches_sampled"] = max(e["dispatches_sampled"], n)
+    for e in res.values():
+        rd, wr = e.pop("rd") / e["dispatches_sampled"], e.pop("wr") / e["dispatches_sampled"]
+        e.update({"hbm_bytes_per_launch": rd + wr, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr})
     return res
 
 
@@ -869,7 +873,7 @@ def dense_p_record(args, ctx):
         try:
             rec["auto_no_hint_ms_per_fwd_bwd"] = measure(6, args, ctx, light=True)["ms_per_step"]
         finally:
-            capi.enable_feedback(True)   # (a fresh, zeroed buffer: the sub-records after this one start without a hint, like a new caller)
+            capi.enable_feedback(True)   # (the same buffer, its words as they were: _capi.enable_feedback)
     return rec
 
 

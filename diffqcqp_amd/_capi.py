@@ -20,6 +20,7 @@ LIB_PATH = os.environ.get("DQQ_LIB") or os.path.join(_HERE, "lib", "libdiffqcqp_
 PYMOD_PATH = os.path.join(_HERE, "lib", "_dqq.so")
 
 P_AUTO, P_DENSE, P_DIAG = 0, 1, 2
+F_REFERENCE_ORDER = 0x100   # DQQ_F_REFERENCE_ORDER: ORed into p_layout (16 < N <= 64 on the reference-order kernels)
 
 _ERRORS = {
     -1: "DQQ_E_NULLPTR: a required pointer is NULL",
@@ -36,8 +37,10 @@ _vp, _i, _d, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.
 # name -> argtypes, in the order of include/diffqcqp_hip.h
 SIGNATURES = {
     "dqq_workspace_bytes": ([_i64], _sz),
-    "dqq_scratch_bytes": ([_i, _i, _i, _i64], _sz),
-    "dqq_max_n": ([_i], _i),
+    "dqq_scratch_bytes": ([_i, _i, _i, _i64, _i], _sz),
+    "dqq_max_n": ([_i, _i], _i),
+    "dqq_workspace_reset": ([_vp, _sz, _vp], _i),
+    "dqq_workspace_status": ([_vp, _sz, _vp, ctypes.POINTER(_i)], _i),
     "dqq_qp_fwd_f64": ([_vp, _vp, _vp, _i64, _i, _d, _d, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp], _i),
     "dqq_qp_bwd_f64": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp], _i),
     "dqq_qcqp_fwd_f64": ([_vp, _vp, _vp, _vp, _vp, _i64, _i, _d, _d, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp], _i),
@@ -114,11 +117,35 @@ def check(rc, what):
 
 
 def set_option(name, value):
+    """Shipped library: the three route counters only ("lane_list_drains", "bwd_whole_batches", "fwd_feedback_routes"; 0
+    resets).  A developer build (-DDQQ_TUNING, see tuning_build()) also takes the kernel-selection knobs of csrc/tuning.h."""
     check(lib().dqq_set_option(name.encode(), int(value)), "dqq_set_option(%s)" % name)
-    import sys
-    ops = sys.modules.get(__package__ + ".ops")
-    if ops is not None:
-        ops._need_cache.clear()   # dqq_scratch_bytes follows the knobs (include/diffqcqp_hip.h)
+
+
+def tuning_build():
+    """Is the loaded library a developer build with run-time tuning knobs (DQQ_EXTRA_FLAGS=-DDQQ_TUNING)?"""
+    if binding() == "pybind11":
+        return lib().dqq_get_option(b"fwd_lpp")[0] == 0
+    v = _i(0)
+    return lib().dqq_get_option(b"fwd_lpp", ctypes.byref(v)) == 0
+
+
+def workspace_reset(ws, stream=0):
+    """dqq_workspace_reset: zero-fill the work-list header of `ws` on `stream` (asynchronous)."""
+    check(lib().dqq_workspace_reset(ws.data_ptr(), ws.numel() * ws.element_size(), stream or None), "dqq_workspace_reset")
+
+
+def workspace_status(ws, stream=0):
+    """dqq_workspace_status: True if a kernel has found this workspace's work-list header inconsistent since its last
+    reset.  Synchronises the stream."""
+    if binding() == "pybind11":
+        rc, dirty = lib().dqq_workspace_status(ws.data_ptr(), ws.numel() * ws.element_size(), stream or None)
+    else:
+        v = _i(0)
+        rc = lib().dqq_workspace_status(ws.data_ptr(), ws.numel() * ws.element_size(), stream or None, ctypes.byref(v))
+        dirty = v.value
+    check(rc, "dqq_workspace_status")
+    return bool(dirty)
 
 
 def get_option(name):
@@ -132,22 +159,31 @@ def get_option(name):
 
 
 FEEDBACK_BYTES = 128   # DQQ_FEEDBACK_BYTES
-_feedback = None       # the registered buffer (a pinned tensor): alive as long as the library may write to it
+_feedback = None       # the buffer while it is REGISTERED with the library (None: not registered)
+_feedback_buf = None   # the pinned tensor itself: allocated once, never freed (see enable_feedback)
 
 
 def enable_feedback(on=True):
-    """Register (or drop) the feedback buffer of include/diffqcqp_hip.h dqq_set_feedback: 128 bytes of pinned host memory
-    through which the drain launch of the N <= 8 backward tells the next call how many non-diagonal problems it found.
-    A timing hint only -- results are the same bits with and without.  Needs a GPU (pinned memory)."""
-    global _feedback
+    """Register (or unregister) the feedback buffer of include/diffqcqp_hip.h dqq_set_feedback: 128 bytes of pinned host
+    memory through which the drain launch of the N <= 8 backward tells the next call how many non-diagonal problems it found.
+    A timing hint only -- results are the same bits with and without.  Needs a GPU (pinned memory).
+
+    The pinned buffer lives as long as the process: drain kernels still in flight, and launches captured into a
+    HIP graph while it was registered, hold its device address and may store into it at any later time -- memory handed back
+    to torch's pinned allocator could by then belong to someone else.  Unregistering only makes the library stop passing the
+    address to NEW launches and stop reading the words; registering again hands the library the same buffer with its words
+    as they are (consistent with the per-workspace record of what was last sent, csrc/launch.h: a zeroed buffer at the same
+    address would never be written again for an unchanged count)."""
+    global _feedback, _feedback_buf
     if not on:
         check(lib().dqq_set_feedback(None, 0), "dqq_set_feedback(NULL)")
         _feedback = None
         return
     if _feedback is None:
-        buf = torch.zeros(FEEDBACK_BYTES // 8, dtype=torch.int64).pin_memory()
-        check(lib().dqq_set_feedback(buf.data_ptr(), FEEDBACK_BYTES), "dqq_set_feedback")
-        _feedback = buf
+        if _feedback_buf is None:
+            _feedback_buf = torch.zeros(FEEDBACK_BYTES // 8, dtype=torch.int64).pin_memory()
+        check(lib().dqq_set_feedback(_feedback_buf.data_ptr(), FEEDBACK_BYTES), "dqq_set_feedback")
+        _feedback = _feedback_buf
 
 
 def feedback_words():

@@ -95,9 +95,9 @@ def _pybind_stale():
     return True
 
 
-def _compile(unit, flags, objdir, verbose):
+def _compile(unit, flags, objdir, verbose, more=()):
     obj = os.path.join(objdir, unit.replace(".hip", ".o"))
-    extra = os.environ.get("DQQ_EXTRA_FLAGS", "").split()  # developer experiments (-D...)
+    extra = os.environ.get("DQQ_EXTRA_FLAGS", "").split() + list(more)  # developer experiments (-D...)
     cmd = [_hipcc()] + COMMON + flags + extra + ["-I", INCLUDE, "-c", os.path.join(CSRC, unit), "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -114,6 +114,9 @@ def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
+    for stale in os.listdir(objdir):   # objects of units that no longer exist must never be linked
+        if stale.endswith(".o") and stale[:-2] + ".hip" not in UNITS:
+            os.remove(os.path.join(objdir, stale))
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(lambda kv: _compile(kv[0], kv[1], objdir, verbose), UNITS.items()))
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
@@ -160,5 +163,30 @@ def _build_pybind(verbose=False):
     return "pybind11: ok"
 
 
+TUNING_LIB = os.path.join(LIBDIR, "tuning", "libdiffqcqp_hip.so")
+
+
+def build_tuning(force=False, verbose=False):
+    """The DEVELOPER build of the same library (-DDQQ_TUNING, csrc/tuning.h: the kernel-selection knobs as run-time options
+    behind dqq_set_option) into lib/tuning/ -- never loaded by default: `DQQ_LIB=<path> python ...` selects it (bound with
+    ctypes, diffqcqp_amd/_capi.py).  For A/B sweeps (tools/) and for the tests that drive the alternative kernels."""
+    if not force and os.path.exists(TUNING_LIB):
+        t = os.path.getmtime(TUNING_LIB)
+        if not any(os.path.getmtime(p) > t for p in _sources() + [os.path.abspath(__file__)]):
+            return TUNING_LIB
+    objdir = os.path.join(LIBDIR, "tuning", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(lambda kv: _compile(kv[0], kv[1], objdir, verbose, more=("-DDQQ_TUNING",)), UNITS.items()))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", TUNING_LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return TUNING_LIB
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--tuning" in sys.argv:
+        print(build_tuning(force="--force" in sys.argv, verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

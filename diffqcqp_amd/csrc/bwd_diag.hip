@@ -26,6 +26,25 @@
 
 namespace dqq {
 
+// A problem that could not be queued for the general kernel (launch.h, work-list hygiene: a header that did not start at
+// zero): it will not be solved by this call -- its gradients say so.  Lane j of the problem's N/2 lanes.
+template <int KIND, int N>
+static DQQ_D void poison_problem_grads(double* __restrict__ grad_P, double* __restrict__ grad_q, double* __restrict__ g0,
+                                       double* __restrict__ g1, long prob, int j)
+{
+    const double nan = __builtin_nan("");
+    if (grad_q != nullptr) { grad_q[prob * N + 2 * j] = nan; grad_q[prob * N + 2 * j + 1] = nan; }
+    if (grad_P != nullptr)
+        for (int c = 0; c < 2 * N; ++c) grad_P[prob * (long)(N * N) + 2 * j * N + c] = nan;   // this lane's two rows
+    if (KIND == 1) {
+        if (g0 != nullptr) g0[prob * (N / 2) + j] = nan;
+        if (g1 != nullptr) g1[prob * (N / 2) + j] = nan;
+    } else if (KIND == 2) {
+        if (g0 != nullptr) { g0[prob * N + 2 * j] = nan; g0[prob * N + 2 * j + 1] = nan; }
+        if (g1 != nullptr) { g1[prob * N + 2 * j] = nan; g1[prob * N + 2 * j + 1] = nan; }
+    }
+}
+
 template <int KIND, int N, int WPB, bool FUSE>
 __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : (KIND == 1 ? 4 : 2)) : 1)) void bwd_diag_kernel(
     const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ l_n,
@@ -53,6 +72,9 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : (KIND == 1 ? 4 :
     const long tile = (long)blockIdx.x * WPB + wave;
     const long first = tile * T;
     if (first >= B) return; // whole wave leaves; no workgroup barrier is used below
+    if constexpr (!FUSE) {   // this launch may fill the work-list: the words only its drain writes start from zero (launch.h)
+        if (tile == 0 && ws != nullptr && layout == DQQ_P_AUTO) worklist_prepare(ws, threadIdx.x & 63);
+    }
     const int nvalid = (B - first) < T ? (int)(B - first) : T;
     const int pl = lane / HL, j = lane % HL;
     bool valid = pl < nvalid;   // (narrowed below to the problems this kernel solves itself)
@@ -108,13 +130,17 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : (KIND == 1 ? 4 :
             if (by_problem) {
                 const bool queued = f == 2 && j == 0;                          // one lane per queued problem
                 const unsigned long long qm = __ballot(queued);
-                worklist_push_entries<AGG, worklist_segmented(N)>(ws, B, __popcll(qm), queued,
-                                                                  __popcll(qm & ((1ull << lane) - 1)), (int)(first + pl), lane, s_cnt);
+                const bool ok = worklist_push_entries<AGG, worklist_segmented(N)>(ws, B, __popcll(qm), queued,
+                                                                                  __popcll(qm & ((1ull << lane) - 1)), (int)(first + pl), lane, s_cnt);
                 if (lane == 0 && qm != 0) ws[kWsPerProblem] = 1;   // (launch.h: how the drain's report is to be read)
+                if (!ok && valid && f == 2) poison_problem_grads<KIND, N>(grad_P, grad_q, grad_l_n, grad_mu, first + pl, j);
                 valid = valid && f == 1;
             } else {
-                worklist_push<AGG, worklist_segmented(N)>(ws, B, first, tile_dense ? nvalid : 0, lane, s_cnt);
-                if (tile_dense) return;
+                const bool ok = worklist_push<AGG, worklist_segmented(N)>(ws, B, first, tile_dense ? nvalid : 0, lane, s_cnt);
+                if (tile_dense) {
+                    if (!ok && valid) poison_problem_grads<KIND, N>(grad_P, grad_q, grad_l_n, grad_mu, first + pl, j);
+                    return;
+                }
             }
         }
         if (!have_diag && !by_problem) {

@@ -537,7 +537,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 
     using S = LaneSys<KIND, N>;
     constexpr int M = S::M, NC = S::NC;
     constexpr bool LIST = MODE == 1, REPORT = MODE == 2;
-    const long total = LIST ? (long)ws[kWsCount] : B;   // problems of this launch
+    const long total = LIST ? worklist_checked_count(ws, ws + kWsCount, kWsEntryInts(B)) : B;   // problems of this launch
     if constexpr (LIST) {
         if (blockIdx.x == 0 && threadIdx.x == 0) worklist_feedback(feedback, ws, B, total);
         if ((long)blockIdx.x * 64 >= total) return;      // (an empty list: every wave, before anything else)
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 
     const long slot = (long)blockIdx.x * 64 + threadIdx.x;
     const bool valid = slot < total;
     // lanes past the end redo the last problem and store nothing
-    const long prob = LIST ? (long)ws[kWsEntries + (valid ? slot : total - 1)] : (valid ? slot : total - 1);
+    const long prob = LIST ? worklist_checked_entry(ws, ws[kWsEntries + (valid ? slot : total - 1)], B) : (valid ? slot : total - 1);
     [[maybe_unused]] const int prob32 = (int)prob;
 
     // ---- load.  A lane's matrix is N*N contiguous doubles, N*N*8 bytes from its neighbour's: read lane by lane, every

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256, (SmallSys<KIND, N>::M > 16 ? 1 : 2)) void bwd_
     // An empty work-list -- what this launch finds behind every backward of a diagonal batch -- leaves on ONE scalar load, before
     // anything else: with the exit below the lane / team arithmetic the compiler had put a register spill (a scratch store by each
     // of the 4096 waves) in front of it, and the headline step paid 4.5 us for it (round 4, A/B of the builds).
-    const long count = use_worklist ? (long)ws[kWsCount] : B;
+    const long count = use_worklist ? worklist_checked_count(ws, ws + kWsCount, kWsEntryInts(B)) : B;
     if (count == 0) return;
     asm volatile("" ::: "memory");
     // launch.h: a hint for the next call -- how long the list was.  Only BEHIND the exit above: with the report in front of it
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256, (SmallSys<KIND, N>::M > 16 ? 1 : 2)) void bwd_
     double* sw = smem + (wave * TP + team) * S::LDS_DOUBLES;
     const long nteams = (long)gridDim.x * wpb * TP;
     for (long w = ((long)blockIdx.x * wpb + wave) * TP + team; w < count; w += nteams) {
-        const long prob = use_worklist ? (long)ws[kWsEntries + w] : w;
+        const long prob = use_worklist ? worklist_checked_entry(ws, ws[kWsEntries + w], B) : w;
         small_bwd_problem<KIND, N>(P, q, aux0, aux1, x, grad_x, grad_P, grad_q, gout0, gout1, gamma_out, dgamma_out,
                                    ir_steps, prob, dual_eps, sw, tl);
     }

@@ -7,59 +7,49 @@
 #include "launch.h"
 
 namespace dqq {
-extern std::atomic<int> g_fwd_compact;
-extern std::atomic<int> g_fwd_respread;
-extern std::atomic<int> g_fwd_respread2;
-extern std::atomic<int> g_dense_wave64;
-extern std::atomic<int> g_lane_dense;
-extern std::atomic<int> g_lane_defer;
-extern std::atomic<int> g_dense_teams;
-extern std::atomic<int> g_small_bwd;
-extern std::atomic<int> g_lane_bwd;
-extern std::atomic<int> g_lane_list_drains;
-extern std::atomic<int> g_bwd_skip_classify;
-extern std::atomic<int> g_bwd_whole_batches;
-extern std::atomic<int> g_fwd_feedback;
-extern std::atomic<int> g_fwd_feedback_routes;
-extern std::atomic<int> g_small_fwd;
-extern std::atomic<int> g_wave_qcqp_bwd;
+#if defined(DQQ_TUNING)
+// developer build: the knobs of tuning.h as process-wide atomics (defined here, declared there)
+#define DQQ_KNOB_DEF(name, dflt) std::atomic<int> g_##name{dflt};
+DQQ_KNOB_DEF(fwd_lpp, 0) DQQ_KNOB_DEF(wpb, 0) DQQ_KNOB_DEF(fuse_fallback, -1) DQQ_KNOB_DEF(fwd_compact, 0)
+DQQ_KNOB_DEF(fwd_respread, 16) DQQ_KNOB_DEF(fwd_respread2, 8) DQQ_KNOB_DEF(lane_dense, 1) DQQ_KNOB_DEF(lane_defer, 0)
+DQQ_KNOB_DEF(dense_teams, 1) DQQ_KNOB_DEF(small_fwd, 1) DQQ_KNOB_DEF(small_bwd, 1) DQQ_KNOB_DEF(lane_bwd, 1)
+DQQ_KNOB_DEF(fwd_feedback, 1) DQQ_KNOB_DEF(bwd_skip_classify, 1)
+#undef DQQ_KNOB_DEF
+#endif
 }
 
 namespace {
-
-std::atomic<int> g_fwd_lpp{0};      // 0 = built-in choice
-std::atomic<int> g_wpb{0};          // 0 = built-in choice
-std::atomic<int> g_auto_fallback{1}; // 0 = skip the dense fallback launch of DQQ_P_AUTO (measurement only)
-std::atomic<int> g_fuse{-1};         // in-kernel dense fallback of the fast paths: -1 built-in, 0 off, 1 on
 
 struct Option {
     const char* name;
     std::atomic<int>* slot;
 };
-Option g_options[] = {{"fwd_lpp", &g_fwd_lpp}, {"wpb", &g_wpb}, {"auto_fallback", &g_auto_fallback},
-                      {"fuse_fallback", &g_fuse},
-                      {"fwd_compact", &dqq::g_fwd_compact},
-                      {"fwd_respread", &dqq::g_fwd_respread},
-                      {"fwd_respread2", &dqq::g_fwd_respread2},
-                      {"dense_wave64", &dqq::g_dense_wave64},
-                      {"lane_dense", &dqq::g_lane_dense},
-                      {"lane_defer", &dqq::g_lane_defer},
-                      {"dense_teams", &dqq::g_dense_teams},
-                      {"small_bwd", &dqq::g_small_bwd},
-                      {"lane_bwd", &dqq::g_lane_bwd},
-                      {"lane_list_drains", &dqq::g_lane_list_drains},
-                      {"bwd_skip_classify", &dqq::g_bwd_skip_classify},
+// What dqq_set_option / dqq_get_option know.  Shipped build: the three route counters (diagnostics; "set" resets them) and
+// nothing else -- no name here changes what a call does.  Developer build (-DDQQ_TUNING): also the knobs of tuning.h.
+Option g_options[] = {{"lane_list_drains", &dqq::g_lane_list_drains},
                       {"bwd_whole_batches", &dqq::g_bwd_whole_batches},
-                      {"fwd_feedback", &dqq::g_fwd_feedback},
                       {"fwd_feedback_routes", &dqq::g_fwd_feedback_routes},
-                      {"small_fwd", &dqq::g_small_fwd},
-                      {"wave_qcqp_bwd", &dqq::g_wave_qcqp_bwd}};
+#if defined(DQQ_TUNING)
+#define DQQ_KNOB_OPT(name) {#name, &dqq::g_##name},
+                      DQQ_KNOB_OPT(fwd_lpp) DQQ_KNOB_OPT(wpb) DQQ_KNOB_OPT(fuse_fallback) DQQ_KNOB_OPT(fwd_compact)
+                      DQQ_KNOB_OPT(fwd_respread) DQQ_KNOB_OPT(fwd_respread2) DQQ_KNOB_OPT(lane_dense) DQQ_KNOB_OPT(lane_defer)
+                      DQQ_KNOB_OPT(dense_teams) DQQ_KNOB_OPT(small_fwd) DQQ_KNOB_OPT(small_bwd) DQQ_KNOB_OPT(lane_bwd)
+                      DQQ_KNOB_OPT(fwd_feedback) DQQ_KNOB_OPT(bwd_skip_classify)
+#undef DQQ_KNOB_OPT
+#endif
+};
+
+// p_layout as passed = layout | flags
+int layout_of(int p_layout) { return p_layout & 0xff; }
+bool ref_order_of(int p_layout) { return (p_layout & DQQ_F_REFERENCE_ORDER) != 0; }
 
 int check_common(int64_t B, int N, int p_layout, bool qcqp)
 {
     if (B < 0 || N < 1 || B > 0x7fffffffLL) return DQQ_E_BAD_SIZE;
     if (qcqp && (N % 2) != 0) return DQQ_E_BAD_SIZE;
-    if (p_layout != DQQ_P_AUTO && p_layout != DQQ_P_DENSE && p_layout != DQQ_P_DIAG) return DQQ_E_BAD_LAYOUT;
+    const int layout = layout_of(p_layout);
+    if ((p_layout & ~(0xff | DQQ_F_REFERENCE_ORDER)) != 0) return DQQ_E_BAD_LAYOUT;   // unknown flag bits
+    if (layout != DQQ_P_AUTO && layout != DQQ_P_DENSE && layout != DQQ_P_DIAG) return DQQ_E_BAD_LAYOUT;
     return 0;
 }
 
@@ -95,15 +85,36 @@ size_t dqq_workspace_bytes(int64_t B)
     return n * sizeof(int);
 }
 
-size_t dqq_scratch_bytes(int kind, int pass, int N, int64_t B)
+size_t dqq_scratch_bytes(int kind, int pass, int N, int64_t B, int p_layout)
 {
     if (B <= 0 || N < 1 || kind < 0 || kind > 3 || (pass != 0 && pass != 1)) return 0;
     if (pass == 0) return dqq::fwd_needs_any(kind, N) ? dqq::any_scratch_bytes(kind, false, N, (long)B) : 0;
     if (kind == dqq::kKindSignedBox) return 0; // no backward
-    return dqq::bwd_needs_any(kind, N) ? dqq::any_scratch_bytes(kind, true, N, (long)B) : 0;
+    return dqq::bwd_needs_any(kind, N, ref_order_of(p_layout)) ? dqq::any_scratch_bytes(kind, true, N, (long)B) : 0;
 }
 
-int dqq_max_n(int kind) { return dqq::public_max_n(kind); }
+int dqq_workspace_reset(void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (workspace == nullptr) return DQQ_E_NULLPTR;
+    const size_t head = sizeof(int) * (size_t)dqq::kWsEntries;
+    if (workspace_bytes < head) return DQQ_E_WORKSPACE;
+    return (int)hipMemsetAsync(workspace, 0, head, static_cast<hipStream_t>(stream));
+}
+
+int dqq_workspace_status(const void* workspace, size_t workspace_bytes, void* stream, int* dirty)
+{
+    if (workspace == nullptr || dirty == nullptr) return DQQ_E_NULLPTR;
+    if (workspace_bytes < sizeof(int) * (size_t)dqq::kWsEntries) return DQQ_E_WORKSPACE;
+    int word = 0;
+    hipError_t e = hipMemcpyAsync(&word, static_cast<const int*>(workspace) + dqq::kWsDirty, sizeof(int),
+                                  hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return (int)e;
+    *dirty = word != 0 ? 1 : 0;
+    return 0;
+}
+
+int dqq_max_n(int kind, int p_layout) { return dqq::public_max_n(kind, ref_order_of(p_layout)); }
 
 const char* dqq_version(void) { return "diffqcqp_hip 0.1.0 gfx950"; }
 
@@ -140,10 +151,10 @@ int dqq_get_option(const char* name, int* value)
     return DQQ_E_BAD_OPTION;
 }
 
-// Routing is a function of (kind, N, B, p_layout) and the process-wide tuning knobs only: two calls with the same
-// arguments launch the same kernels, whatever ran before them, on whatever thread or stream.  (One exception, opt-in:
-// with a feedback buffer registered the drain launch of the N <= 8 backward is picked between two kernels of identical
-// results by what the last such launch found, launch.h.)
+// Routing is a function of (kind, N, B, p_layout) only: two calls with the same arguments launch the same kernels, whatever
+// ran before them, on whatever thread or stream.  (One exception, opt-in: with a feedback buffer registered -- dqq_set_feedback
+// -- an N <= 8 DQQ_P_AUTO call is routed between kernels of IDENTICAL results by what the last backward of its kind found,
+// launch.h.  The developer build, -DDQQ_TUNING, adds the knobs of tuning.h.)
 static int fwd_dispatch(int kind, dqq::FwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t s)
 {
     if (a.B == 0) return 0;
@@ -151,13 +162,13 @@ static int fwd_dispatch(int kind, dqq::FwdArgs& a, void* workspace, size_t works
     const bool dense_ok = dqq::fwd_dense_supported(kind, a.N);
     if (a.layout == DQQ_P_DIAG) {
         if (!fast_ok) return DQQ_E_UNSUPPORTED_N;
-        return (int)dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), g_fuse.load(), s, nullptr);
+        return (int)dqq::launch_fwd_diag(kind, a, dqq::knob_fwd_lpp(), dqq::knob_wpb(), dqq::knob_fuse_fallback(), s, nullptr);
     }
-    const size_t scratch = dqq_scratch_bytes(kind, 0, a.N, a.B); // > 0: the global-memory kernels take the call
+    const size_t scratch = dqq_scratch_bytes(kind, 0, a.N, a.B, a.layout); // > 0: the global-memory kernels take the call
     if (a.layout == DQQ_P_DENSE || !fast_ok) {
-        if (a.layout == DQQ_P_DENSE && fast_ok && dqq::g_lane_dense.load() != 0 && g_fuse.load() != 0 &&
+        if (a.layout == DQQ_P_DENSE && fast_ok && dqq::knob_lane_dense() != 0 && dqq::knob_fuse_fallback() != 0 &&
             dqq::fwd_diag_takes_dense(kind, a.N, a.B))
-            return (int)dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), 1, s, nullptr);
+            return (int)dqq::launch_fwd_diag(kind, a, dqq::knob_fwd_lpp(), dqq::knob_wpb(), 1, s, nullptr);
         if (!dense_ok) return DQQ_E_UNSUPPORTED_N;
         if (scratch > 0) {
             if (int rc = check_ws(workspace, workspace_bytes, a.B, scratch)) return rc;
@@ -170,12 +181,12 @@ static int fwd_dispatch(int kind, dqq::FwdArgs& a, void* workspace, size_t works
     if (int rc = check_ws(workspace, workspace_bytes, a.B, scratch)) return rc;
     a.ws = static_cast<int*>(workspace);
     if (scratch > 0) a.scratch = scratch_of(workspace, a.B);
-    const bool fused = dqq::fwd_diag_will_fuse(a.N, a.B, a.layout, g_fuse.load());
+    const bool fused = dqq::fwd_diag_will_fuse(a.N, a.B, a.layout, dqq::knob_fuse_fallback());
     if (!fused && !dense_ok) return DQQ_E_UNSUPPORTED_N; // a queued tile would never be solved: refuse up front
     bool needs_fallback = true;
-    hipError_t e = dqq::launch_fwd_diag(kind, a, g_fwd_lpp.load(), g_wpb.load(), g_fuse.load(), s, &needs_fallback);
+    hipError_t e = dqq::launch_fwd_diag(kind, a, dqq::knob_fwd_lpp(), dqq::knob_wpb(), dqq::knob_fuse_fallback(), s, &needs_fallback);
     if (e != hipSuccess) return (int)e;
-    if (needs_fallback && g_auto_fallback.load() != 0) {
+    if (needs_fallback) {
         e = dqq::launch_fwd_dense(kind, a, true, s);
         if (e != hipSuccess) reset_worklist(workspace, s);
     }
@@ -189,9 +200,9 @@ static int bwd_dispatch(int kind, dqq::BwdArgs& a, void* workspace, size_t works
     const bool dense_ok = dqq::bwd_dense_supported(kind, a.N);
     if (a.layout == DQQ_P_DIAG) {
         if (!fast_ok) return DQQ_E_UNSUPPORTED_N;
-        return (int)dqq::launch_bwd_diag(kind, a, g_wpb.load(), g_fuse.load(), s, nullptr);
+        return (int)dqq::launch_bwd_diag(kind, a, dqq::knob_wpb(), dqq::knob_fuse_fallback(), s, nullptr);
     }
-    const size_t scratch = dqq_scratch_bytes(kind, 1, a.N, a.B);
+    const size_t scratch = dqq_scratch_bytes(kind, 1, a.N, a.B, a.layout | (a.ref_order ? DQQ_F_REFERENCE_ORDER : 0));
     if (a.layout == DQQ_P_DENSE || !fast_ok) {
         if (!dense_ok) return DQQ_E_UNSUPPORTED_N;
         if (scratch > 0) {
@@ -203,20 +214,20 @@ static int bwd_dispatch(int kind, dqq::BwdArgs& a, void* workspace, size_t works
     if (int rc = check_ws(workspace, workspace_bytes, a.B, scratch)) return rc;
     a.ws = static_cast<int*>(workspace);
     if (scratch > 0) a.scratch = scratch_of(workspace, a.B);
-    const bool fused = dqq::bwd_diag_will_fuse(kind, a.N, a.B, a.layout, g_fuse.load());
+    const bool fused = dqq::bwd_diag_will_fuse(kind, a.N, a.B, a.layout, dqq::knob_fuse_fallback());
     if (!fused && !dense_ok) return DQQ_E_UNSUPPORTED_N; // (box QP, N > 32): nothing could drain the work-list
     // everything was queued last time (feedback word): one launch of the lane-per-problem kernel over the whole batch, which
     // also recounts for the next call (bwd_lane_dense.hip REPORT; a diagonal problem gets the same bits there)
-    if (!fused && g_auto_fallback.load() != 0 && dqq::bwd_lane_takes_auto_batch(kind, a.N, a.B, s)) {
+    if (!fused && dqq::bwd_lane_takes_auto_batch(kind, a.N, a.B, s)) {
         dqq::g_bwd_whole_batches.fetch_add(1, std::memory_order_relaxed);
         hipError_t e2 = dqq::launch_bwd_lane_dense(kind, a, 2, s);
         if (e2 != hipSuccess) reset_worklist(workspace, s);
         return (int)e2;
     }
     bool needs_fallback = true;
-    hipError_t e = dqq::launch_bwd_diag(kind, a, g_wpb.load(), g_fuse.load(), s, &needs_fallback);
+    hipError_t e = dqq::launch_bwd_diag(kind, a, dqq::knob_wpb(), dqq::knob_fuse_fallback(), s, &needs_fallback);
     if (e != hipSuccess) return (int)e;
-    if (needs_fallback && g_auto_fallback.load() != 0) {
+    if (needs_fallback) {
         e = dqq::launch_bwd_dense(kind, a, true, s);
         if (e != hipSuccess) reset_worklist(workspace, s);
     }
@@ -229,9 +240,11 @@ int dqq_qp_fwd_f64(const double* P, const double* q, double* x, int64_t B, int N
 {
     if (int rc = check_common(B, N, p_layout, false)) return rc;
     if (B > 0 && (P == nullptr || q == nullptr || x == nullptr)) return DQQ_E_NULLPTR;
-    const bool keep = p_layout == DQQ_P_AUTO && dqq::fwd_diag_supported(N);
+    const int layout = layout_of(p_layout);
+    const bool keep = layout == DQQ_P_AUTO && dqq::fwd_diag_supported(N);
     dqq::FwdArgs a{P,        q,     nullptr, nullptr, nullptr, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0,
-                   p_layout, iters, nullptr, keep ? pdiag_out : nullptr, keep ? diag_flags_out : nullptr};
+                   layout,   iters, nullptr, keep ? pdiag_out : nullptr, keep ? diag_flags_out : nullptr};
+    a.ref_order = ref_order_of(p_layout);
     if (!keep && diag_flags_out != nullptr && B > 0) { // nothing will be verified: flag every problem 0
         hipError_t e = hipMemsetAsync(diag_flags_out, 0, (size_t)B, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return (int)e;
@@ -247,9 +260,11 @@ int dqq_qcqp_fwd_f64(const double* P, const double* q, const double* l_n, const 
     if (int rc = check_common(B, N, p_layout, true)) return rc;
     if (B > 0 && (P == nullptr || q == nullptr || l_n == nullptr || mu == nullptr || x == nullptr))
         return DQQ_E_NULLPTR;
-    const bool keep = p_layout == DQQ_P_AUTO && dqq::fwd_diag_supported(N);
-    dqq::FwdArgs a{P,     q,       l_n, mu, nullptr, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0, p_layout,
+    const int layout = layout_of(p_layout);
+    const bool keep = layout == DQQ_P_AUTO && dqq::fwd_diag_supported(N);
+    dqq::FwdArgs a{P,     q,       l_n, mu, nullptr, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0, layout,
                    iters, nullptr, keep ? pdiag_out : nullptr, keep ? diag_flags_out : nullptr};
+    a.ref_order = ref_order_of(p_layout);
     if (!keep && diag_flags_out != nullptr && B > 0) {
         hipError_t e = hipMemsetAsync(diag_flags_out, 0, (size_t)B, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return (int)e;
@@ -267,9 +282,11 @@ static int box_fwd(const double* P, const double* q, const double* l_min, const 
     if (B > 0 && (P == nullptr || q == nullptr || l_min == nullptr || l_max == nullptr || x == nullptr ||
                   (is_signed && v == nullptr)))
         return DQQ_E_NULLPTR;
-    const bool keep = p_layout == DQQ_P_AUTO && dqq::fwd_diag_supported(N);
+    const int layout = layout_of(p_layout);
+    const bool keep = layout == DQQ_P_AUTO && dqq::fwd_diag_supported(N);
     dqq::FwdArgs a{P,        q,     l_min,   l_max, v, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0,
-                   p_layout, iters, nullptr, keep ? pdiag_out : nullptr, keep ? diag_flags_out : nullptr};
+                   layout,   iters, nullptr, keep ? pdiag_out : nullptr, keep ? diag_flags_out : nullptr};
+    a.ref_order = ref_order_of(p_layout);
     if (!keep && diag_flags_out != nullptr && B > 0) {
         hipError_t e = hipMemsetAsync(diag_flags_out, 0, (size_t)B, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return (int)e;
@@ -303,7 +320,8 @@ int dqq_qp_bwd_f64(const double* P, const double* q, const double* x, const doub
     if (int rc = check_common(B, N, p_layout, false)) return rc;
     if (B > 0 && (P == nullptr || q == nullptr || x == nullptr || grad_x == nullptr)) return DQQ_E_NULLPTR;
     dqq::BwdArgs a{P,     q,          nullptr, nullptr, x,       grad_x, grad_P,  grad_q,   nullptr,  nullptr,
-                   pdiag, diag_flags, nullptr, nullptr, (long)B, N,      epsilon, p_layout, ir_steps, nullptr};
+                   pdiag, diag_flags, nullptr, nullptr, (long)B, N,      epsilon, layout_of(p_layout), ir_steps, nullptr};
+    a.ref_order = ref_order_of(p_layout);
     return bwd_dispatch(0, a, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
@@ -318,7 +336,8 @@ int dqq_qcqp_bwd_f64(const double* P, const double* q, const double* l_n, const 
                   grad_x == nullptr))
         return DQQ_E_NULLPTR;
     dqq::BwdArgs a{P,     q,          l_n,   mu,     x,       grad_x, grad_P,  grad_q,   grad_l_n, grad_mu,
-                   pdiag, diag_flags, gamma, dgamma, (long)B, N,      epsilon, p_layout, ir_steps, nullptr};
+                   pdiag, diag_flags, gamma, dgamma, (long)B, N,      epsilon, layout_of(p_layout), ir_steps, nullptr};
+    a.ref_order = ref_order_of(p_layout);
     return bwd_dispatch(1, a, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
@@ -333,7 +352,8 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
                   grad_x == nullptr))
         return DQQ_E_NULLPTR;
     dqq::BwdArgs a{P,     q,          l_min, l_max,  x,       grad_x, grad_P,  grad_q,   grad_l_min, grad_l_max,
-                   pdiag, diag_flags, gamma, dgamma, (long)B, N,      epsilon, p_layout, ir_steps,   nullptr};
+                   pdiag, diag_flags, gamma, dgamma, (long)B, N,      epsilon, layout_of(p_layout), ir_steps,   nullptr};
+    a.ref_order = ref_order_of(p_layout);
     return bwd_dispatch(dqq::kKindBox, a, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 

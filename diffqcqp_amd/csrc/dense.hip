@@ -8,18 +8,12 @@
 
 namespace dqq {
 
-std::atomic<int> g_dense_wave64{1}; // 0: never the register-resident wave-per-problem forward / QP backward of 16 < N <= 64 (option "dense_wave64")
-std::atomic<int> g_wave_qcqp_bwd{1}; // 0: never the register-resident QCQP backward of 16 < N <= 64 (option "wave_qcqp_bwd")
-std::atomic<int> g_lane_dense{1};  // 0: never the lane-per-problem kernel of N <= 8 (option "lane_dense")
-std::atomic<int> g_dense_teams{1}; // 0: backward always one problem per wave (option "dense_teams")
-std::atomic<int> g_small_fwd{1};   // 0: never the team-per-problem forward of N = 10..16 (option "small_fwd")
-std::atomic<int> g_small_bwd{1};   // 0: never the statically sized team backward of N <= 8 (option "small_bwd")
 std::atomic<unsigned long long*> g_feedback_dev{nullptr};                     // dqq_set_feedback (launch.h)
 std::atomic<const volatile unsigned long long*> g_feedback_host{nullptr};
-std::atomic<int> g_bwd_skip_classify{1};  // option "bwd_skip_classify": 0 = a DQQ_P_AUTO backward always starts with the fast path's launch
-std::atomic<int> g_bwd_whole_batches{0};  // a counter (tests): DQQ_P_AUTO backwards the feedback word sent to the lane kernel whole
-std::atomic<int> g_lane_list_drains{0};   // a counter, not a knob: drain launches routed to the lane kernel by the feedback word (tests)
-std::atomic<int> g_lane_bwd{1};    // 0: never the lane-per-problem backward of N <= 8, DQQ_P_DENSE (option "lane_bwd")
+// route counters (tuning.h)
+std::atomic<int> g_bwd_whole_batches{0};
+std::atomic<int> g_lane_list_drains{0};
+std::atomic<int> g_fwd_feedback_routes{0};
 
 
 // Workgroups hold `wpb` independent waves (wave-private LDS slices, no workgroup barrier): more waves
@@ -36,7 +30,7 @@ __global__ __launch_bounds__(256) void fwd_dense_kernel(const double* __restrict
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     double* sw = smem + wave * lds_per_wave;
-    const long count = use_worklist ? worklist_count(ws, n) : B;
+    const long count = use_worklist ? worklist_count(ws, n, B) : B;
     const long nwaves = (long)gridDim.x * wpb;
     for (long w = (long)blockIdx.x * wpb + wave; w < count; w += nwaves) {
         const long prob = use_worklist ? worklist_entry(ws, n, B, w) : w;
@@ -59,7 +53,7 @@ __global__ __launch_bounds__(256) void bwd_dense_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int team = lane / T, tl = lane % T;
     double* sw = smem + (wave * TP + team) * lds_per_team;
-    const long count = use_worklist ? worklist_count(ws, n) : B;
+    const long count = use_worklist ? worklist_count(ws, n, B) : B;
     const long nteams = (long)gridDim.x * wpb * TP;
     for (long w = ((long)blockIdx.x * wpb + wave) * TP + team; w < count; w += nteams) {
         const long prob = use_worklist ? worklist_entry(ws, n, B, w) : w;
@@ -81,14 +75,14 @@ int dense_max_n(int kind)
 // register-resident kernels switched off.)  dqq_scratch_bytes / dqq_max_n report exactly this, so that the scratch a call
 // demands is the scratch the kernels it launches use (the default route of QCQP 42 < N <= 64 demanded 46 MB it
 // never touched).
-bool bwd_uses_any(int kind, int N)
+bool bwd_uses_any(int kind, int N, bool ref_order)
 {
-    if (kind == kKindQCQP && N > 16 && N <= 64 && g_wave_qcqp_bwd.load() != 0) return false;
+    if (kind == kKindQCQP && N > 16 && N <= 64 && !ref_order) return false;
     return N > dense_max_n(kind == kKindQP ? 0 : (kind == kKindBox ? 3 : 2));
 }
-int public_max_n(int kind)
+int public_max_n(int kind, bool ref_order)
 {
-    if (kind == 2 && g_wave_qcqp_bwd.load() != 0) return 64;
+    if (kind == 2 && !ref_order) return 64;
     return dense_max_n(kind);
 }
 
@@ -142,10 +136,10 @@ hipError_t launch_fwd_dense(int kind, const FwdArgs& a, bool use_worklist, hipSt
 {
     if (a.B == 0) return hipSuccess;
     if (fwd_needs_any(kind, a.N)) return launch_fwd_any(kind, a, use_worklist, s);
-    if (fwd_lane_dense_supported(a.N) && g_lane_dense.load() != 0)
+    if (fwd_lane_dense_supported(a.N) && knob_lane_dense() != 0)
         return launch_fwd_lane_dense(kind, a, use_worklist, s);
-    if (fwd_small_supported(a.N) && g_small_fwd.load() != 0) return launch_fwd_small(kind, a, use_worklist, s);
-    if (fwd_dense_wave64_supported(a.N) && g_dense_wave64.load() != 0)
+    if (fwd_small_supported(a.N) && knob_small_fwd() != 0) return launch_fwd_small(kind, a, use_worklist, s);
+    if (fwd_dense_wave64_supported(a.N) && !a.ref_order)
         return launch_fwd_dense_wave64(kind, a, use_worklist, s);
     switch (kind) {
     case 0: return launch_fwd_wave<0>(a, use_worklist, s);
@@ -181,7 +175,7 @@ template <int KIND>
 static hipError_t launch_bwd_kind(const BwdArgs& a, bool use_worklist, hipStream_t s)
 {
     const int rows = dense_bwd_rows(KIND, a.N); // lanes a problem needs
-    if (g_dense_teams.load() != 0) {
+    if (knob_dense_teams() != 0) {
         if (rows <= 8) return launch_bwd_team<KIND, 8>(a, use_worklist, s);
         if (rows <= 16) return launch_bwd_team<KIND, 16>(a, use_worklist, s);
         if (rows <= 32) return launch_bwd_team<KIND, 32>(a, use_worklist, s);
@@ -191,7 +185,7 @@ static hipError_t launch_bwd_kind(const BwdArgs& a, bool use_worklist, hipStream
 
 bool bwd_lane_takes_auto_batch(int kind, int N, long B, hipStream_t s)
 {
-    if (g_lane_bwd.load() == 0 || g_bwd_skip_classify.load() == 0 || !bwd_lane_dense_supported(kind, N, B)) return false;
+    if (knob_lane_bwd() == 0 || knob_bwd_skip_classify() == 0 || !bwd_lane_dense_supported(kind, N, B)) return false;
     int streak = 0;
     // three quarters of the batch or more queued, twice running (launch.h): one launch of the lane kernel over everything costs
     // what its waves cost (B / 64 of them, whatever their problems are); classifying first costs a launch that queues the
@@ -205,27 +199,27 @@ hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipSt
     // a batch DECLARED dense that fills the chip: a lane per problem (bwd_lane_dense.hip; the same bits as the team kernel).
     // Not in work-list mode unless the list is known to be long: its 512-register waves need an empty SIMD each, and an empty
     // list must cost next to nothing.
-    if (!use_worklist && g_lane_bwd.load() != 0 && bwd_lane_dense_supported(kind, a.N, a.B))
+    if (!use_worklist && knob_lane_bwd() != 0 && bwd_lane_dense_supported(kind, a.N, a.B))
         return launch_bwd_lane_dense(kind, a, 0, s);
     // ... and the drain launch of a work-list that the last drain of this kind, N and B found that long (launch.h: feedback)
-    if (use_worklist && g_lane_bwd.load() != 0 && bwd_lane_dense_supported(kind, a.N, a.B) &&
+    if (use_worklist && knob_lane_bwd() != 0 && bwd_lane_dense_supported(kind, a.N, a.B) &&
         bwd_lane_dense_supported(kind, a.N, worklist_predicted(kind, a.N, a.B)) && hint_allowed_on(s)) {
         g_lane_list_drains.fetch_add(1, std::memory_order_relaxed);
         return launch_bwd_lane_dense(kind, a, 1, s);
     }
-    if (bwd_small_supported(kind, a.N) && g_small_bwd.load() != 0) return launch_bwd_small(kind, a, use_worklist, s);
-    if (bwd_dense_wave64_supported(kind, a.N) && g_dense_wave64.load() != 0)
+    if (bwd_small_supported(kind, a.N) && knob_small_bwd() != 0) return launch_bwd_small(kind, a, use_worklist, s);
+    if (bwd_dense_wave64_supported(kind, a.N) && !a.ref_order)
         return launch_bwd_dense_wave64(kind, a, use_worklist, s);
     // QCQP, 16 < N <= 64: the register-resident block-Cholesky kernels re-associate the sums of these Tikhonov systems
     // (cond(K) ~ 1e9: gradients within 5e-7 / 8e-6 of the reference-order evaluation, the evaluation-order noise of the
     // reference's own formulas); option "wave_qcqp_bwd" = 0 selects the reference-order kernels instead
     // (LDS wave kernel up to N = 42, global-memory kernel beyond: 1e-9, 10-30x slower).
-    if (bwd_wave_qcqp_supported(kind, a.N) && g_wave_qcqp_bwd.load() != 0) return launch_bwd_wave_qcqp(a, use_worklist, s);
-    if (bwd_wave_qcqp_big_supported(kind, a.N) && g_wave_qcqp_bwd.load() != 0)
+    if (bwd_wave_qcqp_supported(kind, a.N) && !a.ref_order) return launch_bwd_wave_qcqp(a, use_worklist, s);
+    if (bwd_wave_qcqp_big_supported(kind, a.N) && !a.ref_order)
         return launch_bwd_wave_qcqp_big(a, use_worklist, s);
     // Systems beyond the wave kernel's 64 rows (QP N > 64, QCQP N > 42, box N > 21): the global-memory kernel in the
     // reference's summation order.
-    if (bwd_uses_any(kind, a.N)) return launch_bwd_any(kind, a, use_worklist, s);
+    if (bwd_uses_any(kind, a.N, a.ref_order)) return launch_bwd_any(kind, a, use_worklist, s);
     if (kind == kKindBox) return launch_bwd_kind<2>(a, use_worklist, s);
     return kind == 0 ? launch_bwd_kind<0>(a, use_worklist, s) : launch_bwd_kind<1>(a, use_worklist, s);
 }

@@ -36,13 +36,11 @@ namespace dqq {
 #define DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE) \
     __attribute__((amdgpu_waves_per_eu(((FUSE) && (N) == 8 && (LPP) == 2 && (KIND) < 2) ? 4 : 1, 8)))
 
-// Option "fwd_respread": once at most this many (0..16) of a wave's 32 problems are still iterating, they move onto
+// knob fwd_respread (tuning.h): once at most this many (0..16) of a wave's 32 problems are still iterating, they move onto
 // twice the lanes (admm_core.h admm_fwd_diag_respread; N = 8, two lanes per problem, QP / QCQP).  0 = never.
 // Results do not depend on it (bit-identical, tests/test_gpu_compaction.py).
-std::atomic<int> g_fwd_respread{16};
-// Option "fwd_respread2": once at most this many (0..8) of the re-spread problems are still iterating, they move again,
+// knob fwd_respread2: once at most this many (0..8) of the re-spread problems are still iterating, they move again,
 // onto EIGHT lanes per problem (one coordinate per lane).  0 = never.  Bit-identical results.
-std::atomic<int> g_fwd_respread2{8};
 int lane_defer_for(int kind); // fwd_lane_dense.hip: the general routines' deferred refactorisation (option lane_defer)
 constexpr bool fwd_diag_respreads(int kind, int n, int lpp) { return kind < 2 && n == 8 && lpp == 2; }
 
@@ -68,7 +66,12 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
     // FUSE (small N, small batches): a non-diagonal tile is solved right here by the general per-problem
     // routine (its LDS scratch aliases the diagonal staging buffer); otherwise the tile is queued for
     // the dense kernel launched behind this one.
-    constexpr int SMEM = (FUSE && dense_fwd_lds_doubles(N) > 64 * E) ? dense_fwd_lds_doubles(N) : 64 * E;
+    // STAGE (N = 8 on ONE lane per problem, QP / QCQP -- the layout of batches that are mostly non-diagonal): the wave's
+    // whole tile of P goes through LDS (stage_tile_lane8) and is read from HBM once.  33 KB per wave: affordable exactly
+    // here, where the kernel runs one wave per SIMD anyway (DQQ_FWD_DIAG_OCCUPANCY).
+    constexpr bool STAGE = FUSE && N == 8 && LPP == 1 && KIND < 2;
+    constexpr int SMEM = STAGE ? 64 * (N * N + 1)
+                               : ((FUSE && dense_fwd_lds_doubles(N) > 64 * E) ? dense_fwd_lds_doubles(N) : 64 * E);
     __shared__ __attribute__((aligned(16))) double s_diag[WPB][SMEM];
     constexpr bool AGG = !FUSE && WPB > 1; // queue non-diagonal tiles with ONE atomic per workgroup (see launch.h)
     __shared__ int s_cnt[2];
@@ -85,6 +88,7 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
     constexpr int LD = (N == 8 && LPP == 1 && KIND < 2) ? 1 : ((N / 2 > LPP) ? N / 2 : LPP);
     constexpr bool GD = FUSE && N <= 8 && LD <= 4 && group_dense_supported(KIND, N, LD);
     [[maybe_unused]] bool dense_tile = false; // CMP: some tile of this workgroup is not diagonal
+    [[maybe_unused]] unsigned long long pmask = 0;   // N = 8, GD: bit p = problem p of the tile is not diagonal (from the stream)
 
     // the wave index is wave-uniform: in an SGPR, the tile's position (`first`, `nvalid`, pointers) is scalar arithmetic and
     // costs no vector registers -- as a VGPR value the fused forward kept `first` and `nvalid` in SCRATCH (spilled and
@@ -99,6 +103,9 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
     if (B < 0) junk[lane % DQQ_PROBE_SCRATCH] = eps;
 #endif
     if (first >= B) return; // whole wave leaves before any workgroup barrier
+    if constexpr (!FUSE) {   // this launch may fill the work-list: the words only its drain writes start from zero (launch.h)
+        if (tile == 0 && ws != nullptr && layout == DQQ_P_AUTO) worklist_prepare(ws, lane);
+    }
     DQQ_TL(0);
     const int nvalid = (B - first) < PPW ? (int)(B - first) : PPW;
     const int pl = lane / LPP;
@@ -159,9 +166,19 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
         const double* Pw = P + first * (long)(N * N);
         const int limit = nvalid * N * N; // doubles of P that belong to this tile
         double* sd = s_diag[wave];
-        const unsigned nz = (nvalid == PPW) ? stream_tile_diag<N, NCH, false, true>(Pw, limit, sd, lane)
-                                            : stream_tile_diag<N, NCH, true, true>(Pw, limit, sd, lane);
-        const bool tile_dense = __any(nz != 0); // wave-uniform
+        bool tile_dense;   // wave-uniform
+        if constexpr (STAGE) {
+            pmask = (nvalid == PPW) ? stage_tile_lane8<false>(Pw, nvalid, sd, lane) : stage_tile_lane8<true>(Pw, nvalid, sd, lane);
+            tile_dense = pmask != 0;
+        } else if constexpr (GD && N == 8) {
+            pmask = (nvalid == PPW) ? stream_tile_diag_pmask8<NCH, false>(Pw, limit, sd, lane)
+                                    : stream_tile_diag_pmask8<NCH, true>(Pw, limit, sd, lane);
+            tile_dense = pmask != 0;
+        } else {
+            const unsigned nz = (nvalid == PPW) ? stream_tile_diag<N, NCH, false, true>(Pw, limit, sd, lane)
+                                                : stream_tile_diag<N, NCH, true, true>(Pw, limit, sd, lane);
+            tile_dense = __any(nz != 0);
+        }
         if constexpr (CMP) wg_dense = __syncthreads_or(tile_dense) != 0;
         if constexpr (!GD) {   // (GD: problem by problem, below)
             if (tile_dense && flags_out != nullptr && valid && (lane % LPP) == 0) flags_out[first + pl] = 2; // seen, not diagonal
@@ -176,12 +193,24 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
                 return;
             }
         } else {
-            worklist_push<AGG, worklist_segmented(N)>(ws, B, first, tile_dense ? nvalid : 0, lane, s_cnt);
-            if (tile_dense) return;
+            const bool queued = worklist_push<AGG, worklist_segmented(N)>(ws, B, first, tile_dense ? nvalid : 0, lane, s_cnt);
+            if (tile_dense) {
+                if (!queued && valid) {   // (launch.h, work-list hygiene: the tile will not be solved -- say so in its outputs)
+                    double* xx = x + first * N + lane * E;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) xx[e] = __builtin_nan("");
+                }
+                return;
+            }
         }
         wave_lds_fence();
+        if constexpr (STAGE) {   // the lane's own matrix: its diagonal
 #pragma unroll
-        for (int e = 0; e < E; ++e) p[e] = valid ? sd[lane * E + e] : 1.0;
+            for (int e = 0; e < E; ++e) p[e] = valid ? sd[lane * (N * N + 1) + e * (N + 1)] : 1.0;
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) p[e] = valid ? sd[lane * E + e] : 1.0;
+        }
     }
 
     DQQ_TL(1);
@@ -223,19 +252,28 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
         if (__builtin_expect(dense_tile, 0)) {
             bool densep = valid;   // declared dense: every problem
             if (layout != DQQ_P_DENSE) {
-                int* pf = reinterpret_cast<int*>(s_diag[wave]);   // (the staged diagonals are not needed any more, below)
-                tile_problem_flags<N, NCH, PPW>(P + first * (long)(N * N), nvalid * N * N, pf, lane);
-                densep = valid && pf[pl] != 0;
-                wave_lds_fence();
+                if constexpr (N == 8) {   // classified by the stream itself (stream_tile.h)
+                    densep = valid && ((pmask >> pl) & 1ull) != 0;
+                } else {
+                    int* pf = reinterpret_cast<int*>(s_diag[wave]);   // (the staged diagonals are not needed any more, below)
+                    tile_problem_flags<N, NCH, PPW>(P + first * (long)(N * N), nvalid * N * N, pf, lane);
+                    densep = valid && pf[pl] != 0;
+                    wave_lds_fence();
+                }
             }
             if (flags_out != nullptr && densep && (lane % LPP) == 0) flags_out[first + pl] = 2; // seen, not diagonal
             dmask = __ballot(densep);
             mine = valid && !densep;
             // the diagonal of the problems that stay: from P itself (the stream of a large tile stops at the first group of
             // chunks with a non-zero off-diagonal, stream_tile.h: the staging buffer may be incomplete)
-            const double* Pg = P + (first + pl) * (long)(N * N) + ((lane % LPP) * E) * (N + 1);
+            if constexpr (N == 8) {   // the stream of an 8 x 8 tile never stops early: the staged diagonals are complete
 #pragma unroll
-            for (int e = 0; e < E; ++e) p[e] = mine ? Pg[e * (N + 1)] : 1.0;
+                for (int e = 0; e < E; ++e) p[e] = mine ? p[e] : 1.0;
+            } else {
+                const double* Pg = P + (first + pl) * (long)(N * N) + ((lane % LPP) * E) * (N + 1);
+#pragma unroll
+                for (int e = 0; e < E; ++e) p[e] = mine ? Pg[e * (N + 1)] : 1.0;
+            }
         }
     }
     // N = 8 on two lanes per problem: the tail of the tile moves onto four lanes per problem (admm_core.h)
@@ -276,9 +314,19 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
     if constexpr (GD) {
         // the tile's non-diagonal problems: the general solve on LD lanes per problem, 64 / LD problems per pass; it reads its
         // inputs and writes x / iters itself, in its own mapping
-        if (__builtin_expect(dense_tile, 0))
-            group_dense_tile<KIND, N, LD, PPW>(P, q, l_n, mu_c, v_sign, x, iters, first, nvalid, eps, mu_prox, max_iter,
-                                               adaptive, lane, gdefer, dmask, LPP);
+        if (__builtin_expect(dense_tile, 0)) {
+            if constexpr (STAGE) {
+                if (layout != DQQ_P_DENSE)
+                    group_dense_tile<KIND, N, LD, PPW, true>(P, q, l_n, mu_c, v_sign, x, iters, first, nvalid, eps, mu_prox,
+                                                             max_iter, adaptive, lane, gdefer, dmask, LPP, s_diag[wave]);
+                else
+                    group_dense_tile<KIND, N, LD, PPW>(P, q, l_n, mu_c, v_sign, x, iters, first, nvalid, eps, mu_prox, max_iter,
+                                                       adaptive, lane, gdefer, dmask, LPP);
+            } else {
+                group_dense_tile<KIND, N, LD, PPW>(P, q, l_n, mu_c, v_sign, x, iters, first, nvalid, eps, mu_prox, max_iter,
+                                                   adaptive, lane, gdefer, dmask, LPP);
+            }
+        }
     }
     DQQ_TL(5);
 }
@@ -292,8 +340,8 @@ static hipError_t launch_one(const FwdArgs& a, hipStream_t s)
     if (nblocks == 0) return hipSuccess;
     return launch((fwd_diag_kernel<KIND, N, LPP, WPB, FUSE, CMP>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q,
                        a.l_n, a.mu, a.v, a.x, a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.layout, a.iters, a.ws,
-                       a.pdiag_out, a.flags_out, std::min(16, std::max(0, g_fwd_respread.load())),
-                       std::min(8, std::max(0, g_fwd_respread2.load())), lane_defer_for(KIND));
+                       a.pdiag_out, a.flags_out, std::min(16, std::max(0, knob_fwd_respread())),
+                       std::min(8, std::max(0, knob_fwd_respread2())), lane_defer_for(KIND));
 }
 
 // Option "fwd_compact": 1 = repack the tiles of a workgroup as their problems stop (admm_compact.h).  OFF by
@@ -301,15 +349,14 @@ static hipError_t launch_one(const FwdArgs& a, hipStream_t s)
 // every checkpoint costs the workgroup a barrier's worth of imbalance (0.5-1 us) and the launch is bound by its
 // longest problem anyway: QCQP forward 29.4 -> 36.1 us.  It pays for heavy-tailed iteration counts (QP,
 // P = diag(exp(U(-10,10))): 690 -> 480 us).  Instantiated for N = 8, two lanes per problem.
-std::atomic<int> g_fwd_compact{0};
 constexpr bool fwd_diag_compacts(int kind, int n, int lpp) { return kind < 2 && n == 8 && lpp == 2; }
 
 template <int KIND, int N, int LPP>
 static hipError_t launch_wpb(const FwdArgs& a, int wpb, bool fuse, hipStream_t s)
 {
     if constexpr (fwd_diag_fuses(N)) {
-        if constexpr (fwd_diag_compacts(KIND, N, LPP)) {
-            if (fuse && wpb != 1 && g_fwd_compact.load() > 0) return launch_one<KIND, N, LPP, 4, true, true>(a, s);
+        if constexpr (kTuning && fwd_diag_compacts(KIND, N, LPP)) {   // (the compacting kernel exists in the developer build only)
+            if (fuse && wpb != 1 && knob_fwd_compact() > 0) return launch_one<KIND, N, LPP, 4, true, true>(a, s);
         }
         if (fuse) return wpb == 1 ? launch_one<KIND, N, LPP, 1, true>(a, s) : launch_one<KIND, N, LPP, 4, true>(a, s);
     }
@@ -410,8 +457,6 @@ bool fwd_diag_will_fuse(int N, long B, int layout, int fuse_opt)
            (fuse_opt < 0 ? fwd_diag_fuses_fallback(N, B) : fuse_opt != 0);
 }
 
-std::atomic<int> g_fwd_feedback{1};          // option "fwd_feedback": 0 = the forward never looks at the feedback word
-std::atomic<int> g_fwd_feedback_routes{0};   // a counter (tests): forwards the feedback word moved to four lanes per problem
 
 // lpp / wpb == 0 -> built-in choice; an lpp the kernel is not instantiated for falls back to the
 // built-in one.  *needs_fallback: the caller must launch the dense kernel in work-list mode next.
@@ -432,7 +477,7 @@ hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fus
         // few cost one pass of it per affected 16-problem block -- one in 1000: 46 / 52 us, what four lanes per problem took.
         // The same bits either way: neither the diagonal arithmetic nor the general solve depends on the lane layout, and
         // which of the two a problem gets depends on the problem alone.
-        if (a.layout == DQQ_P_AUTO && fuse && a.N == 8 && kind < 2 && lpp == 2 && g_fwd_feedback.load() != 0) {
+        if (a.layout == DQQ_P_AUTO && fuse && a.N == 8 && kind < 2 && lpp == 2 && knob_fwd_feedback() != 0) {
             if (2 * worklist_predicted_in_blocks(kind, a.N, a.B) >= a.B && hint_allowed_on(s)) {
                 lpp = 1;
                 g_fwd_feedback_routes.fetch_add(1, std::memory_order_relaxed);

@@ -30,12 +30,11 @@ namespace dqq {
 //   B = 262144   1: 255 / 275     2: 211 / 246     3: 193 / 236     4: 194 / 234     6: 185 / 247     8: 190 / 248     12: 202 / 270
 // (N = 4: 40.7 / 36.1 -> 38.6 / 34.9).  A model of the wave -- 190 instructions per trip, 440 per refactorisation, the
 // firing pattern of the reference's rho schedule -- predicts 0.66 / 0.73 of the loop's cost at 4.
-std::atomic<int> g_lane_defer{0};
 // 0 = built-in: 4 for the QCQP, 6 for the QP-like kinds (sweeps above and in tools/probe_group_defer.py; box / signed box
 // QP, dense 8 x 8, B = 65536: 1: 79.7 / 80.5   2: 70.7 / 73.4   4: 69.0 / 71.2   6: 65.6 / 68.1   8: 68.0 / 69.9 us)
 int lane_defer_for(int kind)
 {
-    const int v = g_lane_defer.load();
+    const int v = knob_lane_defer();
     return v > 0 ? (v < 64 ? v : 64) : (kind == kKindQCQP ? 4 : 6);
 }
 
@@ -139,14 +138,14 @@ __global__ __launch_bounds__(64, 1) void fwd_lane_dense_kernel(const double* __r
     // KIND 2 / 3 (box / signed box QP, Solver.cpp:198-261 / 374-439): l_n = l_min, mu_c = l_max per coordinate
     static_assert(N % 2 == 0, "even N");
     constexpr bool QP_LIKE = (KIND != 1);
-    const long count = use_worklist ? (long)ws[kWsCount] : B;
+    const long count = use_worklist ? worklist_checked_count(ws, ws + kWsCount, kWsEntryInts(B)) : B;
     const long slot = (long)blockIdx.x * 64 + threadIdx.x;
     const bool valid = slot < count;
     if ((long)blockIdx.x * 64 >= count) { // a wave beyond the end of the work-list: only the reset ticket
         if (use_worklist && threadIdx.x == 0) worklist_release(ws, count, (int)gridDim.x);
         return;
     }
-    const long prob = valid ? (use_worklist ? (long)ws[kWsEntries + slot] : slot) : 0;
+    const long prob = valid ? (use_worklist ? worklist_checked_entry(ws, ws[kWsEntries + slot], B) : slot) : 0;
 
     // ---- load: P (lower triangle kept, full matrix used by the power iteration), q, radius
     double Pm[N][N];

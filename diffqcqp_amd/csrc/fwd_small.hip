@@ -116,14 +116,14 @@ __global__ __launch_bounds__(256, N >= 14 ? 1 : 2) void fwd_small_kernel(const d
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int team = lane / T, tl = lane % T;
-    const long count = use_worklist ? (long)ws[kWsCount] : B;
+    const long count = use_worklist ? worklist_checked_count(ws, ws + kWsCount, kWsEntryInts(B)) : B;
     const long slot = ((long)blockIdx.x * wpb + wave) * TP + team;
     if (((long)blockIdx.x * wpb + wave) * TP >= count) { // a wave beyond the end of the list: only the reset ticket
         if (use_worklist && lane == 0) worklist_release(ws, count, (int)(gridDim.x * wpb));
         return;
     }
     const bool valid = slot < count;
-    const long prob = valid ? (use_worklist ? (long)ws[kWsEntries + slot] : slot) : 0;
+    const long prob = valid ? (use_worklist ? worklist_checked_entry(ws, ws[kWsEntries + slot], B) : slot) : 0;
     const bool actn = tl < N;
     const int i = actn ? tl : 0;
     TeamSolve<N> ts;

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(kAnyT) void fwd_any_kernel(const double* __restrict
     double* A = LDS ? smem : scr;
     double* Ainv = LDS ? smem + mat : scr + mat;
     double* vec = LDS ? scr : scr + 2 * mat;
-    const long count = use_worklist ? worklist_count(ws, n) : B;
+    const long count = use_worklist ? worklist_count(ws, n, B) : B;
     for (long w = blockIdx.x; w < count; w += gridDim.x) {
         const long prob = use_worklist ? worklist_entry(ws, n, B, w) : w;
         any_fwd_problem<KIND>(P, q, l_n, mu_c, v_sign, x, iters, prob, n, eps, mu, max_iter, adaptive, A, Ainv, vec, red,
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kAnyT) void bwd_any_kernel(
     double* At = LDS ? smem : scr + mat;
     double* Kinv = LDS ? smem + mat : scr + 2 * mat;
     double* vec = LDS ? scr + mat : scr + 3 * mat;
-    const long count = use_worklist ? worklist_count(ws, n) : B;
+    const long count = use_worklist ? worklist_count(ws, n, B) : B;
     for (long w = blockIdx.x; w < count; w += gridDim.x) {
         const long prob = use_worklist ? worklist_entry(ws, n, B, w) : w;
         any_bwd_problem<KIND>(P, q, l_n, mu_c, x, grad_x, grad_P, grad_q, grad_l_n, grad_mu, gamma_out, dgamma_out,
@@ -96,7 +96,7 @@ size_t any_scratch_bytes(int kind, bool backward, int N, long B)
 // The sizes beyond the register / LDS kernels of the general path (dqq_max_n).  The backward's answer follows the route
 // (dense.hip: bwd_uses_any): the scratch a call demands is the scratch its kernels use.
 bool fwd_needs_any(int kind, int N) { return N > dense_max_n(kind == kKindQCQP ? 1 : 0); }
-bool bwd_needs_any(int kind, int N) { return bwd_uses_any(kind, N); }
+bool bwd_needs_any(int kind, int N, bool ref_order) { return bwd_uses_any(kind, N, ref_order); }
 
 template <typename Kern, typename... Args>
 static hipError_t launch_any(Kern kernel, size_t lds_bytes, long stride, long B, double* scratch, hipStream_t s,

@@ -89,16 +89,23 @@ struct GroupRows {
             for (int e = 0; e + w < E; e += 2 * w) pr[e] = pr[e] + pr[e + w];
         return LaneGroup<LPP>::sum(pr[0]);
     }
-    // rows s*E.. of the matrix as stored
+    // rows s*E.. of the matrix as stored.  SC: 8-byte loads (the matrix sits in the LDS tile of stage_tile_lane8, whose
+    // row stride of N*N + 1 doubles leaves it 8-byte aligned only)
+    template <bool SC = false>
     static DQQ_D void load_rows(const double* __restrict__ Pg, int s, double (&A)[E][N])
     {
 #pragma unroll
         for (int e = 0; e < E; ++e)
 #pragma unroll
             for (int c = 0; c < N; c += 2) {
-                const double2 t = *reinterpret_cast<const double2*>(Pg + (s * E + e) * N + c);
-                A[e][c] = t.x;
-                A[e][c + 1] = t.y;
+                if constexpr (SC) {
+                    A[e][c] = Pg[(s * E + e) * N + c];
+                    A[e][c + 1] = Pg[(s * E + e) * N + c + 1];
+                } else {
+                    const double2 t = *reinterpret_cast<const double2*>(Pg + (s * E + e) * N + c);
+                    A[e][c] = t.x;
+                    A[e][c + 1] = t.y;
+                }
             }
     }
     // rows s*E.. of the symmetric matrix the LOWER triangle of P defines (what llt() factorises), diagonal `md`.
@@ -106,6 +113,7 @@ struct GroupRows {
     // per-lane pointer each with compile-time offsets, and the side is chosen per entry.  (Indexed as
     // Pg[max(g,c) * N + min(g,c)] every entry had its own per-lane 64-bit address, which the compiler hoisted out of
     // the ADMM loop -- the refactorisation sits inside it -- and kept in ~30 VGPRs for the whole solve.)
+    template <bool SC = false>
     static DQQ_D void load_lower_symmetric(const double* __restrict__ Pg, int s, const double (&md)[E],
                                            double (&A)[E][N])
     {
@@ -116,7 +124,9 @@ struct GroupRows {
             const int g = s * E + e;
 #pragma unroll
             for (int c = 0; c < N; c += 2) {
-                const double2 r = *reinterpret_cast<const double2*>(rowp + e * N + c);
+                double2 r;
+                if constexpr (SC) r = make_double2(rowp[e * N + c], rowp[e * N + c + 1]);
+                else r = *reinterpret_cast<const double2*>(rowp + e * N + c);
                 const double c0 = colp[c * N + e], c1 = colp[(c + 1) * N + e];
                 A[e][c] = (c <= g) ? r.x : c0;
                 A[e][c + 1] = (c + 1 <= g) ? r.y : c1;
@@ -153,7 +163,8 @@ struct GroupRows {
 };
 
 // Pg: this problem's P (N x N, row-major).  q, rad, lo, hi, sg, x, valid, return value: as admm_fwd_diag.
-template <int KIND, int N, int LPP>
+// SC: Pg points into LDS (8-byte aligned): scalar loads.
+template <int KIND, int N, int LPP, bool SC = false>
 DQQ_D int group_dense_fwd(const double* __restrict__ Pg, const double (&q)[N / LPP], const double* rad, double eps,
                           double mu, int max_iter, int adaptive, bool valid, double (&x)[N / LPP],
                           const double* lo = nullptr, const double* hi = nullptr, const double* sg = nullptr,
@@ -167,7 +178,7 @@ DQQ_D int group_dense_fwd(const double* __restrict__ Pg, const double (&q)[N / L
 
     double A[E][N]; // rows of P, of its powers, then of M^-1
     if (valid) {
-        R::load_rows(Pg, s, A);
+        R::template load_rows<SC>(Pg, s, A);
     } else {
 #pragma unroll
         for (int e = 0; e < E; ++e)
@@ -247,7 +258,7 @@ DQQ_D int group_dense_fwd(const double* __restrict__ Pg, const double (&q)[N / L
             const double inv = t > 0 ? fast_rsqrt(t) : 1.0;
 #pragma unroll
             for (int e = 0; e < E; ++e) v[e] = v[e] * inv;
-            if (valid) R::load_rows(Pg, s, A); // the Rayleigh quotient is taken with P itself
+            if (valid) R::template load_rows<SC>(Pg, s, A); // the Rayleigh quotient is taken with P itself
         }
         double Pv[E];
         R::matvec(A, v, Pv);
@@ -270,7 +281,7 @@ DQQ_D int group_dense_fwd(const double* __restrict__ Pg, const double (&q)[N / L
         l2[e] = 0.0;
         u[e] = 0.0;
     }
-    if (valid) R::load_lower_symmetric(Pg, s, md, A);
+    if (valid) R::template load_lower_symmetric<SC>(Pg, s, md, A);
     R::invert(A, s, bad);
 
 #define DQQ_ADMM_GENERAL_P 1
@@ -306,7 +317,7 @@ DQQ_D int group_dense_fwd(const double* __restrict__ Pg, const double (&q)[N / L
         if (!__any(run)) break;
         if (__any(pend) && ((trip + 1) % defer == 0 || !__any(run && !pend))) {
             if (pend) {
-                R::load_lower_symmetric(Pg, s, md, A);
+                R::template load_lower_symmetric<SC>(Pg, s, md, A);
                 R::invert(A, s, bad);                                   // llt() + solveInPlace(Identity), :100-101
             }
             pend = false;
@@ -329,12 +340,15 @@ DQQ_D int group_dense_fwd(const double* __restrict__ Pg, const double (&q)[N / L
 // (DESIGN.md 3.1 (v)).  With two rows per lane the general solve fits the diagonal path's own budget (4 waves per
 // SIMD); a dense tile costs two passes of roughly 0.65x the instructions each.  Reads q (and the constraint data)
 // and writes x / iters itself, in the general solve's mapping.
-template <int KIND, int N, int LD, int TILE>
+template <int KIND, int N, int LD, int TILE, bool STAGED = false>
 DQQ_D void group_dense_tile(const double* __restrict__ P, const double* __restrict__ q, const double* __restrict__ l_n,
                             const double* __restrict__ mu_c, const double* __restrict__ v_sign, double* __restrict__ x,
                             int* __restrict__ iters, long first, int nvalid, double eps, double mu, int max_iter,
-                            int adaptive, int lane, int defer = 4, unsigned long long dmask = ~0ull, int mask_stride = 0)
+                            int adaptive, int lane, int defer = 4, unsigned long long dmask = ~0ull, int mask_stride = 0,
+                            const double* tile_lds = nullptr)
 {
+    // STAGED (LD == 1): the tile's matrices sit in LDS (tile_lds, stage_tile_lane8: row stride N*N + 1) -- P is not read from
+    // memory here at all
     // dmask / mask_stride: only the problems j of the tile with bit j * mask_stride of dmask set are solved here (the caller's
     // ballot over ITS lanes, mask_stride lanes per problem); mask_stride = 0: all of them
     constexpr int E = N / LD, PPP = 64 / LD; // coordinates per lane, problems per pass
@@ -369,8 +383,15 @@ DQQ_D void group_dense_tile(const double* __restrict__ P, const double* __restri
                 if (KIND == 3) { const double c = valid ? v_sign[bo] : 0.0; sg[e] = (double)((c > 0) - (c < 0)); } // :395
             }
         }
-        const int it = group_dense_fwd<KIND, N, LD>(P + prob * (long)(N * N), qv, rad, eps, mu, max_iter, adaptive, valid,
+        int it;
+        if constexpr (STAGED) {
+            static_assert(LD == 1, "the staged tile: a lane per problem");
+            it = group_dense_fwd<KIND, N, LD, true>(tile_lds + pj * (N * N + 1), qv, rad, eps, mu, max_iter, adaptive, valid,
                                                     xv, lo, hi, sg, defer);
+        } else {
+            it = group_dense_fwd<KIND, N, LD>(P + prob * (long)(N * N), qv, rad, eps, mu, max_iter, adaptive, valid, xv, lo,
+                                              hi, sg, defer);
+        }
         if (valid) {
 #pragma unroll
             for (int e = 0; e < E; e += 2)

@@ -4,6 +4,7 @@
 
 #include "../../include/diffqcqp_hip.h"
 #include "common.h"
+#include "tuning.h"
 
 #include <atomic>
 
@@ -24,6 +25,7 @@ constexpr int kWsNext = 2; // work-list mode with dynamic pick-up: next unclaime
 constexpr int kWsRepTop = 8;    // [8..9] bwd_lane_dense.hip, REPORT mode: 64-bit (groups arrived, problems counted); zero between launches
 constexpr int kWsFbShadow = 4;  // [4..7]: what this workspace's drain launches last wrote to the feedback buffer, and where (below)
 constexpr int kWsPerProblem = 11; // bwd_diag.hip: 1 = this list holds single problems of classified mixed tiles (not whole tiles); cleared by the drain
+constexpr int kWsDirty = 12;      // sticky: 1 = a kernel found this header inconsistent (see "work-list hygiene" below); dqq_workspace_status reads it, dqq_workspace_reset clears it
 constexpr int kWsSubTickets = 32;   // first of 32 sub-tickets, kWsSubStride ints apart
 constexpr int kWsSubStride = 32;    // 128 bytes: one sub-ticket per cache line
 // N >= 32 (one to sixteen problems per workgroup of the fast kernel: a dense batch through DQQ_P_AUTO queues from
@@ -43,6 +45,59 @@ DQQ_HD constexpr long kWsSegCap(long B) { return B / 32 + 512; }
 // ints behind the header that hold entries: B for the plain list, 32 segments otherwise
 DQQ_HD constexpr long kWsEntryInts(long B) { return 32 * kWsSegCap(B); }
 
+
+// ---- work-list hygiene (round 5).  The protocol rests on an invariant -- "zero-filled once, every call leaves the header
+// zeroed" -- that a caller can break: a workspace that was never zeroed, memory scribbled over, a launch chain cut short by an
+// error.  The kernels therefore do not TRUST the header:
+//   * the fast kernel that is about to fill the list first re-zeroes every word only the drain kernel writes (exit tickets,
+//     pick-up counters: worklist_prepare -- they are idle while it runs, so this is not a race) -- whatever they held is repaired;
+//   * a push whose slot would fall outside the entry area is not performed: the caller poisons that tile's outputs with NaN
+//     and the header is marked dirty (worklist_push_entries returns false);
+//   * a drain kernel clamps the count it reads to the entry area and replaces an entry that is not a problem of this batch
+//     by problem 0 (solved once more, to the same values): nothing is read or written out of bounds, no problem that does
+//     not exist is "solved", and the header is marked dirty;
+//   * stale entries that ARE problems of this batch (a list left behind by an aborted chain) are solved again by the general
+//     kernel behind the fast path: the same problem, the right answer -- and the drain re-zeroes the header as always.
+// "Dirty" is sticky and host-visible (dqq_workspace_status); dqq_workspace_reset clears everything.
+#if defined(__HIPCC__)
+// plain list: slots behind the header; segmented list: slots per segment
+DQQ_HD constexpr long worklist_capacity(int N, long B) { return worklist_segmented(N) ? kWsSegCap(B) : kWsEntryInts(B); }
+// the count in *word (a word of the header ws), clamped to [0, cap]; a negative one is also repaired on the spot (nobody
+// would draw the exit tickets of an "empty" list)
+static DQQ_D long worklist_checked_count(const int* ws, const int* word, long cap)
+{
+    const long c = *word;
+    if (c < 0 || c > cap) {
+        const_cast<int*>(ws)[kWsDirty] = 1;
+        if (c < 0) *const_cast<int*>(word) = 0;
+        return c < 0 ? 0 : cap;
+    }
+    return c;
+}
+static DQQ_D long worklist_checked_entry(const int* ws, long e, long B)
+{
+    if ((unsigned long)e >= (unsigned long)B) {
+        const_cast<int*>(ws)[kWsDirty] = 1;
+        return 0;
+    }
+    return e;
+}
+// Call from ONE wave of the fast kernel (the first of workgroup 0), before anything is pushed.
+static DQQ_D void worklist_prepare(int* __restrict__ ws, int lane)
+{
+    if (lane < 32) {
+        ws[kWsSubTickets + lane * kWsSubStride] = 0;
+        ws[kWsSubTickets + lane * kWsSubStride + 1] = 0;   // (the high word of the 64-bit report counters, bwd_lane_dense.hip)
+        ws[kWsSegNext + lane * kWsSubStride] = 0;
+    }
+    if (lane == 0) {
+        ws[kWsTicket] = 0;
+        ws[kWsNext] = 0;
+        ws[kWsRepTop] = 0;
+        ws[kWsRepTop + 1] = 0;
+    }
+}
+#endif
 
 #if defined(__HIPCC__)
 // Work-list mode of the general kernels: the last participant (wave or workgroup) out re-zeroes the
@@ -193,12 +248,16 @@ static inline hipError_t launch(void (*kernel)(KArgs...), dim3 grid, dim3 block,
 // barriers; waves that already ended are not waited for).  s_cnt: two ints of LDS.
 // SEG: the segmented list (see kWsSegCounts): the counter and the slots of segment blockIdx.x mod 32.
 template <bool AGG, bool SEG = false>
-static DQQ_D void worklist_push_entries(int* __restrict__ ws, long B, int n, bool writes, int rank, int entry, int lane,
+static DQQ_D bool worklist_push_entries(int* __restrict__ ws, long B, int n, bool writes, int rank, int entry, int lane,
                                         int* s_cnt)
 {
-    // n (wave-uniform) entries from this wave; the lanes with `writes` hold them: `entry` goes to slot base + rank
+    // n (wave-uniform) entries from this wave; the lanes with `writes` hold them: `entry` goes to slot base + rank.
+    // Returns false (wave-uniform) when the slots would fall outside the entry area -- a header that did not start at
+    // zero --: nothing is written then, the header is marked dirty and the caller poisons these problems' outputs.
     int* counter = SEG ? ws + kWsSegCounts + (int)(blockIdx.x & 31u) * kWsSubStride : ws + kWsCount;
     int* slots = SEG ? ws + kWsEntries + (long)(blockIdx.x & 31u) * kWsSegCap(B) : ws + kWsEntries;
+    const long cap = SEG ? kWsSegCap(B) : kWsEntryInts(B);
+    bool ok = true;
     if constexpr (!AGG) {
         if (n > 0) {
             int base = 0;
@@ -207,7 +266,9 @@ static DQQ_D void worklist_push_entries(int* __restrict__ ws, long B, int n, boo
                 if (SEG) ws[kWsCount] = 1;
             }
             base = __shfl(base, 0, 64);
-            if (writes) slots[base + rank] = entry;
+            ok = base >= 0 && (long)base + n <= cap;
+            if (ok) { if (writes) slots[base + rank] = entry; }
+            else if (lane == 0) ws[kWsDirty] = 1;
         }
     } else {
         if (threadIdx.x == 0) s_cnt[0] = 0;
@@ -222,41 +283,45 @@ static DQQ_D void worklist_push_entries(int* __restrict__ ws, long B, int n, boo
         __syncthreads();
         if (n > 0) {
             const int base = s_cnt[1] + __shfl(local, 0, 64);
-            if (writes) slots[base + rank] = entry;
+            ok = s_cnt[1] >= 0 && (long)base + n <= cap;
+            if (ok) { if (writes) slots[base + rank] = entry; }
+            else if (lane == 0) ws[kWsDirty] = 1;
         }
     }
+    return ok;
 }
 template <bool AGG, bool SEG = false>
-static DQQ_D void worklist_push(int* __restrict__ ws, long B, long first, int n, int lane, int* s_cnt)
+static DQQ_D bool worklist_push(int* __restrict__ ws, long B, long first, int n, int lane, int* s_cnt)
 {
-    worklist_push_entries<AGG, SEG>(ws, B, n, lane < n, lane, (int)(first + lane), lane, s_cnt);
+    return worklist_push_entries<AGG, SEG>(ws, B, n, lane < n, lane, (int)(first + lane), lane, s_cnt);
 }
 
 // Readers of the work-list for the kernels that drain it with a fixed stride (the kernels behind tuning options and
 // the global-memory kernels).  Plain list: the count word and entry w.  Segmented list (N >= 32): the 32 segment
 // counters are summed / scanned on every call (~6 us: these kernels spend 50 us to milliseconds per problem).  The
 // counters do not change while a drain kernel runs (the last participant out re-zeroes them, worklist_release).
-static DQQ_D long worklist_count(const int* __restrict__ ws, int N)
+static DQQ_D long worklist_count(const int* __restrict__ ws, int N, long B)
 {
-    if (!worklist_segmented(N) || ws[kWsCount] == 0) return ws[kWsCount];
+    if (!worklist_segmented(N)) return worklist_checked_count(ws, ws + kWsCount, kWsEntryInts(B));
+    if (ws[kWsCount] == 0) return 0;
     long c = 0;
 #pragma unroll
-    for (int h = 0; h < 32; ++h) c += ws[kWsSegCounts + h * kWsSubStride];
+    for (int h = 0; h < 32; ++h) c += worklist_checked_count(ws, ws + kWsSegCounts + h * kWsSubStride, kWsSegCap(B));
     return c;
 }
 // 0 <= w < worklist_count
 static DQQ_D long worklist_entry(const int* __restrict__ ws, int N, long B, long w)
 {
-    if (!worklist_segmented(N)) return ws[kWsEntries + w];
+    if (!worklist_segmented(N)) return worklist_checked_entry(ws, ws[kWsEntries + w], B);
     long base = 0, at = 0;     // entries before segment g; slot of entry w
     int g = 0;
 #pragma unroll
     for (int h = 0; h < 32; ++h) {
-        const long c = ws[kWsSegCounts + h * kWsSubStride];
+        const long c = worklist_checked_count(ws, ws + kWsSegCounts + h * kWsSubStride, kWsSegCap(B));
         if (w >= base && w < base + c) { g = h; at = w - base; }
         base += c;
     }
-    return ws[kWsEntries + g * kWsSegCap(B) + at];
+    return worklist_checked_entry(ws, ws[kWsEntries + g * kWsSegCap(B) + at], B);
 }
 
 // Dynamic pick-up for the wave-per-problem kernels (one wave per workgroup; iteration counts differ by 2x between
@@ -282,7 +347,7 @@ struct WorkClaim {
     {
         listed = use_worklist != 0;
         segd = listed && worklist_segmented(N);
-        count = listed ? (long)ws[kWsCount] : B;
+        count = listed ? (segd ? (long)(ws[kWsCount] != 0) : worklist_checked_count(ws, ws + kWsCount, kWsEntryInts(B))) : B;
         seg = (int)(blockIdx.x & 31u);
         left = 32;
         c = -1;
@@ -295,11 +360,12 @@ struct WorkClaim {
     DQQ_D long claim_segmented(int* __restrict__ ws, long B)
     {
         while (left > 0) {
-            if (c < 0) c = __builtin_amdgcn_readfirstlane(ws[kWsSegCounts + seg * kWsSubStride]);
+            if (c < 0) c = __builtin_amdgcn_readfirstlane((int)worklist_checked_count(ws, ws + kWsSegCounts + seg * kWsSubStride, kWsSegCap(B)));
             if (c > 0) {
                 const int t = __builtin_amdgcn_readfirstlane(
                     threadIdx.x == 0 ? atomicAdd(&ws[kWsSegNext + seg * kWsSubStride], 1) : 0);
-                if (t < c) return (long)__builtin_amdgcn_readfirstlane(ws[kWsEntries + seg * kWsSegCap(B) + t]);
+                if (t >= 0 && t < c)
+                    return worklist_checked_entry(ws, (long)__builtin_amdgcn_readfirstlane(ws[kWsEntries + seg * kWsSegCap(B) + t]), B);
             }
             seg = (seg + 1) & 31;
             --left;
@@ -315,7 +381,7 @@ struct WorkClaim {
         if (count == 0) return -1;
         if (!segd) {
             const long t = __builtin_amdgcn_readfirstlane(threadIdx.x == 0 ? atomicAdd(&ws[kWsNext], 1) : 0);
-            return t < count ? (long)__builtin_amdgcn_readfirstlane(ws[kWsEntries + t]) : -1;
+            return (t >= 0 && t < count) ? worklist_checked_entry(ws, (long)__builtin_amdgcn_readfirstlane(ws[kWsEntries + t]), B) : -1;
         }
         if (!primed || !pipelined) { // the first problem, or a kernel that does not claim ahead
             ahead = claim_segmented(ws, B);
@@ -336,7 +402,7 @@ struct WorkClaim {
     {
         if (stage == 1) {
             const int t = __builtin_amdgcn_readfirstlane(flight);
-            if (t < c) {
+            if (t >= 0 && t < c) {
                 flight = ws[kWsEntries + seg * kWsSegCap(B) + t];
                 stage = 2;
             } else { // this segment is exhausted: ahead_done walks on
@@ -350,7 +416,7 @@ struct WorkClaim {
     DQQ_D void ahead_done(int* __restrict__ ws, long B)
     {
         if (!segd) return;
-        ahead = (stage == 2) ? (long)__builtin_amdgcn_readfirstlane(flight) : claim_segmented(ws, B);
+        ahead = (stage == 2) ? worklist_checked_entry(ws, (long)__builtin_amdgcn_readfirstlane(flight), B) : claim_segmented(ws, B);
         stage = 0;
         pipelined = true;
     }
@@ -373,6 +439,7 @@ struct FwdArgs {
     double* pdiag_out;         // optional (B,N): the diagonal of P, for the backward of the same problems
     unsigned char* flags_out;  // optional (B): 1 = the problem's tile was verified diagonal
     double* scratch = nullptr; // caller's scratch behind the work-list (dqq_scratch_bytes), global-memory kernels only
+    bool ref_order = false;    // DQQ_F_REFERENCE_ORDER: 16 < N <= 64 on the reference-order kernels instead of the matrix cores
 };
 
 struct BwdArgs {
@@ -397,6 +464,7 @@ struct BwdArgs {
     int* ir_steps;
     int* ws;
     double* scratch = nullptr; // see FwdArgs
+    bool ref_order = false;    // see FwdArgs
 };
 
 // Which N can solve their non-diagonal tiles inside the fast kernel (no fallback launch: an empty
@@ -445,9 +513,9 @@ hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipSt
 // bytes of scratch those kernels need for (kind, N, B): a slice per workgroup of a grid that depends on (N, B) only
 size_t any_scratch_bytes(int kind, bool backward, int N, long B);
 bool fwd_needs_any(int kind, int N); // does a call of this size reach them
-bool bwd_needs_any(int kind, int N); // (as routed now: QCQP 42 < N <= 64 only with "wave_qcqp_bwd" = 0)
-bool bwd_uses_any(int kind, int N);
-int public_max_n(int kind);           // dqq_max_n
+bool bwd_needs_any(int kind, int N, bool ref_order); // (QCQP 42 < N <= 64 only with DQQ_F_REFERENCE_ORDER)
+bool bwd_uses_any(int kind, int N, bool ref_order);
+int public_max_n(int kind, bool ref_order);           // dqq_max_n
 hipError_t launch_fwd_any(int kind, const FwdArgs& a, bool use_worklist, hipStream_t s);
 hipError_t launch_bwd_any(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);
 // lane-per-problem backward for N = 2, 4, 6, 8, QP / QCQP (bwd_lane_dense.hip): whole batches declared dense, or -- when the

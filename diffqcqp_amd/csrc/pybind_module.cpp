@@ -31,8 +31,18 @@ PYBIND11_MODULE(_dqq, m)
 {
     m.doc() = "pybind11 binding of libdiffqcqp_hip.so (include/diffqcqp_hip.h): batched ADMM QP / QCQP on MI355X";
     m.def("dqq_workspace_bytes", [](std::int64_t B) { return dqq_workspace_bytes(B); });
-    m.def("dqq_scratch_bytes", [](int kind, int pass, int N, std::int64_t B) { return dqq_scratch_bytes(kind, pass, N, B); });
-    m.def("dqq_max_n", [](int kind) { return dqq_max_n(kind); });
+    m.def("dqq_scratch_bytes", [](int kind, int pass, int N, std::int64_t B, int p_layout) {
+        return dqq_scratch_bytes(kind, pass, N, B, p_layout);
+    });
+    m.def("dqq_max_n", [](int kind, int p_layout) { return dqq_max_n(kind, p_layout); });
+    m.def("dqq_workspace_reset", [](O ws, std::size_t ws_bytes, O stream) {
+        return dqq_workspace_reset(ptr<void>(ws), ws_bytes, ptr<void>(stream));
+    });
+    m.def("dqq_workspace_status", [](O ws, std::size_t ws_bytes, O stream) {
+        int dirty = 0;
+        const int rc = dqq_workspace_status(ptr<const void>(ws), ws_bytes, ptr<void>(stream), &dirty);
+        return py::make_tuple(rc, dirty);
+    });
     m.def("dqq_version", []() { return py::bytes(dqq_version()); });
     m.def("dqq_set_option", [](const py::bytes& name, int value) { return dqq_set_option(std::string(name).c_str(), value); });
     m.def("dqq_set_feedback", [](O host_buffer, std::size_t bytes) { return dqq_set_feedback(ptr<void>(host_buffer), bytes); });

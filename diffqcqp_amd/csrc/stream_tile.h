@@ -65,6 +65,74 @@ static DQQ_D unsigned stream_tile_diag(const double* __restrict__ Pw, int limit,
     return nz;
 }
 
+// N = 8: the same stream (every chunk of the tile, no early stop), that ALSO says WHICH problems are not diagonal: a chunk
+// of 128 doubles is two whole 8 x 8 matrices -- lanes 0..31 one, lanes 32..63 the next --, so one ballot per chunk
+// classifies two problems, in scalar registers (round 5: the fused forward used to stream a non-diagonal tile a second
+// time to find this out, tile_problem_flags below: 33.5 MB of a dense 65536 x 8 batch).  Bit p of the result: problem p of
+// the tile has a non-zero off-diagonal entry.
+template <int NCH, bool GUARD>
+static DQQ_D unsigned long long stream_tile_diag_pmask8(const double* __restrict__ Pw, int limit, double* sd, int lane)
+{
+    constexpr int N = 8;
+    static_assert(NCH <= 32, "at most 64 problems per tile");
+    unsigned long long pmask = 0;
+    constexpr int U = NCH < 16 ? NCH : 16;
+#pragma unroll
+    for (int k0 = 0; k0 < NCH; k0 += U) {
+        double2 v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int f = (k0 + j) * 128 + 2 * lane;
+            if (GUARD) v[j] = f < limit ? *reinterpret_cast<const double2*>(Pw + f) : make_double2(0.0, 0.0);
+            else v[j] = *reinterpret_cast<const double2*>(Pw + f);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int f = (k0 + j) * 128 + 2 * lane;
+            const int row = f / N, r = row % N, c = f % N;
+            const unsigned b0 = nonzero_bits(v[j].x), b1 = nonzero_bits(v[j].y);
+            unsigned b;
+            if (c == r) { sd[row] = v[j].x; b = b1; }
+            else if (c + 1 == r) { sd[row] = v[j].y; b = b0; }
+            else b = b0 | b1;
+            const unsigned long long m = __ballot(b != 0);
+            const unsigned long long two = ((m & 0xffffffffull) != 0 ? 1ull : 0ull) | ((m >> 32) != 0 ? 2ull : 0ull);
+            pmask |= two << (2 * (k0 + j));
+        }
+    }
+    return pmask;
+}
+
+// N = 8, one lane per problem: the wave's tile of 64 matrices (32 KiB, contiguous) goes through LDS WHOLE -- coalesced 16-byte
+// loads in, row stride N*N + 1 doubles (conflict-free when every lane then reads its own matrix) -- and is classified on the
+// way as above.  Everything the lane needs of P afterwards (the diagonal, or the general solve's rows at every
+// refactorisation) comes from there: P is read from HBM exactly once (round 5; the one-lane layout used to read it three
+// times and more: stream, classification, the solve's own loads per refactorisation -- 240 MB per 65536 x 8 QCQP forward
+// against 46 MB algorithmic).
+template <bool GUARD>
+static DQQ_D unsigned long long stage_tile_lane8(const double* __restrict__ Pw, int nvalid, double* st, int lane)
+{
+    constexpr int NN = 64, TS = NN + 1, CPP = NN / 2;   // doubles per matrix, LDS row stride, 16-byte chunks per matrix
+    unsigned long long pmask = 0;
+    const int last = nvalid * CPP - 1;
+#pragma unroll 8
+    for (int k = 0; k < CPP; ++k) {
+        const int ch = k * 64 + lane;                   // chunk of the tile: matrix 2k + lane / 32, chunk lane % 32 of it
+        const bool in = !GUARD || ch <= last;
+        const double2 t = in ? *reinterpret_cast<const double2*>(Pw + 2 * (long)ch) : make_double2(0.0, 0.0);
+        const int pp = ch / CPP, w = ch % CPP;
+        st[pp * TS + 2 * w] = t.x;
+        st[pp * TS + 2 * w + 1] = t.y;
+        const int r = w / 4, c = 2 * (w % 4);           // entries (r, c) and (r, c + 1)
+        const unsigned b0 = nonzero_bits(t.x), b1 = nonzero_bits(t.y);
+        const unsigned b = (c == r) ? b1 : (c + 1 == r) ? b0 : (b0 | b1);
+        const unsigned long long m = __ballot(b != 0);
+        const unsigned long long two = ((m & 0xffffffffull) != 0 ? 1ull : 0ull) | ((m >> 32) != 0 ? 2ull : 0ull);
+        pmask |= two << (2 * k);
+    }
+    return pmask;
+}
+
 // Which problems of a tile are not diagonal?  The tile streamed once more, coalesced (it has just been read: L2), each chunk's
 // verdict dropped into flags[problem] (LDS, `nflags` ints, zeroed here).  Only tiles that stream_tile_diag found non-diagonal come
 // here (fwd_diag.hip): reading a lane's own matrix instead -- N*N*8 bytes from its neighbour's, 64 cache lines per load

@@ -42,7 +42,7 @@ class _device_guard:
 _MAX_WORKSPACES = 16   # cached (device, stream) pairs; the least recently used one is dropped beyond that
 _pinned = []           # workspaces handed out while a stream capture was going on: a captured graph has their address
                        # baked in, so they are never replaced, evicted or freed
-_need_cache = {}       # (kind, pas, N, B) -> bytes, cleared by set_option (dqq_scratch_bytes follows the tuning knobs)
+_need_cache = {}       # (kind, pas, N, B, flags) -> bytes: dqq_workspace_bytes + dqq_scratch_bytes are functions of exactly these
 
 
 _feedback_tried = False
@@ -71,37 +71,39 @@ def _capturing():
         return False
 
 
-def workspace_bytes(B, kind=0, pas=0, N=8):
-    """Bytes of `workspace` a call needs: the work-list + whatever scratch the kernels of (kind, pas, N, B) use -- asked
-    of the library (dqq_workspace_bytes + dqq_scratch_bytes), never guessed here."""
-    key = (int(kind), int(pas), int(N), int(B))
+def workspace_bytes(B, kind=0, pas=0, N=8, layout=0):
+    """Bytes of `workspace` a call needs: the work-list + whatever scratch the kernels of (kind, pas, N, B, layout flags) use
+    -- asked of the library (dqq_workspace_bytes + dqq_scratch_bytes), never guessed here."""
+    key = (int(kind), int(pas), int(N), int(B), int(layout) & _capi.F_REFERENCE_ORDER)
     need = _need_cache.get(key)
     if need is None:
         lib = _capi.lib()
         need = lib.dqq_workspace_bytes(int(B)) + lib.dqq_scratch_bytes(*key)
+        if len(_need_cache) >= 1024:   # (B varies freely in a caller's hands: bounded)
+            _need_cache.clear()
         _need_cache[key] = need
     return need
 
 
-def make_workspace(device, B, kind=0, pas=0, N=8):
+def make_workspace(device, B, kind=0, pas=0, N=8, layout=0):
     """A caller-owned workspace for the `workspace=` argument of the ops below (int32, zero-initialised work-list header,
     uninitialised scratch behind it).  A caller that captures ops calls into a HIP graph should own one per stream and
     keep it alive as long as the graph: the captured launches hold its address."""
     lib = _capi.lib()
     head = lib.dqq_workspace_bytes(int(B))
-    need = max(workspace_bytes(B, kind, pas, N), 4096)
+    need = max(workspace_bytes(B, kind, pas, N, layout), 4096)
     ws = torch.empty((need + 3) // 4, dtype=torch.int32, device=device)
-    ws[: (head + 3) // 4].zero_()     # only the work-list must start zeroed; the scratch needs no initialisation
+    ws[: (head + 3) // 4].zero_()     # only the work-list must start zeroed (= dqq_workspace_reset); the scratch needs no initialisation
     return ws
 
 
-def _workspace(device, B, stream=None, kind=0, pas=0, N=8, given=None):
+def _workspace(device, B, stream=None, kind=0, pas=0, N=8, given=None, layout=0):
     """The work-list (+ the scratch of the global-memory kernels behind it, when (kind, pas, N) needs any): the
     caller's (`given`, checked for size) or one cached per (device, stream); the kernels leave the work-list empty again
     (include/diffqcqp_hip.h: dqq_workspace_bytes, dqq_scratch_bytes).
     Lifetime rule of the cache: an entry is replaced when a larger call arrives and evicted beyond 16 streams -- except
     entries that were handed out during a stream capture, which stay alive for the life of the process."""
-    need = workspace_bytes(B, kind, pas, N)
+    need = workspace_bytes(B, kind, pas, N, layout)
     if given is not None:
         if not (given.is_cuda and given.dtype is torch.int32 and given.is_contiguous() and given.numel() * 4 >= need):
             raise ValueError("workspace must be a contiguous int32 GPU tensor of at least %d bytes (ops.make_workspace)" % need)
@@ -112,10 +114,11 @@ def _workspace(device, B, stream=None, kind=0, pas=0, N=8, given=None):
     ws = _workspaces.get(key)
     cap = _capturing()
     if ws is None or ws.numel() * 4 < need:
-        if cap and ws is None:
-            raise RuntimeError("diffqcqp_amd.ops: first call on this stream inside a stream capture -- the workspace would "
-                               "be allocated and zero-filled inside the capture; warm the stream up first or pass workspace=")
-        ws = make_workspace(device, B, kind, pas, N)
+        if cap:   # (created OR grown: either way an allocation and a zero-fill would be captured, and the cache entry replaced)
+            raise RuntimeError("diffqcqp_amd.ops: a call inside a stream capture needs a workspace that is not there yet (first "
+                               "call on this stream, or a larger batch than any before) -- it would be allocated and zero-filled "
+                               "inside the capture; warm the stream up with the largest call first or pass workspace=")
+        ws = make_workspace(device, B, kind, pas, N, layout)
         _workspaces.pop(key, None)
         _workspaces[key] = ws
         while len(_workspaces) > _MAX_WORKSPACES:
@@ -155,8 +158,9 @@ def _out(t, shape, name):
 
 
 def _dims(P, q, layout):
+    """layout: DQQ_P_* optionally ORed with _capi.F_REFERENCE_ORDER (include/diffqcqp_hip.h), passed to the C ABI as is."""
     B, N = q.shape[0], q.shape[1]
-    pshape = (B, N) if layout == _capi.P_DIAG else (B, N, N)
+    pshape = (B, N) if (layout & 0xff) == _capi.P_DIAG else (B, N, N)
     return B, N, pshape
 
 
@@ -176,7 +180,7 @@ def qp_forward(P, q, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, layout=_cap
     x = _out(out, (B, N, 1), "out") if out is not None else torch.empty((B, N, 1), dtype=torch.float64, device=q.device)
     iters = torch.empty(B, dtype=torch.int32, device=q.device) if return_iters else None
     stream = _raw_stream(q.device.index)
-    ws = _workspace(q.device, B, stream, 0, 0, N, workspace)
+    ws = _workspace(q.device, B, stream, 0, 0, N, workspace, layout)
     with _device_guard(q.device):
         pd, fl = cache if cache is not None else (None, None)
         rc = _capi.lib().dqq_qp_fwd_f64(_ptr(P), _ptr(q), _ptr(x), B, N, float(eps), float(mu_prox), int(max_iter),
@@ -195,7 +199,7 @@ def qcqp_forward(P, q, l_n, mu, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, 
     x = _out(out, (B, N, 1), "out") if out is not None else torch.empty((B, N, 1), dtype=torch.float64, device=q.device)
     iters = torch.empty(B, dtype=torch.int32, device=q.device) if return_iters else None
     stream = _raw_stream(q.device.index)
-    ws = _workspace(q.device, B, stream, 1, 0, N, workspace)
+    ws = _workspace(q.device, B, stream, 1, 0, N, workspace, layout)
     with _device_guard(q.device):
         pd, fl = cache if cache is not None else (None, None)
         rc = _capi.lib().dqq_qcqp_fwd_f64(_ptr(P), _ptr(q), _ptr(l_n), _ptr(mu), _ptr(x), B, N, float(eps),
@@ -215,7 +219,7 @@ def boxqp_forward(P, q, l_min, l_max, eps, max_iter, v=None, mu_prox=1e-7, adapt
     x = _out(out, (B, N, 1), "out") if out is not None else torch.empty((B, N, 1), dtype=torch.float64, device=q.device)
     iters = torch.empty(B, dtype=torch.int32, device=q.device) if return_iters else None
     stream = _raw_stream(q.device.index)
-    ws = _workspace(q.device, B, stream, 2 if v is None else 3, 0, N, workspace)
+    ws = _workspace(q.device, B, stream, 2 if v is None else 3, 0, N, workspace, layout)
     with _device_guard(q.device):
         pd, fl = cache if cache is not None else (None, None)
         tail = (B, N, float(eps), float(mu_prox), int(max_iter), int(bool(adaptive_rho)), layout, _ptr(iters), _ptr(pd),
@@ -245,8 +249,8 @@ def qp_backward(P, q, x, grad_x, need_P=True, need_q=True, layout=_capi.P_AUTO, 
         gq = torch.empty((B, N, 1), dtype=torch.float64, device=dev) if need_q else None
     steps = torch.empty(B, dtype=torch.int32, device=dev) if return_steps else None
     stream = _raw_stream(dev.index)
-    ws = _workspace(dev, B, stream, 0, 1, N, workspace)
-    if not _feedback_tried and layout == _capi.P_AUTO and N <= 8:
+    ws = _workspace(dev, B, stream, 0, 1, N, workspace, layout)
+    if not _feedback_tried and (layout & 0xff) == _capi.P_AUTO and N <= 8:
         feedback_default()
     with _device_guard(dev):
         pd, fl = cache if cache is not None else (None, None)
@@ -277,8 +281,8 @@ def qcqp_backward(P, q, l_n, mu, x, grad_x, need=(True, True, True, True), layou
         gm = torch.empty((B, N // 2, 1), dtype=torch.float64, device=dev) if need[3] else None
     steps = torch.empty(B, dtype=torch.int32, device=dev) if return_steps else None
     stream = _raw_stream(dev.index)
-    ws = _workspace(dev, B, stream, 1, 1, N, workspace)
-    if not _feedback_tried and layout == _capi.P_AUTO and N <= 8:
+    ws = _workspace(dev, B, stream, 1, 1, N, workspace, layout)
+    if not _feedback_tried and (layout & 0xff) == _capi.P_AUTO and N <= 8:
         feedback_default()
     with _device_guard(dev):
         gam, dgam = duals if duals is not None else (None, None)
@@ -311,7 +315,7 @@ def boxqp_backward(P, q, l_min, l_max, x, grad_x, need=(True, True, True, True),
         ghi = torch.empty((B, N, 1), dtype=torch.float64, device=dev) if need[3] else None
     steps = torch.empty((B, 2), dtype=torch.int32, device=dev) if return_steps else None
     stream = _raw_stream(dev.index)
-    ws = _workspace(dev, B, stream, 2, 1, N, workspace)
+    ws = _workspace(dev, B, stream, 2, 1, N, workspace, layout)
     with _device_guard(dev):
         gam, dgam = duals if duals is not None else (None, None)
         pd, fl = cache if cache is not None else (None, None)

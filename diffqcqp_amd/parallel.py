@@ -60,7 +60,11 @@ class _RaggedGather:
         return True
 
     def is_completed(self):
-        return self.done or (self.work is not None and self.work.is_completed())
+        """True once `out` holds the gathered batch -- like the equal-shard handle, whose completion means the result is
+        there: when the collective has completed the trim is run (enqueued) here, before saying so."""
+        if not self.done and (self.work is None or self.work.is_completed()):
+            self.wait()
+        return self.done
 
 
 def gather_scratch_rows(B_total, world):
@@ -97,6 +101,7 @@ def gather_batch(x_local, B_total, group=None, async_op=False, out=None, scratch
         scratch = torch.empty(((world + 1) * m,) + tail, dtype=x_local.dtype, device=x_local.device)
     else:
         assert scratch.shape[0] >= (world + 1) * m and tuple(scratch.shape[1:]) == tail and scratch.is_contiguous()
+        assert scratch.dtype == x_local.dtype and scratch.device == x_local.device, "scratch must match x_local's dtype and device"
     padded, buf = scratch[:m], scratch[m: (world + 1) * m]
     padded[: sizes[rank]].copy_(x_local)
     if sizes[rank] < m:

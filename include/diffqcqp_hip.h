@@ -19,14 +19,14 @@
  *     the default stream) and the call returns without synchronising;
  *   - return value: 0 on success, <0 for an invalid argument (DQQ_E_*), >0 a
  *     hipError_t from the launch (the launch's own status: the calling thread's
- *     sticky HIP error is neither consumed nor cleared).  Nothing throws.  The only
- *     process-wide state is the tuning knobs of dqq_set_option() and the optional
- *     feedback buffer of dqq_set_feedback(); with the knobs fixed, a call's results,
- *     bit for bit, are a function of its arguments alone (no history, thread-safe,
- *     any stream) -- and so are the kernels it launches unless a feedback buffer is
- *     registered, which lets the QP / QCQP forward of N = 8 and one launch of the
- *     backward of N <= 8 be chosen between two kernels (lane layouts) with identical
- *     results (see dqq_set_feedback);
+ *     sticky HIP error is neither consumed nor cleared).  Nothing throws.  A call's
+ *     results, bit for bit, are a function of its arguments alone (no history,
+ *     thread-safe, any stream) -- and so are the kernels it launches.  The one piece
+ *     of process-wide state is OPTIONAL and changes time only: with a feedback buffer
+ *     registered (dqq_set_feedback) an N <= 8 DQQ_P_AUTO call is routed between
+ *     kernels of identical results by what the previous backward of its kind found.
+ *     There are no tuning knobs in this library (a developer build, -DDQQ_TUNING,
+ *     has them: csrc/tuning.h);
  *   - like the reference (Solver.cpp:76, :100), numerical failure is not
  *     signalled: a non-PD P or L=0 yields NaNs in the output;
  *   - `warm_start` does not appear: the reference accepts it and overwrites it
@@ -53,6 +53,13 @@ extern "C" {
 #define DQQ_P_AUTO 0
 #define DQQ_P_DENSE 1
 #define DQQ_P_DIAG 2
+/* Per-call flag, ORed into p_layout: for 16 < N <= 64 the general (non-diagonal) path runs its kernels in the REFERENCE's
+ * summation order (LDS wave kernels; QCQP backward beyond N = 42: a global-memory kernel that needs dqq_scratch_bytes of
+ * scratch) instead of the register-resident kernels on the f64 matrix cores, which re-associate sums: forward x within
+ * 1e-6 with 90+ % identical iteration counts, gradients of the cond ~1e9 Tikhonov systems within 5e-7 (grad_P, grad_q) /
+ * 8e-6 (grad_l_n, grad_mu) relative of the reference-order evaluation -- the evaluation-order noise of the reference's own
+ * formulas.  10-30x slower; for parity studies.  No effect for N <= 16 (always reference order) or on diagonal tiles. */
+#define DQQ_F_REFERENCE_ORDER 0x100
 
 #define DQQ_E_NULLPTR (-1)     /* a required pointer is NULL */
 #define DQQ_E_BAD_SIZE (-2)    /* B < 0, N < 1, odd N for QCQP */
@@ -68,22 +75,38 @@ extern "C" {
  * streams. */
 size_t dqq_workspace_bytes(int64_t B);
 
+/* Work-list hygiene.  The kernels do not trust the work-list header (csrc/launch.h): a header that did not start at zero --
+ * a workspace that was never initialised, memory written over by someone else, a launch chain cut short by an error -- is
+ * REPAIRED by the next DQQ_P_AUTO call where that is possible (exit tickets and pick-up counters are re-zeroed by the fast
+ * kernel; a stale or out-of-range count is clamped; an entry that is not a problem of the batch is replaced by problem 0,
+ * which is then solved once more to the same values) and REPORTED where it is not (problems that cannot be queued get NaN
+ * outputs): nothing is read or written out of bounds and no problem is silently left unsolved.  Either way a sticky "dirty"
+ * word is set in the header.
+ *   dqq_workspace_reset   zero-fills the header on `stream` (asynchronous): the state a fresh workspace must be in.  The
+ *                         recommended way to initialise one (a plain zero-fill of the first dqq_workspace_bytes(0) bytes is
+ *                         equivalent).
+ *   dqq_workspace_status  *dirty = 1 if any kernel has found the header inconsistent since the last reset.  SYNCHRONISES
+ *                         `stream` (a 4-byte read-back): a diagnostic, never on a hot path. */
+int dqq_workspace_reset(void* workspace, size_t workspace_bytes, void* stream);
+int dqq_workspace_status(const void* workspace, size_t workspace_bytes, void* stream, int* dirty);
+
 /* The C ABI never allocates: every buffer, scratch included, is the caller's.  For sizes beyond the register / LDS
  * kernels of the general path (N > dqq_max_n(..), below) a workgroup-per-problem kernel works out of global memory and
  * needs this many bytes of scratch IN ADDITION to dqq_workspace_bytes(B), in the same `workspace` buffer (the work-list
  * first, the scratch behind it; no initialisation needed).  kind: 0 QP, 1 QCQP, 2 box QP, 3 signed box QP; pass: 0
- * forward, 1 backward.  A function of its arguments and of the tuning knobs as they stand (it reports what the kernels
- * a call launches NOW use: QCQP backward 42 < N <= 64 needs scratch only with "wave_qcqp_bwd" = 0); 0 for every size
- * the register / LDS kernels hold (all BASELINE configs).  A call whose workspace is smaller than dqq_workspace_bytes(B) + dqq_scratch_bytes(..) returns
+ * forward, 1 backward; p_layout: as the call will pass it (only DQQ_F_REFERENCE_ORDER matters: QCQP backward 42 < N <= 64
+ * needs scratch only with it).  A function of its arguments; 0 for every size the register / LDS kernels hold (all
+ * BASELINE configs).  A call whose workspace is smaller than dqq_workspace_bytes(B) + dqq_scratch_bytes(..) returns
  * DQQ_E_WORKSPACE -- with DQQ_P_DENSE too, which otherwise needs no workspace at all.  Since nothing is allocated
  * or freed, a forward + backward pair can be captured into a HIP graph (tests/test_gpu_graph_capture.py). */
-size_t dqq_scratch_bytes(int kind, int pass, int N, int64_t B);
+size_t dqq_scratch_bytes(int kind, int pass, int N, int64_t B, int p_layout);
 
 /* There is no size limit (the reference has none, Solver.cpp:61): this returns the largest N the register / LDS
  * kernels of the general path hold -- kind 0 = QP forward/backward and the box forwards (64), 1 = QCQP forward (64),
- * 2 = QCQP backward (64; 42 with "wave_qcqp_bwd" = 0), 3 = box QP backward (21).  Beyond it a workgroup-per-problem kernel works out of global
- * memory, in the reference's operation order, on the caller's scratch (dqq_scratch_bytes). */
-int dqq_max_n(int kind);
+ * 2 = QCQP backward (64; 42 with DQQ_F_REFERENCE_ORDER in p_layout), 3 = box QP backward (21).  Beyond it a
+ * workgroup-per-problem kernel works out of global memory, in the reference's operation order, on the caller's scratch
+ * (dqq_scratch_bytes). */
+int dqq_max_n(int kind, int p_layout);
 
 /* Replaces the loop qcqp.py:29-31 (QPFn2.forward -> diffqcqp.solveQP,
  * pybindings.cpp:17-22 -> Solver::solveQP, Solver.cpp:61-123).
@@ -166,57 +189,12 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
                       const double* pdiag, const unsigned char* diag_flags, void* workspace, size_t workspace_bytes,
                       void* stream);
 
-/* Tuning knobs (process-wide, read at launch time).  Unknown name -> DQQ_E_BAD_OPTION.
- *   "fwd_lpp"        lanes per problem of the diagonal forward kernel (0 = built-in choice from B)
- *   "wpb"            waves per workgroup of the diagonal kernels (1 or 4; 0 = built-in)
- *   "fuse_fallback"  DQQ_P_AUTO, N <= 16: solve non-diagonal tiles inside the fast kernel (1), queue them
- *                    for the dense kernel launched behind it (0), or decide from (N, B) (-1, default: the
- *                    forward inside for N = 2 and N = 8 at every batch size and for N = 4 up to 131072 problems,
- *                    where it solves a whole tile at once on lanes of the fast path; the backward, whose in-kernel routine takes one problem per wave at
- *                    a time, never: its non-diagonal tiles are queued at every batch size)
- *   "fwd_respread"   diagonal fast path, N = 8 on two lanes per problem: once at most this many (0..16, default
- *                    16; 0 = never) of a wave's 32 problems are still iterating they move onto four lanes per
- *                    problem and finish with half the arithmetic per lane.  Bit-identical results.
- *   "fwd_respread2"  the same again: once at most this many (0..8, default 8; 0 = never) of the re-spread problems are
- *                    still iterating they move onto eight lanes per problem, one coordinate per lane (a long tail costs
- *                    its instruction count per iteration).  Bit-identical results.
- *   "fwd_compact"    diagonal fast path, N = 8: repack the tiles of a workgroup as their problems stop (1), or
- *                    leave every tile to its wave (0, default: at the bench shape the barriers cost more than the
- *                    saved wave-iterations; it pays for heavy-tailed iteration counts).  Bit-identical results.
- *   "dense_teams"    general path, backward: pack 64/T problems per wave for small N (1, default) or one
- *                    problem per wave (0)
- *   "small_fwd"      general path, N = 10..16 forward: team-per-problem kernel (1, default) or the
- *                    wave-per-problem kernel (0)
- *   "small_bwd"      general path, even N <= 16 backward (QP, QCQP): statically sized team kernel (1, default) or the
- *                    wave / team kernel with run-time sizes (0)
- *   "lane_bwd"       general path, N = 2, 4, 6, 8 backward (QP, QCQP), B >= 16384: lane-per-problem kernel (1, default) for
- *                    DQQ_P_DENSE batches and -- with dqq_set_feedback -- for the long work-lists of DQQ_P_AUTO batches, or
- *                    always the team kernel (0).  Bit-identical results.
- *   "lane_dense"     general path, N = 2..8 forward: lane-per-problem kernel (1, default) or the
- *                    wave-per-problem kernel (0)
- *   "lane_defer"     general forward for N <= 16 (lane-per-problem kernel, the group solve inside the fused fast
- *                    kernel, team-per-problem kernel): the refactorisation after a rho update runs every this many trips of the wave's loop,
- *                    for all problems that changed rho since the last one (0, default: 4 for the QCQP, 6 for the other
- *                    kinds; 1 = in the trip of the update).  Bit-identical results.
- *   "dense_wave64"   general path, 16 < N <= 64 forward and QP backward: register-resident wave-per-problem kernels
- *                    on the f64 matrix cores (1, default) or the LDS wave kernel in the reference's summation order (0)
- *   "wave_qcqp_bwd"  general path, QCQP backward, 16 < N <= 64: register-resident block-Cholesky kernels (1, default;
- *                    they re-associate the sums of the cond ~1e9 Tikhonov systems: gradients within 5e-7 (grad_P,
- *                    grad_q) / 8e-6 (grad_l_n, grad_mu) relative of the reference-order evaluation, which is the
- *                    evaluation-order noise of the reference's own formulas) or the reference-order kernels (0: LDS
- *                    wave kernel up to N = 42, global-memory kernel beyond -- 1e-9, 10-30x slower, and 42 < N <= 64
- *                    then needs dqq_scratch_bytes of scratch)
- *   "fwd_feedback"   DQQ_P_AUTO forward, N = 8, QP / QCQP, with dqq_set_feedback: one lane per problem instead of two when the
- *                    last backward of this kind, N and B found half of the batch or more non-diagonal (1, default), or
- *                    never look at the word (0).  Bit-identical results.  "fwd_feedback_routes" counts those launches.
- *   "bwd_skip_classify"  DQQ_P_AUTO backward, N <= 8, QP / QCQP, with dqq_set_feedback: when the last two backwards of this
- *                    kind, N and B found three quarters of the batch or more non-diagonal, skip the fast path's launch and solve the whole batch
- *                    with the lane-per-problem kernel, which recounts (1, default), or never (0).  Bit-identical results.
- *                    "bwd_whole_batches" counts those calls.
- *   "lane_list_drains"  not a knob: a counter of the drain launches that dqq_set_feedback's word routed to the
- *                    lane-per-problem kernel (read with dqq_get_option, reset by setting it)
- *   "auto_fallback"  0 skips the dense-kernel launch of DQQ_P_AUTO -- measurement only: non-diagonal
- *                    tiles are then left unsolved (default 1) */
+/* Route counters (diagnostics): how many launches the feedback hint (dqq_set_feedback) has sent down its alternative
+ * routes since the counter was last reset.  Names: "lane_list_drains" (drain launches on the lane-per-problem backward),
+ * "bwd_whole_batches" (DQQ_P_AUTO backwards solved whole by that kernel), "fwd_feedback_routes" (N = 8 forwards on one
+ * lane per problem).  dqq_set_option(name, v) stores v (0 resets); any other name -> DQQ_E_BAD_OPTION.  These are the only
+ * names this library knows and none of them changes what a call does.  (A developer build, -DDQQ_TUNING, also accepts the
+ * kernel-selection knobs of csrc/tuning.h; they change time, never results.) */
 int dqq_set_option(const char* name, int value);
 int dqq_get_option(const char* name, int* value);
 

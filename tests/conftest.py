@@ -13,6 +13,58 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# ---- kernel-selection knobs in the tests -----------------------------------------------------------------------------------
+# The shipped library has none (csrc/tuning.h: compile-time constants; dqq_set_option knows the three route counters only).
+# Tests that drive the alternative kernels -- other lane layouts, the queued instead of the fused fallback, ... -- need the
+# DEVELOPER build (DQQ_EXTRA_FLAGS=-DDQQ_TUNING python -m diffqcqp_amd.build) and SKIP on the shipped one; profiles/ holds
+# the log of the suite run on that build.  The two former knobs that change NUMERICS ("dense_wave64", "wave_qcqp_bwd": the
+# reference-order kernels for 16 < N <= 64) are a per-call flag of the C ABI now (DQQ_F_REFERENCE_ORDER): `knob` keeps a
+# test-side switch for them and `OpsWithFlags` (the `ops` fixture of test_gpu_parity.py) ORs the flag into every call's layout.
+KNOB_DEFAULTS = {"fwd_lpp": 0, "wpb": 0, "fuse_fallback": -1, "fwd_compact": 0, "fwd_respread": 16, "fwd_respread2": 8,
+                 "lane_dense": 1, "lane_defer": 0, "dense_teams": 1, "small_fwd": 1, "small_bwd": 1, "lane_bwd": 1,
+                 "fwd_feedback": 1, "bwd_skip_classify": 1}
+COUNTERS = ("lane_list_drains", "bwd_whole_batches", "fwd_feedback_routes")
+_ref_order = {"dense_wave64": 1, "wave_qcqp_bwd": 1}
+
+
+def reference_order_flag():
+    """F_REFERENCE_ORDER if a test has switched either of the two numerics switches off, else 0."""
+    from diffqcqp_amd import _capi
+    return _capi.F_REFERENCE_ORDER if (_ref_order["dense_wave64"] == 0 or _ref_order["wave_qcqp_bwd"] == 0) else 0
+
+
+def knob(name, value):
+    from diffqcqp_amd import _capi
+    if name in _ref_order:
+        _ref_order[name] = int(value)
+        return
+    if name in COUNTERS:
+        return _capi.set_option(name, value)
+    assert name in KNOB_DEFAULTS, name
+    if _capi.tuning_build():
+        return _capi.set_option(name, value)
+    if int(value) != KNOB_DEFAULTS[name]:
+        pytest.skip("knob %s: needs the developer build of the library (-DDQQ_TUNING, csrc/tuning.h)" % name)
+
+
+class OpsWithFlags:
+    """diffqcqp_amd.ops with the test-side reference-order switch ORed into every call's `layout`."""
+    _WRAPPED = ("qp_forward", "qcqp_forward", "boxqp_forward", "qp_backward", "qcqp_backward", "boxqp_backward")
+
+    def __init__(self, ops):
+        self._ops = ops
+
+    def __getattr__(self, name):
+        fn = getattr(self._ops, name)
+        if name not in self._WRAPPED:
+            return fn
+
+        def call(*a, **kw):
+            kw["layout"] = kw.get("layout", 0) | reference_order_flag()
+            return fn(*a, **kw)
+        return call
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure).  Built on demand with oracle/Makefile."""

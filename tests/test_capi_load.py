@@ -40,21 +40,20 @@ def test_header_symbols_are_exported(lib):
 
 def test_version_and_limits(lib):
     assert b"gfx950" in lib.dqq_version()
-    assert lib.dqq_max_n(0) == 64 and lib.dqq_max_n(1) == 64 and lib.dqq_max_n(2) == 64 and lib.dqq_max_n(3) == 21
+    assert lib.dqq_max_n(0, 0) == 64 and lib.dqq_max_n(1, 0) == 64 and lib.dqq_max_n(2, 0) == 64 and lib.dqq_max_n(3, 0) == 21
     assert lib.dqq_workspace_bytes(0) >= 16
     assert lib.dqq_workspace_bytes(65536) >= 4 * 65536
     # scratch of the global-memory kernels: the caller's, a function of (kind, pass, N, B); 0 for every BASELINE config
     for kind, pas, N, B in ((0, 0, 8, 65536), (1, 0, 8, 65536), (1, 1, 8, 65536), (0, 0, 32, 262144), (0, 1, 32, 262144),
                             (0, 0, 64, 65536), (0, 1, 64, 65536)):
-        assert lib.dqq_scratch_bytes(kind, pas, N, B) == 0
-    assert lib.dqq_scratch_bytes(0, 0, 65, 10) > 0 and lib.dqq_scratch_bytes(1, 1, 66, 10) > 0
-    assert lib.dqq_scratch_bytes(1, 1, 44, 10) == 0 and lib.dqq_scratch_bytes(1, 1, 64, 10) == 0   # register-resident kernels
-    assert lib.dqq_set_option(b"wave_qcqp_bwd", 0) == 0        # the reference-order route needs (and demands) scratch
-    assert lib.dqq_scratch_bytes(1, 1, 44, 10) > 0 and lib.dqq_max_n(2) == 42
-    assert lib.dqq_set_option(b"wave_qcqp_bwd", 1) == 0
-    assert lib.dqq_scratch_bytes(2, 1, 22, 10) > 0 and lib.dqq_scratch_bytes(3, 1, 200, 10) == 0
-    assert lib.dqq_scratch_bytes(0, 0, 65, 4) * 2 == lib.dqq_scratch_bytes(0, 0, 65, 8)   # a slice per workgroup
-    assert lib.dqq_scratch_bytes(0, 0, 65, 10 ** 6) == lib.dqq_scratch_bytes(0, 0, 65, 10 ** 7)  # persistent grid
+        assert lib.dqq_scratch_bytes(kind, pas, N, B, 0) == 0
+    assert lib.dqq_scratch_bytes(0, 0, 65, 10, 0) > 0 and lib.dqq_scratch_bytes(1, 1, 66, 10, 0) > 0
+    assert lib.dqq_scratch_bytes(1, 1, 44, 10, 0) == 0 and lib.dqq_scratch_bytes(1, 1, 64, 10, 0) == 0   # register-resident kernels
+    REF = 0x100   # DQQ_F_REFERENCE_ORDER, a per-call flag: the reference-order route needs (and demands) scratch
+    assert lib.dqq_scratch_bytes(1, 1, 44, 10, 1 | REF) > 0 and lib.dqq_max_n(2, REF) == 42 and lib.dqq_max_n(2, 0) == 64
+    assert lib.dqq_scratch_bytes(2, 1, 22, 10, 0) > 0 and lib.dqq_scratch_bytes(3, 1, 200, 10, 0) == 0
+    assert lib.dqq_scratch_bytes(0, 0, 65, 4, 0) * 2 == lib.dqq_scratch_bytes(0, 0, 65, 8, 0)   # a slice per workgroup
+    assert lib.dqq_scratch_bytes(0, 0, 65, 10 ** 6, 0) == lib.dqq_scratch_bytes(0, 0, 65, 10 ** 7, 0)  # persistent grid
 
 
 def test_argument_validation_without_gpu(lib):
@@ -76,6 +75,30 @@ def test_argument_validation_without_gpu(lib):
     # DQQ_P_DENSE beyond the register / LDS kernels: the scratch is the caller's, nothing is allocated inside
     assert f(one, one, one, 4, 80, 1e-7, 1e-7, 10, 1, 1, None, None, None, None, 0, None) == -5
     assert lib.dqq_set_option(b"no_such_knob", 1) == -6
+    # the shipped library has no kernel-selection knobs (csrc/tuning.h): the three route counters are all dqq_set_option knows
+    v = ctypes.c_int(7)
+
+    def get(name):   # (rc, value) through either binding
+        if isinstance(lib, ctypes.CDLL):
+            rc = lib.dqq_get_option(name, ctypes.byref(v))
+            return rc, v.value
+        return tuple(lib.dqq_get_option(name))
+    tuning = get(b"fwd_lpp")[0] == 0
+    for name in (b"lane_list_drains", b"bwd_whole_batches", b"fwd_feedback_routes"):
+        assert lib.dqq_set_option(name, 0) == 0 and get(name) == (0, 0)
+    if not tuning:
+        for name in (b"fwd_lpp", b"wpb", b"fuse_fallback", b"auto_fallback", b"dense_wave64", b"wave_qcqp_bwd", b"lane_dense",
+                     b"lane_defer", b"fwd_respread", b"fwd_compact", b"dense_teams", b"small_bwd", b"lane_bwd"):
+            assert lib.dqq_set_option(name, 1) == -6, name
+    # unknown flag bits in p_layout are refused; the reference-order flag is accepted with every layout
+    assert f(one, one, one, 4, 8, 1e-7, 1e-7, 10, 1, 0x200, None, None, None, None, 0, None) == -4
+    assert f(one, one, one, 4, 8, 1e-7, 1e-7, 10, 1, 0x103, None, None, None, None, 0, None) == -4
+    # the work-list hygiene entry points validate their arguments without touching the device
+    assert lib.dqq_workspace_reset(None, 0, None) == -1 and lib.dqq_workspace_reset(one, 16, None) == -5
+    if isinstance(lib, ctypes.CDLL):
+        assert lib.dqq_workspace_status(None, 0, None, None) == -1 and lib.dqq_workspace_status(one, 16, None, ctypes.byref(v)) == -5
+    else:
+        assert lib.dqq_workspace_status(None, 0, None)[0] == -1 and lib.dqq_workspace_status(one, 16, None)[0] == -5
     # the feedback buffer: NULL unregisters; a buffer too small or misaligned is refused before anything touches it
     assert lib.dqq_set_feedback(None, 0) == 0
     assert lib.dqq_set_feedback(4096, 64) == -2 and lib.dqq_set_feedback(4100, 128) == -2
@@ -108,7 +131,7 @@ def test_header_is_plain_c(tmp_path):
     import subprocess
     src = tmp_path / "use_header.c"
     src.write_text('#include "diffqcqp_hip.h"\n'
-                   "int main(void) { return dqq_max_n(0) == 64 && dqq_workspace_bytes(0) >= 16 ? 0 : 1; }\n")
+                   "int main(void) { return dqq_max_n(0, 0) == 64 && dqq_workspace_bytes(0) >= 16 ? 0 : 1; }\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
                            "-c", str(src), "-o", str(tmp_path / "use_header.o")])

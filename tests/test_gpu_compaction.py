@@ -9,14 +9,14 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import make_problem
+from conftest import make_problem, knob
 
 pytestmark = pytest.mark.gpu
 
 
 def _run(kind, d, eps, max_iter, compact, layout=0):
     from diffqcqp_amd import _capi, ops
-    _capi.set_option("fwd_compact", compact)
+    knob("fwd_compact", compact)
     try:
         B, N = d["q"].shape[0], d["q"].shape[1]
         x = torch.full((B, N, 1), float("nan"), dtype=torch.float64, device="cuda")
@@ -29,7 +29,7 @@ def _run(kind, d, eps, max_iter, compact, layout=0):
         torch.cuda.synchronize()
         return x.cpu().numpy(), it.cpu().numpy()
     finally:
-        _capi.set_option("fwd_compact", 0)  # the default
+        knob("fwd_compact", 0)  # the default
 
 
 @pytest.mark.parametrize("kind", ["qp", "qcqp"])
@@ -104,15 +104,15 @@ def test_compaction_heavy_tail_distribution():
 
 def _run_respread(kind, d, eps, max_iter, at, lpp=2, at2=0):
     from diffqcqp_amd import _capi
-    _capi.set_option("fwd_respread", at)
-    _capi.set_option("fwd_respread2", at2)
-    _capi.set_option("fwd_lpp", lpp)
+    knob("fwd_respread", at)
+    knob("fwd_respread2", at2)
+    knob("fwd_lpp", lpp)
     try:
         return _run(kind, d, eps, max_iter, 0)
     finally:
-        _capi.set_option("fwd_respread", 16)  # the defaults
-        _capi.set_option("fwd_respread2", 8)
-        _capi.set_option("fwd_lpp", 0)
+        knob("fwd_respread", 16)  # the defaults
+        knob("fwd_respread2", 8)
+        knob("fwd_lpp", 0)
 
 
 @pytest.mark.parametrize("kind", ["qp", "qcqp"])

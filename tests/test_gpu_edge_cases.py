@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import make_problem
+from conftest import make_problem, knob
 from test_gpu_parity import (check_backward_exact, check_dense_backward, check_forward, dev, hip_bwd, hip_fwd, npy, oracle_bwd, oracle_fwd,
                              ops)  # noqa: F401  (ops is a fixture)
 
@@ -241,13 +241,13 @@ def test_lane_kernel_deferred_refactorisation_is_bit_identical(oracle, ops, kind
                                      return_iters=True)
         return hip_fwd(ops, kind, g, layout=1, eps=eps, max_iter=max_iter)
 
-    _capi.set_option("fuse_fallback", 0)   # (N = 8, small B: DQQ_P_DENSE would otherwise take the group solve)
+    knob("fuse_fallback", 0)   # (N = 8, small B: DQQ_P_DENSE would otherwise take the group solve)
     try:
         for eps, max_iter in ((1e-7, 1000), (1e-10, 1000), (1e-7, 23), (1e-7, 7), (1e-7, 1)):
-            _capi.set_option("lane_defer", 1)
+            knob("lane_defer", 1)
             x1, it1 = fwd(eps, max_iter)
             for defer in (0, 2, 3, 4, 7, 64):
-                _capi.set_option("lane_defer", defer)
+                knob("lane_defer", defer)
                 xd, itd = fwd(eps, max_iter)
                 assert torch.equal(it1, itd), (eps, max_iter, defer)
                 assert torch.equal(torch.nan_to_num(x1, nan=12345.0), torch.nan_to_num(xd, nan=12345.0)), (eps, max_iter, defer)
@@ -257,5 +257,5 @@ def test_lane_kernel_deferred_refactorisation_is_bit_identical(oracle, ops, kind
             if max_iter < 1000:
                 assert int(it1.max()) <= max_iter
     finally:
-        _capi.set_option("lane_defer", 0)
-        _capi.set_option("fuse_fallback", -1)
+        knob("lane_defer", 0)
+        knob("fuse_fallback", -1)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import make_problem
+from conftest import make_problem, knob
 
 pytestmark = pytest.mark.gpu
 
@@ -106,7 +106,7 @@ def test_a_captured_call_ignores_the_feedback_word(ops, kind):
         assert _capi.feedback_words()[slot] == (B, B) and _capi.feedback_streaks()[slot] >= 2
         eager = {k: t[k].clone() for k in outs}
         for name in ("fwd_feedback_routes", "bwd_whole_batches", "lane_list_drains"):
-            _capi.set_option(name, 0)
+            knob(name, 0)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=s):
             _run(ops, kind, t, 0)
@@ -142,22 +142,18 @@ def test_scratch_is_the_callers(ops):
         for pas in (0, 1):
             for N in (2, 8, 21, 32, 64):
                 if (kind, pas) == (2, 1) and N > 21:
-                    assert L.dqq_scratch_bytes(kind, pas, N, 1000) > 0
+                    assert L.dqq_scratch_bytes(kind, pas, N, 1000, 0) > 0
                 else:   # QCQP backward up to N = 64 included: the register-resident kernels use no scratch
-                    assert L.dqq_scratch_bytes(kind, pas, N, 1000) == 0, (kind, pas, N)
-    # dqq_scratch_bytes follows the route: with the reference-order QCQP backward selected, 42 < N <= 64 reaches the
-    # global-memory kernel and the call demands (and uses) its scratch
-    assert L.dqq_max_n(2) == 64
-    _capi.set_option("wave_qcqp_bwd", 0)
-    try:
-        assert L.dqq_scratch_bytes(1, 1, 64, 1000) > 0 and L.dqq_scratch_bytes(1, 1, 42, 1000) == 0
-        assert L.dqq_max_n(2) == 42
-        assert ops.workspace_bytes(1000, 1, 1, 64) == L.dqq_workspace_bytes(1000) + L.dqq_scratch_bytes(1, 1, 64, 1000)
-    finally:
-        _capi.set_option("wave_qcqp_bwd", 1)
+                    assert L.dqq_scratch_bytes(kind, pas, N, 1000, 0) == 0, (kind, pas, N)
+    # dqq_scratch_bytes follows the route: with the reference-order flag in p_layout, the QCQP backward of 42 < N <= 64
+    # reaches the global-memory kernel and the call demands (and uses) its scratch
+    REF = _capi.F_REFERENCE_ORDER
+    assert L.dqq_max_n(2, 0) == 64 and L.dqq_max_n(2, REF) == 42
+    assert L.dqq_scratch_bytes(1, 1, 64, 1000, REF) > 0 and L.dqq_scratch_bytes(1, 1, 42, 1000, REF) == 0
+    assert ops.workspace_bytes(1000, 1, 1, 64, REF) == L.dqq_workspace_bytes(1000) + L.dqq_scratch_bytes(1, 1, 64, 1000, REF)
     assert ops.workspace_bytes(1000, 1, 1, 64) == L.dqq_workspace_bytes(1000)
-    need = L.dqq_scratch_bytes(0, 0, 70, 24)
-    assert need > 0 and L.dqq_scratch_bytes(0, 0, 70, 24) == need and L.dqq_scratch_bytes(0, 0, 70, 0) == 0
+    need = L.dqq_scratch_bytes(0, 0, 70, 24, 0)
+    assert need > 0 and L.dqq_scratch_bytes(0, 0, 70, 24, 0) == need and L.dqq_scratch_bytes(0, 0, 70, 0, 0) == 0
     d = make_problem("qp", 24, 70, 8300, "dense")
     P, q = d["P"].cuda(), d["q"].cuda()
     x = torch.empty(24, 70, 1, device="cuda", dtype=torch.float64)

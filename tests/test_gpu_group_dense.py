@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import make_problem
+from conftest import make_problem, knob
 from test_gpu_parity import _box_fwd, check_forward, dev, hip_fwd, npy, oracle_fwd, ops  # noqa: F401
 
 pytestmark = pytest.mark.gpu
@@ -15,17 +15,17 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture()
 def fused(ops):
     from diffqcqp_amd import _capi
-    _capi.set_option("fuse_fallback", 1)
+    knob("fuse_fallback", 1)
     yield _capi
-    _capi.set_option("fuse_fallback", -1)
-    _capi.set_option("fwd_lpp", 0)
+    knob("fuse_fallback", -1)
+    knob("fwd_lpp", 0)
 
 
 @pytest.mark.parametrize("kind", ["qp", "qcqp"])
 @pytest.mark.parametrize("N,lpp", [(2, 1), (4, 1), (4, 2), (8, 2), (8, 4)])
 @pytest.mark.parametrize("structure", ["dense", "mixed"])
 def test_fused_general_tiles_match_oracle(oracle, ops, fused, kind, N, lpp, structure):
-    fused.set_option("fwd_lpp", lpp)
+    knob("fwd_lpp", lpp)
     for B in (1, 37, 1029):
         d = make_problem(kind, B, N, 5100 + N + B, structure)
         xo, ito = oracle_fwd(oracle, kind, d)
@@ -58,7 +58,7 @@ def test_fused_general_tiles_non_symmetric_p(oracle, ops, fused, kind):
 @pytest.mark.parametrize("kind", ["box", "sbox"])
 @pytest.mark.parametrize("N,lpp", [(2, 1), (4, 1), (4, 2), (8, 4)])
 def test_fused_general_tiles_box_solvers(oracle, ops, fused, kind, N, lpp):
-    fused.set_option("fwd_lpp", lpp)
+    knob("fwd_lpp", lpp)
     d = make_problem(kind, 333, N, 5400 + N, "dense")
     xo, ito, xh, ith = _box_fwd(oracle, ops, kind, d)
     check_forward(xh, ith, xo, ito, min_match=0.98)
@@ -99,7 +99,7 @@ def test_group_solve_deferred_refactorisation_is_bit_identical(ops, fused, kind,
     meanwhile: x and the iteration counts must not depend on the setting -- through DQQ_P_AUTO (tiles of a mixed batch
     met by the fused kernel, the two-pass narrow mapping at N = 8 on two lanes per problem) and through DQQ_P_DENSE
     (the solve's own mapping), budgets that run out mid-solve included."""
-    fused.set_option("fwd_lpp", lpp)
+    knob("fwd_lpp", lpp)
     B = 1500
     g = dev(make_problem(kind, B, N, 9300 + N, "mixed"))
     gd = dev(make_problem(kind, B, N, 9400 + N, "dense"))
@@ -113,12 +113,12 @@ def test_group_solve_deferred_refactorisation_is_bit_identical(ops, fused, kind,
     try:
         for gg, layout in ((g, 0), (gd, 0), (gd, 1)):
             for eps, max_iter in ((1e-7, 1000), (1e-10, 1000), (1e-7, 9), (1e-7, 1)):
-                fused.set_option("lane_defer", 1)
+                knob("lane_defer", 1)
                 x1, it1 = fwd(gg, layout, eps, max_iter)
                 for defer in (0, 2, 4, 6, 64):
-                    fused.set_option("lane_defer", defer)
+                    knob("lane_defer", defer)
                     xd, itd = fwd(gg, layout, eps, max_iter)
                     assert torch.equal(it1, itd), (layout, eps, max_iter, defer)
                     assert torch.equal(torch.nan_to_num(x1, nan=12345.0), torch.nan_to_num(xd, nan=12345.0))
     finally:
-        fused.set_option("lane_defer", 0)
+        knob("lane_defer", 0)

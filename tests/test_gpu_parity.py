@@ -24,7 +24,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import make_problem
+from conftest import KNOB_DEFAULTS, knob, make_problem
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -40,15 +40,10 @@ def ops():
     from diffqcqp_amd import build, ops as _ops, _capi
     build.build()
     _capi.lib()
-    yield _ops
-    _capi.set_option("fwd_lpp", 0)
-    _capi.set_option("wpb", 0)
-    _capi.set_option("fuse_fallback", -1)
-    _capi.set_option("dense_wave64", 1)
-    _capi.set_option("wave_qcqp_bwd", 1)
-    _capi.set_option("lane_dense", 1)
-    _capi.set_option("dense_teams", 1)
-    _capi.set_option("small_bwd", 1)
+    from conftest import OpsWithFlags
+    yield OpsWithFlags(_ops)
+    for name, value in list(KNOB_DEFAULTS.items()) + [("dense_wave64", 1), ("wave_qcqp_bwd", 1)]:
+        knob(name, value)
 
 
 def dev(d):
@@ -193,12 +188,12 @@ def test_every_lanes_per_problem_variant(oracle, ops, kind, N, lpps):
     xo, ito = oracle_fwd(oracle, kind, d)
     for wpb in (1, 4):
         for lpp in lpps:
-            _capi.set_option("fwd_lpp", lpp)
-            _capi.set_option("wpb", wpb)
+            knob("fwd_lpp", lpp)
+            knob("wpb", wpb)
             xh, ith = hip_fwd(ops, kind, g)
             check_forward(xh, ith, xo, ito)
-    _capi.set_option("fwd_lpp", 0)
-    _capi.set_option("wpb", 0)
+    knob("fwd_lpp", 0)
+    knob("wpb", 0)
     grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda())  # wpb = default after the wpb=1 sweep
     check_backward_exact(grads, st, oracle_bwd(oracle, kind, d, xo))
 
@@ -315,11 +310,11 @@ def test_register_and_lds_wave_dense_forward_agree(oracle, ops, kind, N, B):
     out = {}
     try:
         for reg in (1, 0):
-            _capi.set_option("dense_wave64", reg)
+            knob("dense_wave64", reg)
             out[reg] = hip_fwd(ops, kind, g, layout=_capi.P_DENSE)
             check_forward(out[reg][0], out[reg][1], xo, ito, min_match=0.9)
     finally:
-        _capi.set_option("dense_wave64", 1)
+        knob("dense_wave64", 1)
     assert (out[0][0] - out[1][0]).abs().max() < 1e-8
 
 
@@ -335,11 +330,11 @@ def test_register_and_lds_wave_dense_backward_agree(oracle, ops, N, B):
     out = {}
     try:
         for reg in (1, 0):
-            _capi.set_option("dense_wave64", reg)
+            knob("dense_wave64", reg)
             out[reg] = hip_bwd(ops, "qp", g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
             check_backward_exact(out[reg][0], out[reg][1], ref, exact=False)
     finally:
-        _capi.set_option("dense_wave64", 1)
+        knob("dense_wave64", 1)
     for a, b in zip(out[0][0], out[1][0]):
         assert (a - b).abs().max() <= 1e-9 * max(1.0, float(b.abs().max()))
 
@@ -354,17 +349,17 @@ def test_dense_backward_teams_agree_with_one_problem_per_wave(oracle, ops, kind,
     xo, _ = oracle_fwd(oracle, kind, d)
     ref = oracle_bwd(oracle, kind, d, xo)
     out = {}
-    _capi.set_option("dense_wave64", 0)   # the LDS kernels (the matrix-core kernels take 16 < N by default)
-    _capi.set_option("wave_qcqp_bwd", 0)
+    knob("dense_wave64", 0)   # the LDS kernels (the matrix-core kernels take 16 < N by default)
+    knob("wave_qcqp_bwd", 0)
     try:
         for teams in (1, 0):
-            _capi.set_option("dense_teams", teams)
+            knob("dense_teams", teams)
             out[teams] = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
             check_backward_exact(out[teams][0], out[teams][1], ref, exact=False)
     finally:
-        _capi.set_option("dense_teams", 1)
-        _capi.set_option("dense_wave64", 1)
-        _capi.set_option("wave_qcqp_bwd", 1)
+        knob("dense_teams", 1)
+        knob("dense_wave64", 1)
+        knob("wave_qcqp_bwd", 1)
     for a, b in zip(out[0][0], out[1][0]):
         assert torch.equal(a, b)  # identical operation order -> identical bits
 
@@ -382,9 +377,9 @@ def test_small_dense_backward_is_bit_exact_and_matches_the_wave_kernel(oracle, o
     ref = oracle_bwd(oracle, kind, d, xo)
     out = {}
     for opt in (1, 0):
-        _capi.set_option("small_bwd", opt)
+        knob("small_bwd", opt)
         out[opt] = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
-    _capi.set_option("small_bwd", 1)
+    knob("small_bwd", 1)
     check_backward_exact(out[1][0], out[1][1], ref, exact=True)
     check_backward_exact(out[0][0], out[0][1], ref, exact=False)
 
@@ -406,10 +401,10 @@ def test_lane_per_problem_backward_is_the_team_kernel_bit_for_bit(oracle, ops, k
     out = {}
     try:
         for opt in (1, 0):
-            _capi.set_option("lane_bwd", opt)
+            knob("lane_bwd", opt)
             out[opt] = hip_bwd(ops, kind, g, x, layout=_capi.P_DENSE)
     finally:
-        _capi.set_option("lane_bwd", 1)
+        knob("lane_bwd", 1)
     for a, b in zip(out[1][0], out[0][0]):
         assert torch.equal(a, b)
     assert torch.equal(out[1][1], out[0][1])
@@ -437,7 +432,7 @@ def test_feedback_routes_a_long_work_list_to_the_lane_kernel_same_bits(ops, kind
     slot = (0 if kind == "qp" else 1) * 4 + N // 2 - 1
     was_on = _capi._feedback is not None
     _capi.enable_feedback(True)
-    _capi.set_option("lane_list_drains", 0)
+    knob("lane_list_drains", 0)
     try:
         _capi._feedback.zero_()
         team = hip_bwd(ops, kind, g, x)             # nothing known yet: the team kernel drains, and reports
@@ -481,7 +476,7 @@ def test_feedback_routes_a_long_work_list_to_the_lane_kernel_same_bits(ops, kind
             assert torch.equal(a, b)
         # without the buffer: the team kernel, whatever came before
         _capi.enable_feedback(False)
-        _capi.set_option("lane_list_drains", 0)
+        knob("lane_list_drains", 0)
         off = hip_bwd(ops, kind, g, x)
         torch.cuda.synchronize()
         assert _capi.get_option("lane_list_drains") == 0
@@ -512,7 +507,7 @@ def test_feedback_sends_an_all_dense_auto_batch_to_the_lane_kernel_whole(ops, ki
     same = lambda a, b: all(torch.equal(u, v) for u, v in zip(a[0], b[0])) and torch.equal(a[1], b[1])
     try:
         _capi._feedback.zero_()
-        _capi.set_option("bwd_whole_batches", 0)
+        knob("bwd_whole_batches", 0)
         for expect_whole, expect_streak in ((0, 0), (0, 1), (1, 2), (2, 3), (3, 3)):
             out = hip_bwd(ops, kind, g, x)
             torch.cuda.synchronize()
@@ -549,13 +544,13 @@ def test_feedback_sends_an_all_dense_auto_batch_to_the_lane_kernel_whole(ops, ki
         torch.cuda.synchronize()
         assert same(ref, out) and _capi.get_option("bwd_whole_batches") == 5
         assert _capi.feedback_words()[slot] == (B, 0)
-        _capi.set_option("bwd_skip_classify", 0)                # the option keeps the fast path's launch in front
+        knob("bwd_skip_classify", 0)                # the option keeps the fast path's launch in front
         _capi._feedback[slot] = ((2 << 62) | (B << 32) | B) - (1 << 64)   # (as a signed 64-bit integer)
         out = hip_bwd(ops, kind, g, x)
         torch.cuda.synchronize()
         assert same(ref, out) and _capi.get_option("bwd_whole_batches") == 5
     finally:
-        _capi.set_option("bwd_skip_classify", 1)
+        knob("bwd_skip_classify", 1)
         _capi.enable_feedback(was_on)
 
 
@@ -578,7 +573,7 @@ def test_feedback_moves_a_mostly_dense_forward_to_one_lane_same_bits(ops, kind):
     _capi.enable_feedback(True)
     try:
         _capi._feedback.zero_()
-        _capi.set_option("fwd_feedback_routes", 0)
+        knob("fwd_feedback_routes", 0)
         x2, it2 = hip_fwd(ops, kind, g)                       # nothing known: two lanes per problem
         assert _capi.get_option("fwd_feedback_routes") == 0
         hip_bwd(ops, kind, g, x2)
@@ -589,20 +584,20 @@ def test_feedback_moves_a_mostly_dense_forward_to_one_lane_same_bits(ops, kind):
         assert _capi.get_option("fwd_feedback_routes") == 1
         assert torch.equal(x2, x4) and torch.equal(it2, it4)
         for lpp in (1, 4):                                    # (what the hint selects are the instantiations of option fwd_lpp)
-            _capi.set_option("fwd_lpp", lpp)
+            knob("fwd_lpp", lpp)
             xf, itf = hip_fwd(ops, kind, g)
             assert torch.equal(x4, xf) and torch.equal(it4, itf)
-        _capi.set_option("fwd_lpp", 0)
-        _capi.set_option("fwd_feedback", 0)
+        knob("fwd_lpp", 0)
+        knob("fwd_feedback", 0)
         hip_fwd(ops, kind, g)
         assert _capi.get_option("fwd_feedback_routes") == 1   # the option keeps the forward off the word
-        _capi.set_option("fwd_feedback", 1)
+        knob("fwd_feedback", 1)
         _capi._feedback[slot] = (B << 32) | (B // 2 - 1)      # fewer than half of the batch last time: two lanes stay
         x1, it1 = hip_fwd(ops, kind, g)
         assert _capi.get_option("fwd_feedback_routes") == 1 and torch.equal(x1, x2) and torch.equal(it1, it2)
     finally:
-        _capi.set_option("fwd_lpp", 0)
-        _capi.set_option("fwd_feedback", 1)
+        knob("fwd_lpp", 0)
+        knob("fwd_feedback", 1)
         _capi.enable_feedback(was_on)
 
 
@@ -626,12 +621,12 @@ def test_a_diagonal_problem_gets_the_fast_paths_bits_from_the_general_backward(o
     bits = lambda t: t.view(torch.int64) if t.dtype is torch.float64 else t
     try:
         for lane in (1, 0):
-            _capi.set_option("lane_bwd", lane)
+            knob("lane_bwd", lane)
             general = hip_bwd(ops, kind, g, x, layout=_capi.P_DENSE)
             for a, b in zip(fast[0] + [fast[1]], general[0] + [general[1]]):
                 assert torch.equal(bits(a), bits(b))
     finally:
-        _capi.set_option("lane_bwd", 1)
+        knob("lane_bwd", 1)
 
 
 @pytest.mark.parametrize("kind", ["qp", "qcqp"])
@@ -683,7 +678,7 @@ def test_forward_hint_with_the_hand_off_counts_blocks_not_problems(ops, kind, ev
     _capi.enable_feedback(True)
     try:
         _capi._feedback.zero_()
-        _capi.set_option("fwd_feedback_routes", 0)
+        knob("fwd_feedback_routes", 0)
         cache = ops.diag_cache(g["q"])
         if kind == "qp":
             fwd = lambda: ops.qp_forward(g["P"], g["q"], 1e-7, 1000, cache=cache, return_iters=True)
@@ -811,11 +806,11 @@ def test_reference_order_backward_beyond_the_wave_kernel(oracle, ops, kind, N, B
     g = dev(d)
     if kind == "qcqp":
         xo, _ = oracle_fwd(oracle, kind, d)
-        _capi.set_option("wave_qcqp_bwd", 0)
+        knob("wave_qcqp_bwd", 0)
         try:
             grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda(), layout=_capi.P_DENSE)
         finally:
-            _capi.set_option("wave_qcqp_bwd", 1)
+            knob("wave_qcqp_bwd", 1)
         check_backward_exact(grads, st, oracle_bwd(oracle, kind, d, xo), exact=False)
     else:
         xo = oracle.boxqp_fwd_batch(d["P"].numpy(), d["q"].numpy(), d["l_min"].numpy(), d["l_max"].numpy(), 1e-7, 1000,
@@ -842,14 +837,14 @@ def test_wave_per_problem_forward_every_size(oracle, ops, kind, N, B):
     else:
         xo, ito, xh, ith = _box_fwd(oracle, ops, kind, d, layout=_capi.P_DENSE)
     check_forward(xh, ith, xo, ito, min_match=0.97)
-    _capi.set_option("dense_wave64", 0)
+    knob("dense_wave64", 0)
     try:
         if kind in ("qp", "qcqp"):
             xw, itw = hip_fwd(ops, kind, g, layout=_capi.P_DENSE)
         else:
             _, _, xw, itw = _box_fwd(oracle, ops, kind, d, layout=_capi.P_DENSE)
     finally:
-        _capi.set_option("dense_wave64", 1)
+        knob("dense_wave64", 1)
     assert (xw - xh).abs().max() < 1e-8 and (itw == ith).float().mean() >= 0.97
     if kind == "qp":
         # QP backward: every 16 < N <= 64 runs on the same register-resident design (K on the matrix cores);
@@ -896,7 +891,7 @@ def test_auto_layout_mixed_batch_uses_fallback(oracle, ops, kind, N):
     # fuse_fallback: 1 = non-diagonal tiles solved inside the fast kernel (small N), 0 = work-list + dense
     # kernel, -1 = built-in choice.  Twice each: the second call relies on the work-list being re-zeroed.
     for fuse in (0, 0, 1, -1):
-        _capi.set_option("fuse_fallback", fuse)
+        knob("fuse_fallback", fuse)
         xh, ith = hip_fwd(ops, kind, g)
         check_forward(xh, ith, xo, ito, min_match=0.99)
         grads, st = hip_bwd(ops, kind, g, torch.from_numpy(xo).cuda())
@@ -933,7 +928,7 @@ def test_worklist_header_is_rezeroed_by_large_drains(ops, kind, N, B):
     g = dev(make_problem(kind, B, N, 4100 + N, "dense"))
     xd, itd = hip_fwd(ops, kind, g, layout=1)
     gd, std = hip_bwd(ops, kind, g, xd, layout=1)
-    _capi.set_option("fuse_fallback", 0)
+    knob("fuse_fallback", 0)
     try:
         first = None
         for _ in range(3):
@@ -964,7 +959,7 @@ def test_worklist_header_is_rezeroed_by_large_drains(ops, kind, N, B):
         for ws in ops._workspaces.values():
             assert header_is_clean(ws)
     finally:
-        _capi.set_option("fuse_fallback", -1)
+        knob("fuse_fallback", -1)
 
 
 def test_single_nonzero_offdiagonal_is_detected(oracle, ops):
@@ -1056,13 +1051,13 @@ def test_box_forward_dense_and_mixed(oracle, ops, kind, N, B, structure):
         xo, ito, xh, ith = _box_fwd(oracle, ops, kind, d, layout=layout)
         check_forward(xh, ith, xo, ito, min_match=0.99 if N < 32 else 0.9)
     if structure == "dense" and N in (8, 32):  # the wave kernel behind the lane / workgroup kernels agrees
-        _capi.set_option("lane_dense", 0)
-        _capi.set_option("dense_wave64", 0)
+        knob("lane_dense", 0)
+        knob("dense_wave64", 0)
         try:
             xo, ito, xw, itw = _box_fwd(oracle, ops, kind, d, layout=_capi.P_DENSE)
         finally:
-            _capi.set_option("lane_dense", 1)
-            _capi.set_option("dense_wave64", 1)
+            knob("lane_dense", 1)
+            knob("dense_wave64", 1)
         check_forward(xw, itw, xo, ito, min_match=0.99)
         assert (xw - xh).abs().max() < 1e-8
 
@@ -1131,7 +1126,7 @@ def test_box_end_to_end_and_large_n(oracle, ops):
     check_forward(xh, ith, xo, ito)
     ref, out, _ = _box_bwd(oracle, ops, d, npy(xh))
     check_end_to_end(list(out[:4]), out[4][:, 1], (ref[0], ref[1], ref[2], ref[3], ref[5][:, 1]))
-    assert _capi.lib().dqq_max_n(3) == 21
+    assert _capi.lib().dqq_max_n(3, 0) == 21
     for N, B, structure, layout in ((40, 6, "dense", _capi.P_DENSE), (64, 70, "dense", _capi.P_AUTO),
                                     (64, 70, "mixed", _capi.P_AUTO), (26, 9, "dense", _capi.P_DENSE)):
         dd = make_problem("box", B, N, 891 + N, structure)
@@ -1522,7 +1517,7 @@ def test_segmented_worklist_uneven_segments(ops, kind, N, B, pattern):
     nd = sel.numpy()
     try:
         for wpb in (0, 1, 0):
-            _capi.set_option("wpb", wpb)
+            knob("wpb", wpb)
             xa, ita = hip_fwd(ops, kind, g, layout=0)
             ga, sa = hip_bwd(ops, kind, g, xd, layout=0)
             torch.cuda.synchronize()
@@ -1541,7 +1536,7 @@ def test_segmented_worklist_uneven_segments(ops, kind, N, B, pattern):
                 a, b = npy(a), npy(b)
                 assert np.abs(a - b)[same].max() <= 1e-6 * max(1.0, np.abs(b).max())
     finally:
-        _capi.set_option("wpb", 0)
+        knob("wpb", 0)
 
 
 @pytest.mark.parametrize("N,B", [(18, 300), (20, 129), (24, 500), (26, 64), (30, 257), (32, 1024), (34, 96), (40, 200),
@@ -1567,9 +1562,9 @@ def test_qcqp_backward_wave_kernel_16_to_32(oracle, ops, N, B):
         check_backward_reassociated(oracle, "qcqp", d, xo, (gP, gq, gl, gm), st, ref)
         assert torch.isfinite(duals[0]).all() and torch.isfinite(duals[1]).all()
     # the kernel in the reference's summation order agrees (bit-exact with the oracle on identical x)
-    _capi.set_option("wave_qcqp_bwd", 0)
+    knob("wave_qcqp_bwd", 0)
     try:
         grads, st2 = hip_bwd(ops, "qcqp", g, xs, layout=_capi.P_DENSE)
         check_backward_exact(grads, st2, ref, exact=False)
     finally:
-        _capi.set_option("wave_qcqp_bwd", 1)
+        knob("wave_qcqp_bwd", 1)

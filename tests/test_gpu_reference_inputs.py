@@ -24,6 +24,8 @@ import sys
 
 import numpy as np
 import pytest
+
+from conftest import knob
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -193,13 +195,13 @@ def test_rank_deficient_batches_on_one_two_and_four_lanes_per_problem(ops, famil
     out = {}
     try:
         for lpp in (1, 2, 4):
-            _capi.set_option("fwd_lpp", lpp)
+            knob("fwd_lpp", lpp)
             if kind == "qp":
                 out[lpp] = ops.qp_forward(g["P"], g["q"], 1e-7, 1000, return_iters=True)
             else:
                 out[lpp] = ops.qcqp_forward(g["P"], g["q"], g["l_n"], g["mu"], 1e-7, 1000, return_iters=True)
     finally:
-        _capi.set_option("fwd_lpp", 0)
+        knob("fwd_lpp", 0)
     for lpp in (1, 4):
         assert torch.equal(out[lpp][0].view(torch.int64), out[2][0].view(torch.int64)), "x differs on %d lanes" % lpp
         assert torch.equal(out[lpp][1], out[2][1]), "iteration counts differ on %d lanes" % lpp
@@ -225,10 +227,10 @@ def test_rank_deficient_backward_lane_kernel_is_the_team_kernel_bit_for_bit(ops,
     out = {}
     try:
         for opt in (1, 0):
-            _capi.set_option("lane_bwd", opt)
+            knob("lane_bwd", opt)
             out[opt] = run()
     finally:
-        _capi.set_option("lane_bwd", 1)
+        knob("lane_bwd", 1)
     for a, b in zip(out[1], out[0]):
         a64 = a.view(torch.int64) if a.dtype is torch.float64 else a
         b64 = b.view(torch.int64) if b.dtype is torch.float64 else b

@@ -64,6 +64,7 @@ def main():
         for name, counter, val, n in c.execute("select kernel_name, counter_name, avg(value), count(*) "
                                                "from counters_collection group by kernel_name, counter_name"):
             pmc.setdefault(short(name), {})[counter] = val
+            pmc[short(name)]["_dispatches"] = max(pmc[short(name)].get("_dispatches", 0), n)
     latest = {}
     for k, v in pmc.items():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
@@ -82,9 +83,15 @@ def main():
                     v[cn + "_frac"] = v[cn] / v["SQ_WAVE_CYCLES"]
         key = bench_key(k)
         if key and "hbm_bytes_per_launch" in v:
-            e = latest.setdefault(key, {"kernels": [], "hbm_bytes_per_launch": 0.0})
+            # a launch (one C-ABI call) = the kernels it enqueues; several kernels can serve one launch name over a run (the
+            # first calls of a dense batch take other routes than the steady state): bytes per launch = the dispatch-weighted
+            # sum over the kernels / the dispatches of the most frequent one (round 5: the plain sum of the per-kernel means
+            # counted a once-only route as if every call had taken it)
+            e = latest.setdefault(key, {"kernels": [], "_weighted": 0.0, "_calls": 0})
             e["kernels"].append(k)
-            e["hbm_bytes_per_launch"] += v["hbm_bytes_per_launch"]
+            e["_weighted"] += v["hbm_bytes_per_launch"] * v.get("_dispatches", 1)
+            e["_calls"] = max(e["_calls"], v.get("_dispatches", 1))
+            e["hbm_bytes_per_launch"] = e["_weighted"] / e["_calls"]
             # instruction counters: those of the kernel that does the work (the largest), not of the empty
             # work-list launch next to it
             if v.get("SQ_INSTS_VALU", 0.0) >= e.get("SQ_INSTS_VALU", -1.0):
@@ -96,6 +103,8 @@ def main():
                     if extra in v:
                         e[extra] = v[extra]
     for e in latest.values():
+        e.pop("_weighted", None)
+        e.pop("_calls", None)
         if e.get("SQ_WAVES"):
             e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
     latest["_tag"] = tag
