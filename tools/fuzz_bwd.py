@@ -11,6 +11,19 @@ from conftest import make_problem
 from diffqcqp_amd import _capi, ops
 from oracle import oracle as O
 
+TUNING = _capi.tuning_build()   # the developer build (-DDQQ_TUNING): the kernel-selection knobs exist; the shipped library has none
+
+
+def apply_opts(opts):
+    """Knobs -> the library (developer build only; on the shipped build the draw still happens, so that a seed names the same
+    trials on both).  The two former NUMERICS knobs are the per-call flag DQQ_F_REFERENCE_ORDER now: returned for the layout."""
+    ref = _capi.F_REFERENCE_ORDER if (opts.get("dense_wave64", 1) == 0 or opts.get("wave_qcqp_bwd", 1) == 0) else 0
+    if TUNING:
+        for k, v in opts.items():
+            if k not in ("dense_wave64", "wave_qcqp_bwd"): _capi.set_option(k, v)
+    return ref
+
+
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 bad, worst, lane_list = 0, 0.0, 0
@@ -39,7 +52,7 @@ for t in range(trials):
         gg = torch.Generator().manual_seed(t)
         d["P"] = (d["P"] + torch.triu(torch.rand(B, N, N, generator=gg, dtype=torch.float64), diagonal=1) * 0.05).contiguous()
     P, q, gx = d["P"].numpy(), d["q"].numpy(), d["grad_x"].numpy()
-    for k, v in opts.items(): _capi.set_option(k, v)
+    ref_flag = apply_opts(opts)
     if B >= 16384 and layout == 0 and kind != "box":
         # the feedback word of dqq_set_feedback, set to anything: a "long list" sends the lane-per-problem kernel (LIST) after
         # whatever list this batch has -- full, every other tile, empty; a hint must never change a result
@@ -53,25 +66,25 @@ for t in range(trials):
         xo, _ = O.qp_fwd_batch(P, q, 1e-7, 1000, nthreads=16)
         ref = O.qp_bwd_batch(P, q, xo, gx, nthreads=16)
         if use_cache: ops.qp_forward(g["P"], g["q"], 1e-7, 1000, cache=cache)
-        out = ops.qp_backward(g["P"], g["q"], torch.from_numpy(xo).cuda(), g["grad_x"], layout=layout, return_steps=True, cache=cache)
+        out = ops.qp_backward(g["P"], g["q"], torch.from_numpy(xo).cuda(), g["grad_x"], layout=layout | ref_flag, return_steps=True, cache=cache)
         grads, st, gref, sref = out[:2], out[2].cpu().numpy(), ref[:2], ref[2]
     elif kind == "qcqp":
         xo, _ = O.qcqp_fwd_batch(P, q, d["l_n"].numpy(), d["mu"].numpy(), 1e-7, 1000, nthreads=16)
         ref = O.qcqp_bwd_batch(P, q, d["l_n"].numpy(), d["mu"].numpy(), xo, gx, nthreads=16)
         if use_cache: ops.qcqp_forward(g["P"], g["q"], g["l_n"], g["mu"], 1e-7, 1000, cache=cache)
-        out = ops.qcqp_backward(g["P"], g["q"], g["l_n"], g["mu"], torch.from_numpy(xo).cuda(), g["grad_x"], layout=layout, return_steps=True, cache=cache)
+        out = ops.qcqp_backward(g["P"], g["q"], g["l_n"], g["mu"], torch.from_numpy(xo).cuda(), g["grad_x"], layout=layout | ref_flag, return_steps=True, cache=cache)
         grads, st, gref, sref = out[:4], out[4].cpu().numpy(), ref[:4], ref[4]
     else:
         xo, _ = O.boxqp_fwd_batch(P, q, d["l_min"].numpy(), d["l_max"].numpy(), 1e-7, 1000, nthreads=16)
         ref = O.boxqp_bwd_batch(P, q, d["l_min"].numpy(), d["l_max"].numpy(), xo, gx, nthreads=16)
         if use_cache: ops.boxqp_forward(g["P"], g["q"], g["l_min"], g["l_max"], 1e-7, 1000, cache=cache)
-        out = ops.boxqp_backward(g["P"], g["q"], g["l_min"], g["l_max"], torch.from_numpy(xo).cuda(), g["grad_x"], layout=layout, return_steps=True, cache=cache)
+        out = ops.boxqp_backward(g["P"], g["q"], g["l_min"], g["l_max"], torch.from_numpy(xo).cuda(), g["grad_x"], layout=layout | ref_flag, return_steps=True, cache=cache)
         grads, st, gref, sref = out[:4], out[4].cpu().numpy()[:, 1], ref[:4], ref[5][:, 1]
     same = st == sref
     rel = 0.0
     # the QCQP's contact gradients through the matrix-core kernels (16 < N <= 64, wave_qcqp_bwd = 1): the evaluation-order
     # noise of the reference's own formulas is up to 8.6e-6 there (tests/test_gpu_parity.py: REASSOC_TOL); judged at 2e-5
-    reassoc = kind == "qcqp" and 16 < N <= 64 and opts["wave_qcqp_bwd"] == 1 and structure != "diag"
+    reassoc = kind == "qcqp" and 16 < N <= 64 and ref_flag == 0 and structure != "diag"
     for k, (a, b) in enumerate(zip(grads, gref)):
         a, b = a.cpu().numpy()[same], b[same]
         if a.size:
@@ -84,6 +97,6 @@ for t in range(trials):
     if not ok:
         bad += 1
         print("FAIL", t, kind, N, B, structure, layout, opts, "cache", use_cache, "rel %.2e exits equal %.3f finite %s" % (rel, same.mean(), finite), flush=True)
-for k, v in {"fuse_fallback": -1, "wpb": 0, "small_bwd": 1, "dense_teams": 1, "dense_wave64": 1, "wave_qcqp_bwd": 1, "lane_bwd": 1}.items(): _capi.set_option(k, v)
+apply_opts({"fuse_fallback": -1, "wpb": 0, "small_bwd": 1, "dense_teams": 1, "dense_wave64": 1, "wave_qcqp_bwd": 1, "lane_bwd": 1})
 print("%d trials, %d failures, worst rel err %.2e  (feedback word poked in %d trials: %d drains by the lane kernel, %d whole batches)"
       % (trials, bad, worst, lane_list, _capi.get_option("lane_list_drains"), _capi.get_option("bwd_whole_batches")))

@@ -10,6 +10,19 @@ from conftest import make_problem
 from diffqcqp_amd import _capi, ops
 from oracle import oracle as O
 
+TUNING = _capi.tuning_build()   # the developer build (-DDQQ_TUNING): the kernel-selection knobs exist; the shipped library has none
+
+
+def apply_opts(opts):
+    """Knobs -> the library (developer build only; on the shipped build the draw still happens, so that a seed names the same
+    trials on both).  The two former NUMERICS knobs are the per-call flag DQQ_F_REFERENCE_ORDER now: returned for the layout."""
+    ref = _capi.F_REFERENCE_ORDER if (opts.get("dense_wave64", 1) == 0 or opts.get("wave_qcqp_bwd", 1) == 0) else 0
+    if TUNING:
+        for k, v in opts.items():
+            if k not in ("dense_wave64", "wave_qcqp_bwd"): _capi.set_option(k, v)
+    return ref
+
+
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 LPP = {2: [1], 4: [1, 2], 8: [1, 2, 4], 16: [2, 4, 8], 32: [4, 8, 16], 64: [8, 16, 32]}
@@ -46,15 +59,15 @@ for t in range(trials):
     else:
         v = d["v"].numpy() if kind == "sbox" else None
         xo, ito = O.boxqp_fwd_batch(P, q, d["l_min"].numpy(), d["l_max"].numpy(), eps, max_iter, v=v, nthreads=16)
-    for k, v in opts.items(): _capi.set_option(k, v)
+    ref_flag = apply_opts(opts)
     g = {k: v.cuda() for k, v in d.items()}
     Pin = g["P"] if layout != 2 else torch.diagonal(g["P"], dim1=1, dim2=2).contiguous()
     if kind == "qp":
-        xh, ith = ops.qp_forward(Pin, g["q"], eps, max_iter, layout=layout, return_iters=True)
+        xh, ith = ops.qp_forward(Pin, g["q"], eps, max_iter, layout=layout | ref_flag, return_iters=True)
     elif kind == "qcqp":
-        xh, ith = ops.qcqp_forward(Pin, g["q"], g["l_n"], g["mu"], eps, max_iter, layout=layout, return_iters=True)
+        xh, ith = ops.qcqp_forward(Pin, g["q"], g["l_n"], g["mu"], eps, max_iter, layout=layout | ref_flag, return_iters=True)
     else:
-        xh, ith = ops.boxqp_forward(Pin, g["q"], g["l_min"], g["l_max"], eps, max_iter, v=g.get("v"), layout=layout,
+        xh, ith = ops.boxqp_forward(Pin, g["q"], g["l_min"], g["l_max"], eps, max_iter, v=g.get("v"), layout=layout | ref_flag,
                                     return_iters=True)
     err = float(np.abs(xh.cpu().numpy() - xo).max())
     same = float((ith.cpu().numpy() == ito).mean())
@@ -63,6 +76,6 @@ for t in range(trials):
     if not ok:
         bad += 1
         print("FAIL", t, kind, N, B, structure, layout, eps, max_iter, opts, "err %.2e iters equal %.4f" % (err, same), flush=True)
-for k, v in {"fwd_lpp": 0, "fuse_fallback": -1, "fwd_compact": 0, "wpb": 0, "dense_wave64": 1, "lane_dense": 1,
-             "small_fwd": 1, "lane_defer": 0, "fwd_respread": 16, "fwd_respread2": 8}.items(): _capi.set_option(k, v)
+apply_opts({"fwd_lpp": 0, "fuse_fallback": -1, "fwd_compact": 0, "wpb": 0, "dense_wave64": 1, "lane_dense": 1,
+            "small_fwd": 1, "lane_defer": 0, "fwd_respread": 16, "fwd_respread2": 8})
 print("%d trials, %d failures, worst |dx| %.2e" % (trials, bad, worst))
