@@ -127,6 +127,34 @@ static DQQ_D void store_lower_to_lds(const v4d (&G)[NT][NT], double* __restrict_
             }
 }
 
+// The same LDS image written from the TRANSPOSED tile layout the power iteration leaves in registers
+// (load_tiles_transposed: T[ti][tj][r] of lane (g,l) = A[16 tj + l][16 ti + 4 r + g]): the lower triangle of A is all in
+// there, so the first factorisation needs no second pass over P in memory (round 5: that pass re-read the lower triangle
+// row-wise AND column-wise -- 0.55 GB of the 2.76 GB a 65536 x 64 forward moved, 1.25x its algorithmic bytes).
+// Entry (a, b) of A, a >= b, sits in tile (ta, tb) = (a / 16, b / 16): for ta > tb it is T[tb][ta][r](g, l) with
+// a = 16 ta + l, b = 16 tb + 4 r + g -- stored at row l, column 4 r + g of the LDS tile (ta, tb).
+template <int NT, bool PAD>
+static DQQ_D void store_lower_to_lds_from_transposed(const v4d (&T)[NT][NT], double* __restrict__ lds, int n, int lane)
+{
+    using L = LowerLds<NT>;
+    const int g = lane >> 4, l = lane & 15;
+#pragma unroll
+    for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+        for (int tb = 0; tb <= ta; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int al = l, bl = 4 * r + g;                       // position inside the tile
+                double v = T[tb][ta][r];
+                if (PAD) {                                              // the padding of the SYMMETRIC matrix is the identity
+                    const int a = 16 * ta + al, b = 16 * tb + bl;
+                    if (!(a < n && b < n)) v = (a == b) ? 1.0 : 0.0;
+                }
+                if (ta > tb) lds[L::tile_base(ta, tb) + al * kLowLd + bl] = v;
+                else if (al >= bl) lds[L::DIAG0 + 136 * ta + al * (al + 1) / 2 + bl] = v;
+            }
+}
+
 template <int NT>
 static DQQ_D void load_lower_from_lds(v4d (&G)[NT][NT], const double* __restrict__ lds, int lane)
 {
@@ -193,10 +221,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT == 4 ?
             v = s > 0 ? Av * fast_rsqrt(s) : Av;
         }
         const double Lmax = wave_sum64(v * W.matvec(v, xsrc));
+        // the lower triangle of P goes to LDS straight from these registers: every factorisation starts from there
+        store_lower_to_lds_from_transposed<NT, PAD>(W.G, s_lower, N, lane);
+        wave_lds_fence();
         RhoSchedule sched;
         sched.init(Lmax, mu);                                    // :72-73 / :531-532
         double rho = sched.rho;
-        double mdiag = live ? Pg[lane * (N + 1)] + (rho + mu) : 1.0; // accumulated shifted diagonal, :75
+        // accumulated shifted diagonal, :75 -- P's diagonal from the LDS image just written (lane i: entry (i, i) of diagonal
+        // tile i / 16), not from memory again (64 lanes x one 64-byte line each)
+        const int dl_ = lane & 15;
+        double mdiag = live ? s_lower[LowerLds<NT>::DIAG0 + 136 * ((lane >> 4) < NT ? (lane >> 4) : 0) + dl_ * (dl_ + 1) / 2 + dl_] + (rho + mu) : 1.0;
         bool bad = false;
 
         const double qi = live ? q[prob * N + lane] : 0.0;
@@ -210,18 +244,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT == 4 ?
         }
         double qp = qi, l2 = 0.0, l2p = 0.0, u = 0.0;
         int it_done = 0;
-        bool need_refactor = true, first_factor = true;
+        bool need_refactor = true;
         double inv_rho = 1.0 / rho;
         for (int it = 0; it < max_iter; ++it) {
             if (need_refactor) { // llt() + solveInPlace(Identity) of P + shift, Solver.cpp:76-77: W.G <- -(P + shift)^-1
-                if (first_factor) {      // from global memory once; the lower triangle stays in LDS for the rho updates
-                    load_tiles_lower_symmetric<NT, PAD>(W.G, Pg, N, lane);
-                    store_lower_to_lds<NT>(W.G, s_lower, lane);
-                    wave_lds_fence();
-                    first_factor = false;
-                } else {
-                    load_lower_from_lds<NT>(W.G, s_lower, lane);
-                }
+                load_lower_from_lds<NT>(W.G, s_lower, lane);   // (never from memory: P was read once, for the power iteration)
                 set_tile_diagonal<NT>(W.G, mdiag, lane);
                 block_sweep_inverse<NT>(W.G, lane, bad, s_tr);
                 need_refactor = false;

@@ -1444,10 +1444,14 @@ def test_full_size_config5_dense_n64(oracle, ops):
     gP, gq, st = ops.qp_backward(P, q, x, gx, return_steps=True)
     assert torch.equal(gP, gq * x.transpose(1, 2))                  # qcqp.py:48-51
     assert int(st.max()) <= 10 and bool(torch.isfinite(gq).all())
-    idx = torch.arange(0, B, 2048, device="cuda")
+    idx = torch.arange(0, B, 256, device="cuda")                    # 256 problems of the batch against the oracle
     d = {"P": P[idx].cpu(), "q": q[idx].cpu(), "grad_x": gx[idx].cpu()}
     xo, ito = oracle_fwd(oracle, "qp", d)
-    check_forward(x[idx], it[idx], xo, ito, min_match=0.9)
+    # the matrix-core kernel re-associates the sums of the inverse (block Gauss-Jordan instead of LLT + substitutions):
+    # x within 1e-6 everywhere, the iteration count equal to the oracle's on >= 99 % of the sample (measured: 1024 of 1024 equal,
+    # max |dx| 1.3e-14: profiles/r06e_cfg5_match.txt) and never more than 2 apart
+    check_forward(x[idx], it[idx], xo, ito, min_match=0.99)
+    assert np.abs(npy(it[idx]).astype(np.int64) - ito).max() <= 2
     gs, sts = hip_bwd(ops, "qp", dev(d), torch.from_numpy(xo).cuda())
     check_backward_exact(gs, sts, oracle_bwd(oracle, "qp", d, xo), exact=False)
 
