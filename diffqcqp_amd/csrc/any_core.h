@@ -1,8 +1,8 @@
 // any_core.h -- per-problem device routines of the general path WITHOUT a size limit: one 256-thread workgroup
 // per problem, every matrix and vector in a per-workgroup slice of GLOBAL memory (L2-resident for moderate N),
 // coordinates strided over the threads.  The reference has no size limit either (Solver.cpp:61: any n); this is
-// the kernel behind every N the register / LDS kernels do not hold, and the reference-ORDER backward for the
-// sizes where the matrix-core backward (bwd_block.hip) is the only LDS-resident alternative.
+// the kernel behind every N the register / LDS kernels do not hold, and -- with DQQ_F_REFERENCE_ORDER -- the
+// reference-ORDER QCQP backward for 42 < N <= 64, where the matrix-core kernels (bwd_wave_qcqp_big.hip) are the default.
 //
 // It is dense_core.h with "lane i owns coordinate i" replaced by "thread t owns coordinates t, t+256, ...":
 // the same restatement of Solver::solveQP / solveQCQP / solveBoxQP / solveSignedBoxQP (Solver.cpp:61-123,

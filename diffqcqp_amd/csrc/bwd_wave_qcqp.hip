@@ -14,8 +14,8 @@
 //     A[16+i][c] = 2 l_i (i in contact c),  A[16+i][16+j] = P[i][j] + [i == j] 2 gamma_(i/2)            (:651-657)
 //     solve  A^T b = [0; grad_l]  in the Tikhonov sense of iterative_refinement(A^T, .):  K = A A^T + mu I, rhs A dd.
 // K (upper tiles) is factored and inverted in place by block Cholesky (wave_chol.h), a second copy serves the
-// refinement residual.  Round 2 had no fast accurate kernel here: the LDS wave kernel in the reference's summation
-// order (0.9 ms per 4096 problems at N = 32) or the 1e-4-accurate workgroup kernel behind block_bwd = 1.
+// refinement residual.  The alternative is the LDS wave kernel in the reference's summation order (0.9 ms per 4096
+// problems at N = 32), selected per call with DQQ_F_REFERENCE_ORDER.
 #include "kkt_core.h"
 #include "launch.h"
 #include "wave_chol.h"

@@ -212,7 +212,7 @@ hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipSt
         return launch_bwd_dense_wave64(kind, a, use_worklist, s);
     // QCQP, 16 < N <= 64: the register-resident block-Cholesky kernels re-associate the sums of these Tikhonov systems
     // (cond(K) ~ 1e9: gradients within 5e-7 / 8e-6 of the reference-order evaluation, the evaluation-order noise of the
-    // reference's own formulas); option "wave_qcqp_bwd" = 0 selects the reference-order kernels instead
+    // reference's own formulas); the per-call flag DQQ_F_REFERENCE_ORDER selects the reference-order kernels instead
     // (LDS wave kernel up to N = 42, global-memory kernel beyond: 1e-9, 10-30x slower).
     if (bwd_wave_qcqp_supported(kind, a.N) && !a.ref_order) return launch_bwd_wave_qcqp(a, use_worklist, s);
     if (bwd_wave_qcqp_big_supported(kind, a.N) && !a.ref_order)

@@ -4,7 +4,7 @@
 // Same algorithm as the reference (Solver::solveQP / solveQCQP / solveBoxQP / solveSignedBoxQP,
 // Solver.cpp:61-123, 521-582, 198-261, 374-439): power iteration, adaptive-rho ADMM with the explicit inverse of
 // P + (rho+mu) I rebuilt at every rho update (the reference's llt() + solveInPlace(Identity), :76-77, :100-101,
-// :114-115).  What is different from the workgroup-per-problem kernel (dense_block.hip) is the execution model:
+// :114-115).  What is different from the LDS wave-per-problem kernel (dense.hip / dense_core.h) is the execution model:
 //
 //   * no LDS, no workgroup barrier: the 64 x 64 matrix lives in 128 VGPRs per lane in the matrix-core tile
 //     layout (wave_tile.h), two independent waves per SIMD, eight problems in flight per CU;
@@ -346,7 +346,7 @@ hipError_t launch_fwd_dense_wave64(int kind, const FwdArgs& a, bool use_worklist
 // Solver::solveDerivativesQP (:136-196), Solver::iterative_refinement (:15-44) and the gradient assembly of
 // qcqp.py:48-51, on the system in the ORIGINAL index order with the active rows / columns masked
 // (A~[a][k] = P[a][k] if a and k are inactive, l_a if a = k is active, 0 otherwise -- a symmetric permutation of the
-// reference's blkdiag(diag(l_A), P_II), see dense_block.hip).
+// reference's blkdiag(diag(l_A), P_II), see small_bwd_core.h).
 //
 // P is read ONCE (tile layout of P^T in registers): gamma = -(P l + q), then the masks are applied in place and A^T b
 // follows from the same registers.  The UPPER tiles of K = A~ A~^T + mu I are accumulated on the matrix cores

@@ -22,7 +22,7 @@
 
 namespace dqq {
 
-// Option "lane_defer": the lane-per-problem kernel runs the refactorisation of the lanes that changed rho every this
+// Knob lane_defer (tuning.h): the lane-per-problem kernel runs the refactorisation of the lanes that changed rho every this
 // many trips of its loop (1 = in the trip of the change, as rounds 1-2 did; 0 = built-in choice per kind).  Results do
 // not depend on it.  The group solve of the fused forward (group_dense.h) takes the same option.
 // Dense 8 x 8 (P = S S^T/8 + 0.1 I), QP / QCQP forward, us (tools/probe_lane_defer.py):

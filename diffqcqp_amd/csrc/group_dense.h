@@ -291,7 +291,7 @@ DQQ_D int group_dense_fwd(const double* __restrict__ Pg, const double (&q)[N / L
         _Pragma("unroll") for (int e_ = 0; e_ < E; ++e_) rhs_[e_] = __builtin_fma(rho, l2[e_], -u[e_]) - qp[e_];                  \
         R::matvec(A, rhs_, l);                                                                                        \
     } while (0)
-    // The refactorisation after a rho update is DEFERRED (as in fwd_lane_dense.hip; option "lane_defer"): the group
+    // The refactorisation after a rho update is DEFERRED (as in fwd_lane_dense.hip; knob lane_defer, tuning.h): the group
     // updates rho, 1/rho and the shifted diagonal on the spot and sits out until the wave next runs the sweep -- every
     // `defer`-th trip of the loop, or as soon as no group has anything else to do.  One sweep (~590 instructions, a
     // trip of the iteration is ~150) then serves every group that changed rho since the last one; with 16 problems

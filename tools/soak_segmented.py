@@ -23,7 +23,8 @@ for t in range(trials):
     else: sel = idx >= int(rng.integers(B))
     d = dict(dd); d["P"] = torch.where(sel.view(B, 1, 1), dd["P"], dg["P"]).contiguous()
     g = {k: v.cuda() for k, v in d.items()}
-    _capi.set_option("wpb", int(rng.choice([0, 1])))
+    wpb_draw = int(rng.choice([0, 1]))
+    if _capi.tuning_build(): _capi.set_option("wpb", wpb_draw)   # (developer build only: csrc/tuning.h)
     def fwd(lay):
         if kind == "qp": return ops.qp_forward(g["P"], g["q"], 1e-7, 1000, layout=lay, return_iters=True)
         return ops.qcqp_forward(g["P"], g["q"], g["l_n"], g["mu"], 1e-7, 1000, layout=lay, return_iters=True)
@@ -48,5 +49,5 @@ for t in range(trials):
     if not ok:
         bad += 1
         print("FAIL", t, kind, N, B, mode, int(sel.sum()), flush=True)
-_capi.set_option("wpb", 0)
+if _capi.tuning_build(): _capi.set_option("wpb", 0)
 print("%d trials, %d failures" % (trials, bad))
