@@ -330,13 +330,18 @@ static hipError_t launch_one(const BwdArgs& a, hipStream_t s)
                        a.ir_steps, a.ws, a.pdiag, a.flags);
 }
 
+// Shipped build: four waves per workgroup, non-diagonal tiles always queued (bwd_diag_fuses_fallback); the one-wave
+// workgroups ("wpb" = 1) and the in-kernel general routine ("fuse_fallback" = 1) exist in the developer build only.
 template <int KIND, int N>
 static hipError_t launch_wpb(const BwdArgs& a, int wpb, bool fuse, hipStream_t s)
 {
-    if constexpr (bwd_diag_fuses(N) && KIND != 2) {
-        if (fuse) return wpb == 1 ? launch_one<KIND, N, 1, true>(a, s) : launch_one<KIND, N, 4, true>(a, s);
+    if constexpr (kTuning) {
+        if constexpr (bwd_diag_fuses(N) && KIND != 2) {
+            if (fuse) return wpb == 1 ? launch_one<KIND, N, 1, true>(a, s) : launch_one<KIND, N, 4, true>(a, s);
+        }
+        if (wpb == 1) return launch_one<KIND, N, 1, false>(a, s);
     }
-    return wpb == 1 ? launch_one<KIND, N, 1, false>(a, s) : launch_one<KIND, N, 4, false>(a, s);
+    return launch_one<KIND, N, 4, false>(a, s);
 }
 
 

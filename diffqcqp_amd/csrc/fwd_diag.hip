@@ -20,7 +20,6 @@
 #include <atomic>
 #include <type_traits>
 
-#include "admm_compact.h"
 #include "admm_core.h"
 #include "dense_core.h"
 #include "group_dense.h"
@@ -38,15 +37,13 @@ namespace dqq {
 
 // knob fwd_respread (tuning.h): once at most this many (0..16) of a wave's 32 problems are still iterating, they move onto
 // twice the lanes (admm_core.h admm_fwd_diag_respread; N = 8, two lanes per problem, QP / QCQP).  0 = never.
-// Results do not depend on it (bit-identical, tests/test_gpu_compaction.py).
+// Results do not depend on it (bit-identical, tests/test_gpu_respread.py).
 // knob fwd_respread2: once at most this many (0..8) of the re-spread problems are still iterating, they move again,
 // onto EIGHT lanes per problem (one coordinate per lane).  0 = never.  Bit-identical results.
 int lane_defer_for(int kind); // fwd_lane_dense.hip: the general routines' deferred refactorisation (option lane_defer)
 constexpr bool fwd_diag_respreads(int kind, int n, int lpp) { return kind < 2 && n == 8 && lpp == 2; }
 
-// CMP: the tiles of a workgroup are repacked as their problems stop (admm_compact.h); a workgroup that meets a
-// non-diagonal tile runs the plain per-wave solve instead.
-template <int KIND, int N, int LPP, int WPB, bool FUSE, bool CMP = false>
+template <int KIND, int N, int LPP, int WPB, bool FUSE>
 __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE) void fwd_diag_kernel(const double* __restrict__ P,
                                                             const double* __restrict__ q,
                                                             const double* __restrict__ l_n,
@@ -78,16 +75,13 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
     // the segmented work-list's capacity, kWsSegCap(B) = B/32 + 512 slots per segment, rests on: one tile per wave, the
     // grid exactly ceil(tiles / WPB), at most 256 problems per workgroup
     static_assert(!worklist_segmented(N) || PPW * WPB <= 256, "segmented work-list: at most 256 problems per workgroup");
-    static_assert(!CMP || (WPB > 1 && KIND < 2), "compaction: QP / QCQP, several waves per workgroup");
-    [[maybe_unused]] __shared__ typename std::conditional<CMP, CompactLds<(KIND == 1) ? 1 : 0, N / LPP>, int>::type s_cmp;
-    [[maybe_unused]] bool wg_dense = false;
     // FUSE, N <= 8: a non-diagonal tile is solved by this wave, 64/LD problems at a time with LD = max(N/2, LPP) lanes
     // per problem (group_dense.h): two rows of the matrices per lane keep the general solve inside the register
     // budget of the diagonal arithmetic
     // (one lane per problem, QP / QCQP: the general solve on the caller's mapping too -- a lane per problem, LD == LPP)
     constexpr int LD = (N == 8 && LPP == 1 && KIND < 2) ? 1 : ((N / 2 > LPP) ? N / 2 : LPP);
     constexpr bool GD = FUSE && N <= 8 && LD <= 4 && group_dense_supported(KIND, N, LD);
-    [[maybe_unused]] bool dense_tile = false; // CMP: some tile of this workgroup is not diagonal
+    [[maybe_unused]] bool dense_tile = false; // GD: this tile holds non-diagonal problems
     [[maybe_unused]] unsigned long long pmask = 0;   // N = 8, GD: bit p = problem p of the tile is not diagonal (from the stream)
 
     // the wave index is wave-uniform: in an SGPR, the tile's position (`first`, `nvalid`, pointers) is scalar arithmetic and
@@ -159,7 +153,6 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
     } else if (GD && layout == DQQ_P_DENSE) {
         // the caller declares P general: no diagonal to look for, every tile takes the group solve
         dense_tile = true;
-        wg_dense = true; // (CMP: no tile of this launch takes the diagonal arithmetic, nothing to repack)
 #pragma unroll
         for (int e = 0; e < E; ++e) p[e] = 1.0;
     } else {
@@ -179,7 +172,6 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
                                                 : stream_tile_diag<N, NCH, true, true>(Pw, limit, sd, lane);
             tile_dense = __any(nz != 0);
         }
-        if constexpr (CMP) wg_dense = __syncthreads_or(tile_dense) != 0;
         if constexpr (!GD) {   // (GD: problem by problem, below)
             if (tile_dense && flags_out != nullptr && valid && (lane % LPP) == 0) flags_out[first + pl] = 2; // seen, not diagonal
         }
@@ -215,26 +207,6 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
 
     DQQ_TL(1);
     DQQ_TL(2);
-    if constexpr (CMP) {
-        if (!wg_dense) {
-            if (valid) { // hand the verified diagonal to the backward first: p does not travel with a problem
-                if (flags_out != nullptr && (lane % LPP) == 0) flags_out[first + pl] = 1;
-                if (pdiag_out != nullptr) {
-                    double* pp = pdiag_out + first * N + lane * E;
-#pragma unroll
-                    for (int e = 0; e < E; e += 2) *reinterpret_cast<double2*>(pp + e) = make_double2(p[e], p[e + 1]);
-                }
-            }
-            unsigned live = 0;
-#pragma unroll
-            for (int w = 0; w < WPB; ++w)
-                if (((long)blockIdx.x * WPB + w) * PPW < B) live |= 1u << w;
-            admm_fwd_diag_compact<KIND, E, LPP, WPB>(p, qv, rad, N, eps, mu_prox, max_iter, adaptive, valid, first + pl,
-                                                     x, iters, s_cmp, wave, live);
-            DQQ_TL(5);
-            return;
-        }
-    }
     int it = 0;
     // `mine`: this lane's problem is solved by the diagonal arithmetic below.  A tile with non-diagonal problems hands THOSE
     // to the general solve, problem by problem (round 4, late): which routine solves a problem -- and with it the last
@@ -277,7 +249,7 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
         }
     }
     // N = 8 on two lanes per problem: the tail of the tile moves onto four lanes per problem (admm_core.h)
-    constexpr bool RSP = fwd_diag_respreads(KIND, N, LPP) && !CMP;
+    constexpr bool RSP = fwd_diag_respreads(KIND, N, LPP);
     [[maybe_unused]] bool moved = false; // this lane's problem was finished (and stored) in the re-spread layout
     if (__builtin_expect(!GD || !dense_tile || __any(mine), 1)) {   // (a tile that is all non-diagonal: nothing for it)
         if constexpr (RSP)
@@ -331,36 +303,33 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
     DQQ_TL(5);
 }
 
-template <int KIND, int N, int LPP, int WPB, bool FUSE, bool CMP = false>
+template <int KIND, int N, int LPP, int WPB, bool FUSE>
 static hipError_t launch_one(const FwdArgs& a, hipStream_t s)
 {
     constexpr int PPW = 64 / LPP;
     const long ntiles = (a.B + PPW - 1) / PPW;
     const long nblocks = (ntiles + WPB - 1) / WPB;
     if (nblocks == 0) return hipSuccess;
-    return launch((fwd_diag_kernel<KIND, N, LPP, WPB, FUSE, CMP>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q,
+    return launch((fwd_diag_kernel<KIND, N, LPP, WPB, FUSE>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q,
                        a.l_n, a.mu, a.v, a.x, a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.layout, a.iters, a.ws,
                        a.pdiag_out, a.flags_out, std::min(16, std::max(0, knob_fwd_respread())),
                        std::min(8, std::max(0, knob_fwd_respread2())), lane_defer_for(KIND));
 }
 
-// Option "fwd_compact": 1 = repack the tiles of a workgroup as their problems stop (admm_compact.h).  OFF by
-// default: at the bench shape (B = 65536, iteration counts 8..38) a tile needs 20 % fewer wave-iterations, but
-// every checkpoint costs the workgroup a barrier's worth of imbalance (0.5-1 us) and the launch is bound by its
-// longest problem anyway: QCQP forward 29.4 -> 36.1 us.  It pays for heavy-tailed iteration counts (QP,
-// P = diag(exp(U(-10,10))): 690 -> 480 us).  Instantiated for N = 8, two lanes per problem.
-constexpr bool fwd_diag_compacts(int kind, int n, int lpp) { return kind < 2 && n == 8 && lpp == 2; }
-
+// What the shipped build instantiates is what its routing can reach (tuning.h: the knobs are constants there): four waves
+// per workgroup always; the in-kernel general solve (FUSE) for N <= 8 only.  The developer build adds one wave per
+// workgroup ("wpb" = 1) and the fused form for N = 16 ("fuse_fallback" = 1).
 template <int KIND, int N, int LPP>
 static hipError_t launch_wpb(const FwdArgs& a, int wpb, bool fuse, hipStream_t s)
 {
-    if constexpr (fwd_diag_fuses(N)) {
-        if constexpr (kTuning && fwd_diag_compacts(KIND, N, LPP)) {   // (the compacting kernel exists in the developer build only)
-            if (fuse && wpb != 1 && knob_fwd_compact() > 0) return launch_one<KIND, N, LPP, 4, true, true>(a, s);
+    if constexpr (fwd_diag_fuses(N) && (kTuning || N <= 8)) {
+        if (fuse) {
+            if constexpr (kTuning) { if (wpb == 1) return launch_one<KIND, N, LPP, 1, true>(a, s); }
+            return launch_one<KIND, N, LPP, 4, true>(a, s);
         }
-        if (fuse) return wpb == 1 ? launch_one<KIND, N, LPP, 1, true>(a, s) : launch_one<KIND, N, LPP, 4, true>(a, s);
     }
-    return wpb == 1 ? launch_one<KIND, N, LPP, 1, false>(a, s) : launch_one<KIND, N, LPP, 4, false>(a, s);
+    if constexpr (kTuning) { if (wpb == 1) return launch_one<KIND, N, LPP, 1, false>(a, s); }
+    return launch_one<KIND, N, LPP, 4, false>(a, s);
 }
 
 // Lanes-per-problem choices the kernel is instantiated for (E = N/LPP coordinates per lane,
@@ -416,12 +385,18 @@ static bool launch_kind(const FwdArgs& a, int lpp, int wpb, bool fuse, hipStream
 {
 #define DQQ_CASE(NN, LL) \
     if (a.N == NN && lpp == LL) { err = launch_wpb<KIND, NN, LL>(a, wpb, fuse, s); return true; }
+    // the lane layouts fwd_diag_default_lpp (+ the hint's one lane, + DQQ_P_DENSE's N / 2) can ask for ...
     DQQ_CASE(2, 1)
     DQQ_CASE(4, 1) DQQ_CASE(4, 2)
     DQQ_CASE(8, 1) DQQ_CASE(8, 2) DQQ_CASE(8, 4)
-    DQQ_CASE(16, 2) DQQ_CASE(16, 4) DQQ_CASE(16, 8)
-    DQQ_CASE(32, 4) DQQ_CASE(32, 8) DQQ_CASE(32, 16)
-    DQQ_CASE(64, 8) DQQ_CASE(64, 16) DQQ_CASE(64, 32)
+    DQQ_CASE(16, 4) DQQ_CASE(16, 8)
+    DQQ_CASE(32, 16)
+    DQQ_CASE(64, 32)
+    if constexpr (kTuning) {   // ... and, behind "fwd_lpp" in the developer build, the others the sweeps compared them with
+        DQQ_CASE(16, 2)
+        DQQ_CASE(32, 4) DQQ_CASE(32, 8)
+        DQQ_CASE(64, 8) DQQ_CASE(64, 16)
+    }
 #undef DQQ_CASE
     return false;
 }

@@ -28,7 +28,6 @@ constexpr bool kTuning = false;
 DQQ_KNOB(fwd_lpp, 0)                // lanes per problem of the diagonal forward (0 = from (N, B): fwd_diag_default_lpp)
 DQQ_KNOB(wpb, 0)                    // waves per workgroup of the diagonal kernels (0 = 4)
 DQQ_KNOB(fuse_fallback, -1)         // non-diagonal tiles inside the fast kernel (1), queued (0), by (N, B) (-1)
-DQQ_KNOB(fwd_compact, 0)            // N = 8 forward: repack a workgroup's tiles as problems stop (pays only for heavy tails)
 DQQ_KNOB(fwd_respread, 16)          // N = 8 forward on two lanes: tail of <= this many problems moves to four lanes
 DQQ_KNOB(fwd_respread2, 8)          // ... and of <= this many to eight lanes
 DQQ_KNOB(lane_dense, 1)             // general forward N <= 8: lane-per-problem kernel

@@ -1,6 +1,6 @@
 """Bounded runs of the randomised route fuzzers (tools/fuzz_small.py, tools/fuzz_bwd.py): random kind, size, batch,
 structure, layout and tuning options against the oracle.  A run of tools/fuzz_small.py found the one routing bug of
-round 2 (DQQ_P_DENSE + fwd_compact); these keep the net in place with fixed seeds."""
+round 2 (DQQ_P_DENSE + a since-removed option); these keep the net in place with fixed seeds."""
 import os
 import subprocess
 import sys

@@ -19,7 +19,7 @@ def apply_opts(opts):
     ref = _capi.F_REFERENCE_ORDER if (opts.get("dense_wave64", 1) == 0 or opts.get("wave_qcqp_bwd", 1) == 0) else 0
     if TUNING:
         for k, v in opts.items():
-            if k not in ("dense_wave64", "wave_qcqp_bwd"): _capi.set_option(k, v)
+            if k not in ("dense_wave64", "wave_qcqp_bwd", "fwd_compact"): _capi.set_option(k, v)   # (fwd_compact: removed in round 5; still drawn so that a seed names the same trials)
     return ref
 
 
