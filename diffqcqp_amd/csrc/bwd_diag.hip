@@ -72,8 +72,12 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : (KIND == 1 ? 4 :
     const long tile = (long)blockIdx.x * WPB + wave;
     const long first = tile * T;
     if (first >= B) return; // whole wave leaves; no workgroup barrier is used below
-    if constexpr (!FUSE) {   // this launch may fill the work-list: the words only its drain writes start from zero (launch.h)
-        if (tile == 0 && ws != nullptr && layout == DQQ_P_AUTO) worklist_prepare(ws, threadIdx.x & 63);
+    // this launch may fill the work-list: the words only its drain writes must be zero (launch.h, work-list hygiene) -- loaded
+    // here by the first wave, looked at below, once its tile of P has been streamed
+    [[maybe_unused]] WorklistIdle idle{0, 0, 0, 0};
+    const bool prepares = !FUSE && tile == 0 && ws != nullptr && layout == DQQ_P_AUTO;
+    if constexpr (!FUSE) {
+        if (prepares) idle = worklist_prepare_begin(ws, threadIdx.x & 63);
     }
     const int nvalid = (B - first) < T ? (int)(B - first) : T;
     const int pl = lane / HL, j = lane % HL;
@@ -118,6 +122,9 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : (KIND == 1 ? 4 :
             const unsigned nz = (nvalid == T) ? stream_tile_diag<N, N, false>(Pw, limit, pd, lane)
                                               : stream_tile_diag<N, N, true>(Pw, limit, pd, lane);
             tile_dense = __any(nz != 0); // wave-uniform
+        }
+        if constexpr (!FUSE) {
+            if (prepares) worklist_prepare_end(ws, lane, idle);
         }
         if constexpr (FUSE) {
             if (tile_dense) {

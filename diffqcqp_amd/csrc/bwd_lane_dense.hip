@@ -537,6 +537,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, (KIND == 
     using S = LaneSys<KIND, N>;
     constexpr int M = S::M, NC = S::NC;
     constexpr bool LIST = MODE == 1, REPORT = MODE == 2;
+    if constexpr (LIST) {   // an empty list: every wave leaves on one scalar load, before the hygiene checks of launch.h
+        if (ws[kWsCount] == 0) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) worklist_feedback(feedback, ws, B, 0);
+            return;
+        }
+        asm volatile("" ::: "memory");
+    }
     const long total = LIST ? worklist_checked_count(ws, ws + kWsCount, kWsEntryInts(B)) : B;   // problems of this launch
     if constexpr (LIST) {
         if (blockIdx.x == 0 && threadIdx.x == 0) worklist_feedback(feedback, ws, B, total);

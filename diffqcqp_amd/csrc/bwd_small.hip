@@ -18,6 +18,10 @@ __global__ __launch_bounds__(256, (SmallSys<KIND, N>::M > 16 ? 1 : 2)) void bwd_
     // An empty work-list -- what this launch finds behind every backward of a diagonal batch -- leaves on ONE scalar load, before
     // anything else: with the exit below the lane / team arithmetic the compiler had put a register spill (a scratch store by each
     // of the 4096 waves) in front of it, and the headline step paid 4.5 us for it (round 4, A/B of the builds).
+    // (round 5: the hygiene checks of launch.h come BEHIND that exit too -- in front of it they cost every empty drain 0.4 us,
+    // A/B of the builds: tools/ab_libs.py)
+    if (use_worklist && ws[kWsCount] == 0) return;
+    asm volatile("" ::: "memory");
     const long count = use_worklist ? worklist_checked_count(ws, ws + kWsCount, kWsEntryInts(B)) : B;
     if (count == 0) return;
     asm volatile("" ::: "memory");

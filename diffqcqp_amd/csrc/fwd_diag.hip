@@ -97,8 +97,12 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
     if (B < 0) junk[lane % DQQ_PROBE_SCRATCH] = eps;
 #endif
     if (first >= B) return; // whole wave leaves before any workgroup barrier
-    if constexpr (!FUSE) {   // this launch may fill the work-list: the words only its drain writes start from zero (launch.h)
-        if (tile == 0 && ws != nullptr && layout == DQQ_P_AUTO) worklist_prepare(ws, lane);
+    // this launch may fill the work-list: the words only its drain writes must be zero (launch.h, work-list hygiene) -- loaded
+    // here by the first wave, looked at where the tile is queued
+    [[maybe_unused]] WorklistIdle idle{0, 0, 0, 0};
+    [[maybe_unused]] const bool prepares = !FUSE && tile == 0 && ws != nullptr && layout == DQQ_P_AUTO;
+    if constexpr (!FUSE) {
+        if (prepares) idle = worklist_prepare_begin(ws, lane);
     }
     DQQ_TL(0);
     const int nvalid = (B - first) < PPW ? (int)(B - first) : PPW;
@@ -185,6 +189,7 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
                 return;
             }
         } else {
+            if (prepares) worklist_prepare_end(ws, lane, idle);
             const bool queued = worklist_push<AGG, worklist_segmented(N)>(ws, B, first, tile_dense ? nvalid : 0, lane, s_cnt);
             if (tile_dense) {
                 if (!queued && valid) {   // (launch.h, work-list hygiene: the tile will not be solved -- say so in its outputs)

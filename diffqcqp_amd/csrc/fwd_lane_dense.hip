@@ -138,6 +138,7 @@ __global__ __launch_bounds__(64, 1) void fwd_lane_dense_kernel(const double* __r
     // KIND 2 / 3 (box / signed box QP, Solver.cpp:198-261 / 374-439): l_n = l_min, mu_c = l_max per coordinate
     static_assert(N % 2 == 0, "even N");
     constexpr bool QP_LIKE = (KIND != 1);
+    if (use_worklist && ws[kWsCount] == 0) return;   // an empty list: one scalar load, before the hygiene checks of launch.h
     const long count = use_worklist ? worklist_checked_count(ws, ws + kWsCount, kWsEntryInts(B)) : B;
     const long slot = (long)blockIdx.x * 64 + threadIdx.x;
     const bool valid = slot < count;

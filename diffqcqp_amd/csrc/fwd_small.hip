@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256, N >= 14 ? 1 : 2) void fwd_small_kernel(const d
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int team = lane / T, tl = lane % T;
+    if (use_worklist && ws[kWsCount] == 0) return;   // an empty list: one scalar load, before the hygiene checks of launch.h
     const long count = use_worklist ? worklist_checked_count(ws, ws + kWsCount, kWsEntryInts(B)) : B;
     const long slot = ((long)blockIdx.x * wpb + wave) * TP + team;
     if (((long)blockIdx.x * wpb + wave) * TP >= count) { // a wave beyond the end of the list: only the reset ticket

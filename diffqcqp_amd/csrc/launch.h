@@ -49,8 +49,9 @@ DQQ_HD constexpr long kWsEntryInts(long B) { return 32 * kWsSegCap(B); }
 // ---- work-list hygiene (round 5).  The protocol rests on an invariant -- "zero-filled once, every call leaves the header
 // zeroed" -- that a caller can break: a workspace that was never zeroed, memory scribbled over, a launch chain cut short by an
 // error.  The kernels therefore do not TRUST the header:
-//   * the fast kernel that is about to fill the list first re-zeroes every word only the drain kernel writes (exit tickets,
-//     pick-up counters: worklist_prepare -- they are idle while it runs, so this is not a race) -- whatever they held is repaired;
+//   * the fast kernel that fills the list re-zeroes every word only the drain kernel writes that is not zero (exit tickets,
+//     pick-up counters: worklist_prepare_begin / _end -- they are idle while it runs, so this is not a race) -- whatever they
+//     held is repaired;
 //   * a push whose slot would fall outside the entry area is not performed: the caller poisons that tile's outputs with NaN
 //     and the header is marked dirty (worklist_push_entries returns false);
 //   * a drain kernel clamps the count it reads to the entry area and replaces an entry that is not a problem of this batch
@@ -82,12 +83,31 @@ static DQQ_D long worklist_checked_entry(const int* ws, long e, long B)
     }
     return e;
 }
-// Call from ONE wave of the fast kernel (the first of workgroup 0), before anything is pushed.
-static DQQ_D void worklist_prepare(int* __restrict__ ws, int lane)
+// ONE wave of the fast kernel (the first of workgroup 0) LOADS those words when it starts (worklist_prepare_begin: the loads
+// are in flight while the wave does its own tile) and looks at them when it is done (worklist_prepare_end): only a word that
+// is not zero is written.  On the path every call takes this costs a handful of instructions and no wait; unconditional
+// stores to the ~100 cache lines these words sit on delayed that wave -- and with it the end of an 8 us backward -- by
+// 0.2 us (A/B of the builds, tools/ab_libs.py).  The drain is launched behind the fast kernel: the end of it is early enough.
+struct WorklistIdle {
+    int sub, sub_hi, segnext, head;   // lane < 32: its sub-ticket (two words) and segment pick-up; lane 0: ticket | next | report words
+};
+static DQQ_D WorklistIdle worklist_prepare_begin(const int* __restrict__ ws, int lane)
 {
+    WorklistIdle w{0, 0, 0, 0};
+    if (lane < 32) {
+        w.sub = ws[kWsSubTickets + lane * kWsSubStride];
+        w.sub_hi = ws[kWsSubTickets + lane * kWsSubStride + 1];   // (the high word of the 64-bit report counters, bwd_lane_dense.hip)
+        w.segnext = ws[kWsSegNext + lane * kWsSubStride];
+    }
+    if (lane == 0) w.head = ws[kWsTicket] | ws[kWsNext] | ws[kWsRepTop] | ws[kWsRepTop + 1];
+    return w;
+}
+static DQQ_D void worklist_prepare_end(int* __restrict__ ws, int lane, const WorklistIdle& w)
+{
+    if ((w.sub | w.sub_hi | w.segnext | w.head) == 0) return;
     if (lane < 32) {
         ws[kWsSubTickets + lane * kWsSubStride] = 0;
-        ws[kWsSubTickets + lane * kWsSubStride + 1] = 0;   // (the high word of the 64-bit report counters, bwd_lane_dense.hip)
+        ws[kWsSubTickets + lane * kWsSubStride + 1] = 0;
         ws[kWsSegNext + lane * kWsSubStride] = 0;
     }
     if (lane == 0) {
@@ -302,8 +322,8 @@ static DQQ_D bool worklist_push(int* __restrict__ ws, long B, long first, int n,
 // counters do not change while a drain kernel runs (the last participant out re-zeroes them, worklist_release).
 static DQQ_D long worklist_count(const int* __restrict__ ws, int N, long B)
 {
+    if (ws[kWsCount] == 0) return 0;   // (an empty list, either kind: one load)
     if (!worklist_segmented(N)) return worklist_checked_count(ws, ws + kWsCount, kWsEntryInts(B));
-    if (ws[kWsCount] == 0) return 0;
     long c = 0;
 #pragma unroll
     for (int h = 0; h < 32; ++h) c += worklist_checked_count(ws, ws + kWsSegCounts + h * kWsSubStride, kWsSegCap(B));

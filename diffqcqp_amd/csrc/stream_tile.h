@@ -75,7 +75,10 @@ static DQQ_D unsigned long long stream_tile_diag_pmask8(const double* __restrict
 {
     constexpr int N = 8;
     static_assert(NCH <= 32, "at most 64 problems per tile");
-    unsigned long long pmask = 0;
+    // every chunk's verdict is kept (NCH <= 16 registers, live only here, next to the 2 * U of the loads in flight) and only
+    // OR-ed on the path a diagonal tile takes; the ballots that turn them into a per-problem mask run for a tile that HAS a
+    // non-zero off-diagonal.  (With a ballot per chunk on every tile the headline's forwards read 1-1.5 % slower, A/B.)
+    unsigned bs[NCH], nz = 0;
     constexpr int U = NCH < 16 ? NCH : 16;
 #pragma unroll
     for (int k0 = 0; k0 < NCH; k0 += U) {
@@ -95,9 +98,17 @@ static DQQ_D unsigned long long stream_tile_diag_pmask8(const double* __restrict
             if (c == r) { sd[row] = v[j].x; b = b1; }
             else if (c + 1 == r) { sd[row] = v[j].y; b = b0; }
             else b = b0 | b1;
-            const unsigned long long m = __ballot(b != 0);
+            bs[k0 + j] = b;
+            nz |= b;
+        }
+    }
+    unsigned long long pmask = 0;
+    if (__builtin_expect(__any(nz != 0), 0)) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const unsigned long long m = __ballot(bs[k] != 0);
             const unsigned long long two = ((m & 0xffffffffull) != 0 ? 1ull : 0ull) | ((m >> 32) != 0 ? 2ull : 0ull);
-            pmask |= two << (2 * (k0 + j));
+            pmask |= two << (2 * k);
         }
     }
     return pmask;
