@@ -54,12 +54,13 @@ static hipError_t launch_small(const BwdArgs& a, bool use_worklist, hipStream_t 
     const long per_block = (long)WPB * TP;
     const long need = (a.B + per_block - 1) / per_block;
     const long cap = 256L * 16;
-    // work-list mode: the list holds at most B entries (a small batch does not pay for 1024 idle workgroups);
-    // beyond 1024 persistent workgroups the team kernel gets slower, not faster (65536 x 8 dense: 102 vs 155 us)
-#if defined(DQQ_SMALL_WPB)
-    const long lim = use_worklist ? 4096 / WPB : cap;
+    // work-list mode: the list holds at most B entries (a small batch does not pay for idle workgroups); persistent
+    // workgroups, 65536 x 8 dense QCQP list, us: 128: 279, 256: 150, 512: 110, 1024: 114, 4096: 155 -- and an EMPTY list costs
+    // the same launch latency whatever the grid (round 5, profiles/r06l_drain_grid.txt)
+#if defined(DQQ_SMALL_LIST_GRID)   // developer A/B (tools/ab_libs.py)
+    const long lim = use_worklist ? DQQ_SMALL_LIST_GRID : cap;
 #else
-    const long lim = use_worklist ? 1024 : cap;
+    const long lim = use_worklist ? 512 : cap;
 #endif
     const unsigned grid = (unsigned)(need < lim ? (need > 0 ? need : 1) : lim);
     auto kernel = bwd_small_kernel<KIND, N>;
