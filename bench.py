@@ -109,8 +109,10 @@ class Chain:
         self.names = [kind + "_fwd"] + ([kind + "_bwd"] if backward else [])
         self.ws = {}
         self.calls = {}
-        self.ops = ops
+        self.ops, self.capi = ops, _capi
         self.handoff = structure == "diag" and layout == 0
+        self.kidx = 0 if kind == "qp" else 1
+        self.hinted = layout == 0 and N <= 8
 
     def _make_set(self, seed):
         B, N, dev = self.B, self.N, self.dev
@@ -140,33 +142,38 @@ class Chain:
             self.ws[stream] = self.ops._workspace(self.dev, self.B, stream)
         return self.ws[stream]
 
-    def _call(self, which, stream, s):
+    def _call(self, which, stream, s, flags=0, report=None):
         """(C-ABI function, full argument tuple) of one launch -- every pointer resolved ONCE (the host
-        side of a 56 us step must not re-resolve 16 data_ptr() per call)."""
+        side of a 56 us step must not re-resolve 16 data_ptr() per call).  flags / report: the caller's side of the hint
+        protocol of include/diffqcqp_hip.h (what diffqcqp_amd.ops does for its callers)."""
         t, L, p = self.sets[s], self.lib, (lambda a: a.data_ptr())
         ws = self.workspace(stream)
         wsb, B, N = ws.numel() * 4, self.B, self.N
+        lay = self.layout | flags
         # the verified-diagonal hand-off exists for DQQ_P_AUTO only (diffqcqp_amd/qcqp.py: _cache_for): a batch declared
         # dense passes no pdiag / flags (with them the C ABI would clear the flags with a memset launch per forward)
         pd, fl = (p(t["pdiag"]), p(t["flags"])) if self.layout == 0 else (None, None)
         if which == 0 and self.kind == "qp":
-            return L.dqq_qp_fwd_f64, (p(t["P"]), p(t["q"]), p(t["x"]), B, N, EPS, MU_PROX, MAX_ITER, 1, self.layout, None,
+            return L.dqq_qp_fwd_f64, (p(t["P"]), p(t["q"]), p(t["x"]), B, N, EPS, MU_PROX, MAX_ITER, 1, lay, None,
                                       pd, fl, p(ws), wsb, stream)
         if which == 0:
             return L.dqq_qcqp_fwd_f64, (p(t["P"]), p(t["q"]), p(t["l_n"]), p(t["mu"]), p(t["x"]), B, N, EPS, MU_PROX,
-                                        MAX_ITER, 1, self.layout, None, pd, fl, p(ws), wsb, stream)
+                                        MAX_ITER, 1, lay, None, pd, fl, p(ws), wsb, stream)
         if self.kind == "qp":
             return L.dqq_qp_bwd_f64, (p(t["P"]), p(t["q"]), p(t["x"]), p(t["g"]), p(t["gP"]), p(t["gq"]), B, N, 1e-10,
-                                      self.layout, None, pd, fl, p(ws), wsb, stream)
+                                      lay, None, pd, fl, report, p(ws), wsb, stream)
         return L.dqq_qcqp_bwd_f64, (p(t["P"]), p(t["q"]), p(t["l_n"]), p(t["mu"]), p(t["x"]), p(t["g"]), p(t["gP"]),
-                                    p(t["gq"]), p(t["gl"]), p(t["gm"]), None, None, B, N, 1e-10, self.layout, None,
-                                    pd, fl, p(ws), wsb, stream)
+                                    p(t["gq"]), p(t["gl"]), p(t["gm"]), None, None, B, N, 1e-10, lay, None,
+                                    pd, fl, report, p(ws), wsb, stream)
 
     def launch(self, which, stream, s=0):
-        key = (which, stream, s)
+        flags, report = 0, None
+        if self.hinted:   # DQQ_P_AUTO, N <= 8: read this (device, kind, N)'s report word, derive the flags (pure function)
+            flags, report = self.capi.hint(self.kidx, which, self.N, self.B, self.dev.index)
+        key = (which, stream, s, flags)
         c = self.calls.get(key)
         if c is None:
-            c = self.calls[key] = self._call(which, stream, s)
+            c = self.calls[key] = self._call(which, stream, s, flags, report)
         rc = c[0](*c[1])
         if rc != 0:
             raise RuntimeError("launch %s failed with %d" % (self.names[which], rc))
@@ -255,7 +262,7 @@ def gpu_environment():
            "HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG"), "device": torch.cuda.get_device_name(0)}
     try:
         from diffqcqp_amd import _capi
-        env["dqq_feedback"] = _capi._feedback is not None   # dqq_set_feedback registered (DQQ_FEEDBACK=0 turns it off)
+        env["dqq_hints"] = bool(_capi._hints_on)   # the caller-side route hints of _capi.py (DQQ_FEEDBACK=0 turns them off)
     except Exception:
         pass
     try:
@@ -353,7 +360,6 @@ def pmc_child(cfg):
     dev = torch.device("cuda", 0)
     from diffqcqp_amd import _capi, ops
     _capi.lib()
-    ops.feedback_default()
     _, families, B_total, _, _ = WORKLOADS[cfg]
     chains = [Chain(f[0], B_total, f[1], f[2], f[3], dev, 1000 + 17 * (0 if cfg >= 8 else min(cfg, 6)) + 31 * i,
                     layout=(f[4] if len(f) > 4 else 0)) for i, f in enumerate(families)]
@@ -864,16 +870,16 @@ def dense_p_record(args, ctx):
     rec["auto_ms_per_fwd_bwd"], rec["dense_ms_per_fwd_bwd"] = rec["auto"]["ms_per_step"], rec["dense"]["ms_per_step"]
     rec["auto_over_dense"] = rec["auto_ms_per_fwd_bwd"] / rec["dense_ms_per_fwd_bwd"]
     # "auto" above is the steady state of a caller that presents this kind of batch step after step: from the third step on
-    # the feedback word (dqq_set_feedback) has moved the forward to four lanes per problem and the backward to
-    # one launch of the lane-per-problem kernel.  The same through the routes the arguments alone determine (a first call,
-    # a captured graph, DQQ_FEEDBACK=0):
+    # the caller-side hints (include/diffqcqp_hip.h: dqq_hint_flags) have moved the forward to one lane per
+    # problem and the backward to one launch of the lane-per-problem kernel.  The same without hints (a first call, a
+    # captured graph, DQQ_FEEDBACK=0):
     capi = ctx["capi"]
-    if capi._feedback is not None:
+    if capi._hints_on:
         capi.enable_feedback(False)
         try:
             rec["auto_no_hint_ms_per_fwd_bwd"] = measure(6, args, ctx, light=True)["ms_per_step"]
         finally:
-            capi.enable_feedback(True)   # (the same buffer, its words as they were: _capi.enable_feedback)
+            capi.enable_feedback(True)   # (the words as they were)
     return rec
 
 
@@ -1009,8 +1015,6 @@ def main():
     if use_dist:
         dist.barrier()
     _capi.lib()
-    from diffqcqp_amd import ops as _ops
-    _ops.feedback_default()   # what ops.*_backward does on its first DQQ_P_AUTO call (the chains below call the C ABI directly)
     ctx = {"rank": rank, "world": world, "dev": dev, "use_dist": use_dist, "dist": dist, "parallel": parallel,
            "capi": _capi, "side": torch.cuda.Stream(),
            # the counter passes run for a plain one-GPU run of a whole workload (not for sub-records, not under RCCL)

@@ -21,6 +21,7 @@ PYMOD_PATH = os.path.join(_HERE, "lib", "_dqq.so")
 
 P_AUTO, P_DENSE, P_DIAG = 0, 1, 2
 F_REFERENCE_ORDER = 0x100   # DQQ_F_REFERENCE_ORDER: ORed into p_layout (16 < N <= 64 on the reference-order kernels)
+F_EXPECT_DENSE, F_EXPECT_LONG_LIST = 0x200, 0x400   # hint flags (dqq_hint_flags): routes of identical results
 
 _ERRORS = {
     -1: "DQQ_E_NULLPTR: a required pointer is NULL",
@@ -42,10 +43,10 @@ SIGNATURES = {
     "dqq_workspace_reset": ([_vp, _sz, _vp], _i),
     "dqq_workspace_status": ([_vp, _sz, _vp, ctypes.POINTER(_i)], _i),
     "dqq_qp_fwd_f64": ([_vp, _vp, _vp, _i64, _i, _d, _d, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp], _i),
-    "dqq_qp_bwd_f64": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp], _i),
+    "dqq_qp_bwd_f64": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _d, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp], _i),
     "dqq_qcqp_fwd_f64": ([_vp, _vp, _vp, _vp, _vp, _i64, _i, _d, _d, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp], _i),
     "dqq_qcqp_bwd_f64": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _d, _i, _vp, _vp, _vp,
-                          _vp, _sz, _vp], _i),
+                          _vp, _vp, _sz, _vp], _i),
     "dqq_boxqp_fwd_f64": ([_vp, _vp, _vp, _vp, _vp, _i64, _i, _d, _d, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp], _i),
     "dqq_signedboxqp_fwd_f64": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _d, _d, _i, _i, _i, _vp, _vp, _vp, _vp, _sz,
                                  _vp], _i),
@@ -53,7 +54,8 @@ SIGNATURES = {
                            _vp, _sz, _vp], _i),
     "dqq_set_option": ([ctypes.c_char_p, _i], _i),
     "dqq_get_option": ([ctypes.c_char_p, ctypes.POINTER(_i)], _i),
-    "dqq_set_feedback": ([_vp, _sz], _i),
+    "dqq_hint_flags": ([_i, _i, _i, _i64, ctypes.c_ulonglong], _i),
+    "dqq_device_pointer": ([_vp, ctypes.POINTER(_vp)], _i),
     "dqq_version": ([], ctypes.c_char_p),
 }
 
@@ -69,8 +71,6 @@ def ctypes_lib():
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
     handle = ctypes.CDLL(LIB_PATH)
     for name, (argtypes, restype) in SIGNATURES.items():
-        if os.environ.get("DQQ_LIB") and name == "dqq_set_feedback" and not hasattr(handle, name):
-            continue   # (developer A/B against a build that predates the entry point: ops.feedback_default then finds no hint)
         fn = getattr(handle, name)  # AttributeError if the library does not export it
         fn.argtypes = argtypes
         fn.restype = restype
@@ -158,44 +158,78 @@ def get_option(name):
     return v.value
 
 
-FEEDBACK_BYTES = 128   # DQQ_FEEDBACK_BYTES
-_feedback = None       # the buffer while it is REGISTERED with the library (None: not registered)
-_feedback_buf = None   # the pinned tensor itself: allocated once, never freed (see enable_feedback)
+# ---- the route hints (include/diffqcqp_hip.h: "adapting to the data without state in the library") ----------------------
+# The C library keeps no state.  This module does what its header describes for a caller: one 8-byte report word of pinned host
+# memory per (device, kind, N) -- 16 words per device --, handed to the backward calls as `report`, read back with a plain host
+# load before every call and turned into hint flags by the pure function dqq_hint_flags.  A hint selects between kernels of
+# identical results; no hints are given while the current stream is being captured.  On by default (the first backward of an
+# N <= 8 DQQ_P_AUTO batch creates the device's words; DQQ_FEEDBACK=0 in the environment turns it off).
+HINT_WORDS = 16
+_hints_on = os.environ.get("DQQ_FEEDBACK", "1") != "0"
+_hint_store = {}       # device index -> (pinned int64 tensor, host address, device address); never freed (in-flight launches
+                       # and captured graphs hold the device address)
+_feedback = None       # the words of cuda:0 (tests poke them), None until created / when off
 
 
 def enable_feedback(on=True):
-    """Register (or unregister) the feedback buffer of include/diffqcqp_hip.h dqq_set_feedback: 128 bytes of pinned host
-    memory through which the drain launch of the N <= 8 backward tells the next call how many non-diagonal problems it found.
-    A timing hint only -- results are the same bits with and without.  Needs a GPU (pinned memory).
-
-    The pinned buffer lives as long as the process: drain kernels still in flight, and launches captured into a
-    HIP graph while it was registered, hold its device address and may store into it at any later time -- memory handed back
-    to torch's pinned allocator could by then belong to someone else.  Unregistering only makes the library stop passing the
-    address to NEW launches and stop reading the words; registering again hands the library the same buffer with its words
-    as they are (consistent with the per-workspace record of what was last sent, csrc/launch.h: a zeroed buffer at the same
-    address would never be written again for an unchanged count)."""
-    global _feedback, _feedback_buf
+    """Turn the hints on or off for this process (the words stay where they are: launches in flight and captured graphs may
+    still write to them; switched on again, the words are as they were left)."""
+    global _hints_on, _feedback
+    _hints_on = bool(on)
     if not on:
-        check(lib().dqq_set_feedback(None, 0), "dqq_set_feedback(NULL)")
         _feedback = None
-        return
-    if _feedback is None:
-        if _feedback_buf is None:
-            _feedback_buf = torch.zeros(FEEDBACK_BYTES // 8, dtype=torch.int64).pin_memory()
-        check(lib().dqq_set_feedback(_feedback_buf.data_ptr(), FEEDBACK_BYTES), "dqq_set_feedback")
-        _feedback = _feedback_buf
+    elif torch.cuda.is_available():
+        _feedback = _words(0)[0]
 
 
-def feedback_words():
-    """The registered buffer's words as (B, entries) pairs, index kind * 4 + N / 2 - 1 (a debugging view), or None."""
-    if _feedback is None:
+def _words(dev_index):
+    st = _hint_store.get(dev_index)
+    if st is None:
+        buf = torch.zeros(HINT_WORDS, dtype=torch.int64).pin_memory()
+        if binding() == "pybind11":
+            rc, dev = lib().dqq_device_pointer(buf.data_ptr())
+        else:
+            out = _vp(0)
+            rc = lib().dqq_device_pointer(buf.data_ptr(), ctypes.byref(out))
+            dev = out.value or 0
+        check(rc, "dqq_device_pointer")
+        st = _hint_store[dev_index] = (buf, buf.data_ptr(), dev)
+        if dev_index == 0:
+            global _feedback
+            _feedback = buf
+    return st
+
+
+def hint_index(kind, N):
+    return kind * 4 + N // 2 - 1 if (kind in (0, 1) and 2 <= N <= 8 and N % 2 == 0) else -1
+
+
+def hint(kind, pas, N, B, dev_index, capturing=False):
+    """-> (flags to OR into p_layout, device address of the report word or None) for a DQQ_P_AUTO call of (kind, pass, N, B)
+    on device dev_index.  (0, None) when hints are off or do not apply; no flags while capturing."""
+    i = hint_index(kind, N)
+    if not _hints_on or i < 0:
+        return 0, None
+    _, host, dev = _words(dev_index)
+    if capturing:
+        return 0, dev + 8 * i
+    word = ctypes.c_ulonglong.from_address(host + 8 * i).value
+    flags = lib().dqq_hint_flags(kind, pas, N, B, word) if word else 0
+    return flags, dev + 8 * i
+
+
+def feedback_words(dev_index=0):
+    """The report words of a device as (B, entries) pairs, index kind * 4 + N / 2 - 1 (a debugging view), or None."""
+    if not _hints_on or dev_index not in _hint_store:
         return None
-    return [((int(w) >> 32) & 0x3fffffff, int(w) & 0x7fffffff) for w in _feedback.tolist()]   # (bit 31: entries are single problems)
+    return [((int(w) >> 32) & 0x3fffffff, int(w) & 0x7fffffff) for w in _hint_store[dev_index][0].tolist()]   # (bit 31: entries are single problems)
 
 
-def feedback_streaks():
+def feedback_streaks(dev_index=0):
     """Bits 62..63 of each word: consecutive earlier reports of "three quarters of the batch or more" (saturating at 3)."""
-    return None if _feedback is None else [(int(w) >> 62) & 3 for w in _feedback.tolist()]
+    if not _hints_on or dev_index not in _hint_store:
+        return None
+    return [(int(w) >> 62) & 3 for w in _hint_store[dev_index][0].tolist()]
 
 
 def version():

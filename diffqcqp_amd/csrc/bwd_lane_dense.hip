@@ -745,7 +745,7 @@ static hipError_t launch_lane_bwd(const BwdArgs& a, hipStream_t s)
     }
     return launch(bwd_lane_dense_kernel<KIND, N, MODE>, dim3((unsigned)grid), dim3(64), lds, s, a.P, a.q, a.l_n, a.mu, a.x,
                   a.grad_x, a.grad_P, a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.epsilon, a.ir_steps, a.ws,
-                  MODE != 0 ? worklist_feedback_slot(KIND, N) : nullptr);
+                  (MODE != 0 && hint_applies(KIND, N)) ? a.report : nullptr);
 }
 
 // P declared dense, QP / QCQP, N = 2, 4, 6, 8, batches that fill the chip: a lane per problem needs 64 problems per wave

@@ -71,7 +71,7 @@ static hipError_t launch_small(const BwdArgs& a, bool use_worklist, hipStream_t 
     }
     return launch(kernel, dim3(grid), dim3(64 * WPB), lds_bytes, s, a.P, a.q, a.l_n, a.mu, a.x, a.grad_x, a.grad_P,
                        a.grad_q, a.grad_l_n, a.grad_mu, a.gamma, a.dgamma, a.B, a.epsilon, a.ir_steps, a.ws,
-                       use_worklist ? 1 : 0, use_worklist ? worklist_feedback_slot(KIND, N) : nullptr);
+                       use_worklist ? 1 : 0, (use_worklist && hint_applies(KIND, N)) ? a.report : nullptr);
 }
 
 // The box QP instantiations (M = 3N: 24 unknowns at N = 8) exist and are correct, but run out of registers

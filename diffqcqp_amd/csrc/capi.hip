@@ -40,15 +40,17 @@ Option g_options[] = {{"lane_list_drains", &dqq::g_lane_list_drains},
 };
 
 // p_layout as passed = layout | flags
+constexpr int kAllFlags = DQQ_F_REFERENCE_ORDER | DQQ_F_EXPECT_DENSE | DQQ_F_EXPECT_LONG_LIST;
 int layout_of(int p_layout) { return p_layout & 0xff; }
 bool ref_order_of(int p_layout) { return (p_layout & DQQ_F_REFERENCE_ORDER) != 0; }
+int hints_of(int p_layout) { return p_layout & (DQQ_F_EXPECT_DENSE | DQQ_F_EXPECT_LONG_LIST); }
 
 int check_common(int64_t B, int N, int p_layout, bool qcqp)
 {
     if (B < 0 || N < 1 || B > 0x7fffffffLL) return DQQ_E_BAD_SIZE;
     if (qcqp && (N % 2) != 0) return DQQ_E_BAD_SIZE;
     const int layout = layout_of(p_layout);
-    if ((p_layout & ~(0xff | DQQ_F_REFERENCE_ORDER)) != 0) return DQQ_E_BAD_LAYOUT;   // unknown flag bits
+    if ((p_layout & ~(0xff | kAllFlags)) != 0) return DQQ_E_BAD_LAYOUT;   // unknown flag bits
     if (layout != DQQ_P_AUTO && layout != DQQ_P_DENSE && layout != DQQ_P_DIAG) return DQQ_E_BAD_LAYOUT;
     return 0;
 }
@@ -126,21 +128,30 @@ int dqq_set_option(const char* name, int value)
     return DQQ_E_BAD_OPTION;
 }
 
-int dqq_set_feedback(void* host_buffer, size_t bytes)
+int dqq_hint_flags(int kind, int pass, int N, int64_t B, unsigned long long last_report)
 {
-    static_assert(DQQ_FEEDBACK_BYTES == dqq::kFeedbackWords * sizeof(unsigned long long), "feedback words");
-    if (host_buffer == nullptr) {
-        dqq::g_feedback_host.store(nullptr);
-        dqq::g_feedback_dev.store(nullptr);
-        return 0;
+    // pure: the flags a caller may OR into p_layout for a call of (kind, pass, N, B) when the last backward of that kind and N
+    // left `last_report` in the caller's report word (launch.h).  0 whenever the word says nothing about such a batch.
+    if (!dqq::hint_applies(kind, N) || B <= 0 || (pass != 0 && pass != 1)) return 0;
+    int flags = 0;
+    if (pass == 0) {
+        // forward, N = 8: half of the batch or more sat in 16-problem blocks with a non-diagonal problem
+        if (N == 8 && 2 * dqq::report_count_in_blocks(last_report, (long)B) >= B) flags |= DQQ_F_EXPECT_DENSE;
+        return flags;
     }
-    if (bytes < DQQ_FEEDBACK_BYTES || (reinterpret_cast<uintptr_t>(host_buffer) & 7) != 0) return DQQ_E_BAD_SIZE;
-    void* dev = nullptr;
-    const hipError_t e = hipHostGetDevicePointer(&dev, host_buffer, 0);   // (pinned / registered host memory only)
-    if (e != hipSuccess) return (int)e;
-    dqq::g_feedback_dev.store(static_cast<unsigned long long*>(dev));
-    dqq::g_feedback_host.store(static_cast<const volatile unsigned long long*>(host_buffer));
-    return 0;
+    if (!dqq::bwd_lane_dense_supported(kind, N, (long)B)) return 0;
+    int streak = 0;
+    const long c = dqq::report_count(last_report, (long)B, &streak);
+    if (4 * c >= 3 * B && streak >= 1) flags |= DQQ_F_EXPECT_DENSE;              // all non-diagonal, twice running
+    if (dqq::bwd_lane_dense_supported(kind, N, c)) flags |= DQQ_F_EXPECT_LONG_LIST; // a list that fills the chip
+    return flags;
+}
+
+int dqq_device_pointer(void* pinned_host, void** device)
+{
+    if (pinned_host == nullptr || device == nullptr) return DQQ_E_NULLPTR;
+    if ((reinterpret_cast<uintptr_t>(pinned_host) & 7) != 0) return DQQ_E_BAD_SIZE;
+    return (int)hipHostGetDevicePointer(device, pinned_host, 0);   // (pinned / registered host memory only)
 }
 
 int dqq_get_option(const char* name, int* value)
@@ -151,10 +162,9 @@ int dqq_get_option(const char* name, int* value)
     return DQQ_E_BAD_OPTION;
 }
 
-// Routing is a function of (kind, N, B, p_layout) only: two calls with the same arguments launch the same kernels, whatever
-// ran before them, on whatever thread or stream.  (One exception, opt-in: with a feedback buffer registered -- dqq_set_feedback
-// -- an N <= 8 DQQ_P_AUTO call is routed between kernels of IDENTICAL results by what the last backward of its kind found,
-// launch.h.  The developer build, -DDQQ_TUNING, adds the knobs of tuning.h.)
+// Routing is a function of (kind, N, B, p_layout) only -- p_layout including the caller's hint flags --: two calls with the
+// same arguments launch the same kernels, whatever ran before them, on whatever thread or stream.  The library keeps no
+// state.  (The developer build, -DDQQ_TUNING, adds the knobs of tuning.h.)
 static int fwd_dispatch(int kind, dqq::FwdArgs& a, void* workspace, size_t workspace_bytes, hipStream_t s)
 {
     if (a.B == 0) return 0;
@@ -216,9 +226,9 @@ static int bwd_dispatch(int kind, dqq::BwdArgs& a, void* workspace, size_t works
     if (scratch > 0) a.scratch = scratch_of(workspace, a.B);
     const bool fused = dqq::bwd_diag_will_fuse(kind, a.N, a.B, a.layout, dqq::knob_fuse_fallback());
     if (!fused && !dense_ok) return DQQ_E_UNSUPPORTED_N; // (box QP, N > 32): nothing could drain the work-list
-    // everything was queued last time (feedback word): one launch of the lane-per-problem kernel over the whole batch, which
-    // also recounts for the next call (bwd_lane_dense.hip REPORT; a diagonal problem gets the same bits there)
-    if (!fused && dqq::bwd_lane_takes_auto_batch(kind, a.N, a.B, s)) {
+    // the caller expects all of it non-diagonal (DQQ_F_EXPECT_DENSE): one launch of the lane-per-problem kernel over the whole
+    // batch, which also recounts for the caller's next hint (bwd_lane_dense.hip REPORT; a diagonal problem gets the same bits there)
+    if (!fused && dqq::bwd_lane_takes_auto_batch(kind, a.N, a.B, a.hints)) {
         dqq::g_bwd_whole_batches.fetch_add(1, std::memory_order_relaxed);
         hipError_t e2 = dqq::launch_bwd_lane_dense(kind, a, 2, s);
         if (e2 != hipSuccess) reset_worklist(workspace, s);
@@ -245,6 +255,7 @@ int dqq_qp_fwd_f64(const double* P, const double* q, double* x, int64_t B, int N
     dqq::FwdArgs a{P,        q,     nullptr, nullptr, nullptr, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0,
                    layout,   iters, nullptr, keep ? pdiag_out : nullptr, keep ? diag_flags_out : nullptr};
     a.ref_order = ref_order_of(p_layout);
+    a.hints = hints_of(p_layout);
     if (!keep && diag_flags_out != nullptr && B > 0) { // nothing will be verified: flag every problem 0
         hipError_t e = hipMemsetAsync(diag_flags_out, 0, (size_t)B, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return (int)e;
@@ -265,6 +276,7 @@ int dqq_qcqp_fwd_f64(const double* P, const double* q, const double* l_n, const 
     dqq::FwdArgs a{P,     q,       l_n, mu, nullptr, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0, layout,
                    iters, nullptr, keep ? pdiag_out : nullptr, keep ? diag_flags_out : nullptr};
     a.ref_order = ref_order_of(p_layout);
+    a.hints = hints_of(p_layout);
     if (!keep && diag_flags_out != nullptr && B > 0) {
         hipError_t e = hipMemsetAsync(diag_flags_out, 0, (size_t)B, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return (int)e;
@@ -287,6 +299,7 @@ static int box_fwd(const double* P, const double* q, const double* l_min, const 
     dqq::FwdArgs a{P,        q,     l_min,   l_max, v, x, (long)B, N, eps, mu_prox, max_iter, adaptive_rho ? 1 : 0,
                    layout,   iters, nullptr, keep ? pdiag_out : nullptr, keep ? diag_flags_out : nullptr};
     a.ref_order = ref_order_of(p_layout);
+    a.hints = hints_of(p_layout);
     if (!keep && diag_flags_out != nullptr && B > 0) {
         hipError_t e = hipMemsetAsync(diag_flags_out, 0, (size_t)B, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return (int)e;
@@ -315,21 +328,24 @@ int dqq_signedboxqp_fwd_f64(const double* P, const double* q, const double* l_mi
 
 int dqq_qp_bwd_f64(const double* P, const double* q, const double* x, const double* grad_x, double* grad_P,
                    double* grad_q, int64_t B, int N, double epsilon, int p_layout, int* ir_steps, const double* pdiag,
-                   const unsigned char* diag_flags, void* workspace, size_t workspace_bytes, void* stream)
+                   const unsigned char* diag_flags, unsigned long long* report, void* workspace, size_t workspace_bytes,
+                   void* stream)
 {
     if (int rc = check_common(B, N, p_layout, false)) return rc;
     if (B > 0 && (P == nullptr || q == nullptr || x == nullptr || grad_x == nullptr)) return DQQ_E_NULLPTR;
     dqq::BwdArgs a{P,     q,          nullptr, nullptr, x,       grad_x, grad_P,  grad_q,   nullptr,  nullptr,
                    pdiag, diag_flags, nullptr, nullptr, (long)B, N,      epsilon, layout_of(p_layout), ir_steps, nullptr};
     a.ref_order = ref_order_of(p_layout);
+    a.hints = hints_of(p_layout);
+    a.report = report;
     return bwd_dispatch(0, a, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 int dqq_qcqp_bwd_f64(const double* P, const double* q, const double* l_n, const double* mu, const double* x,
                      const double* grad_x, double* grad_P, double* grad_q, double* grad_l_n, double* grad_mu,
                      double* gamma, double* dgamma, int64_t B, int N, double epsilon, int p_layout, int* ir_steps,
-                     const double* pdiag, const unsigned char* diag_flags, void* workspace, size_t workspace_bytes,
-                     void* stream)
+                     const double* pdiag, const unsigned char* diag_flags, unsigned long long* report, void* workspace,
+                     size_t workspace_bytes, void* stream)
 {
     if (int rc = check_common(B, N, p_layout, true)) return rc;
     if (B > 0 && (P == nullptr || q == nullptr || l_n == nullptr || mu == nullptr || x == nullptr ||
@@ -338,6 +354,8 @@ int dqq_qcqp_bwd_f64(const double* P, const double* q, const double* l_n, const 
     dqq::BwdArgs a{P,     q,          l_n,   mu,     x,       grad_x, grad_P,  grad_q,   grad_l_n, grad_mu,
                    pdiag, diag_flags, gamma, dgamma, (long)B, N,      epsilon, layout_of(p_layout), ir_steps, nullptr};
     a.ref_order = ref_order_of(p_layout);
+    a.hints = hints_of(p_layout);
+    a.report = report;
     return bwd_dispatch(1, a, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 

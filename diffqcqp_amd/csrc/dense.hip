@@ -8,8 +8,6 @@
 
 namespace dqq {
 
-std::atomic<unsigned long long*> g_feedback_dev{nullptr};                     // dqq_set_feedback (launch.h)
-std::atomic<const volatile unsigned long long*> g_feedback_host{nullptr};
 // route counters (tuning.h)
 std::atomic<int> g_bwd_whole_batches{0};
 std::atomic<int> g_lane_list_drains{0};
@@ -183,14 +181,13 @@ static hipError_t launch_bwd_kind(const BwdArgs& a, bool use_worklist, hipStream
     return launch_bwd_team<KIND, 64>(a, use_worklist, s);
 }
 
-bool bwd_lane_takes_auto_batch(int kind, int N, long B, hipStream_t s)
+bool bwd_lane_takes_auto_batch(int kind, int N, long B, int hints)
 {
-    if (knob_lane_bwd() == 0 || knob_bwd_skip_classify() == 0 || !bwd_lane_dense_supported(kind, N, B)) return false;
-    int streak = 0;
-    // three quarters of the batch or more queued, twice running (launch.h): one launch of the lane kernel over everything costs
-    // what its waves cost (B / 64 of them, whatever their problems are); classifying first costs a launch that queues the
-    // entries through one atomic per workgroup (14 us per 65536) plus the same waves for the queued part
-    return 4 * worklist_predicted(kind, N, B, &streak) >= 3 * B && streak >= 1 && hint_allowed_on(s);
+    // DQQ_F_EXPECT_DENSE (dqq_hint_flags: three quarters of the batch or more queued, twice running): one launch of the lane
+    // kernel over everything costs what its waves cost (B / 64 of them, whatever their problems are); classifying first costs
+    // a launch that queues the entries through one atomic per workgroup (14 us per 65536) plus the same waves for the queued part
+    return knob_lane_bwd() != 0 && knob_bwd_skip_classify() != 0 && bwd_lane_dense_supported(kind, N, B) &&
+           (hints & DQQ_F_EXPECT_DENSE) != 0;
 }
 
 hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s)
@@ -201,9 +198,9 @@ hipError_t launch_bwd_dense(int kind, const BwdArgs& a, bool use_worklist, hipSt
     // list must cost next to nothing.
     if (!use_worklist && knob_lane_bwd() != 0 && bwd_lane_dense_supported(kind, a.N, a.B))
         return launch_bwd_lane_dense(kind, a, 0, s);
-    // ... and the drain launch of a work-list that the last drain of this kind, N and B found that long (launch.h: feedback)
+    // ... and the drain launch of a work-list the caller expects to be that long (DQQ_F_EXPECT_LONG_LIST, launch.h)
     if (use_worklist && knob_lane_bwd() != 0 && bwd_lane_dense_supported(kind, a.N, a.B) &&
-        bwd_lane_dense_supported(kind, a.N, worklist_predicted(kind, a.N, a.B)) && hint_allowed_on(s)) {
+        (a.hints & DQQ_F_EXPECT_LONG_LIST) != 0) {
         g_lane_list_drains.fetch_add(1, std::memory_order_relaxed);
         return launch_bwd_lane_dense(kind, a, 1, s);
     }

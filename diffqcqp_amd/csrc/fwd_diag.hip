@@ -216,7 +216,7 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
     // `mine`: this lane's problem is solved by the diagonal arithmetic below.  A tile with non-diagonal problems hands THOSE
     // to the general solve, problem by problem (round 4, late): which routine solves a problem -- and with it the last
     // bits of its x -- must not depend on its neighbours or on how many lanes a problem has (the layout follows the batch
-    // size and a hint, dqq_set_feedback; routed by whole wave tiles, the diagonal neighbours of a non-diagonal problem took
+    // size and the caller's hint flags, include/diffqcqp_hip.h; routed by whole wave tiles, the diagonal neighbours of a non-diagonal problem took
     // the general solve on two lanes per problem and the diagonal arithmetic on four: 1e-14 apart).
     bool mine = valid;
     [[maybe_unused]] unsigned long long dmask = 0;   // the lanes whose problem is non-diagonal (wave-uniform)
@@ -449,19 +449,18 @@ hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fus
         lpp = fwd_diag_default_lpp(a.N, a.B, kind);
         // a batch declared dense takes the general solve's own mapping (N/2 lanes per problem): one pass per tile
         if (a.layout == DQQ_P_DENSE && a.N <= 8) lpp = a.N / 2;
-        // A DQQ_P_AUTO batch of which the last backward of this kind, N and B found half or more non-diagonal (launch.h: the
-        // feedback word of dqq_set_feedback) runs on ONE lane per problem: the general solve with a problem's whole matrix
+        // A DQQ_P_AUTO batch the caller expects to be half or more non-diagonal (DQQ_F_EXPECT_DENSE: dqq_hint_flags from the
+        // report word of the last backward, launch.h) runs on ONE lane per problem: the general solve with a problem's whole matrix
         // in its lane's registers instead of four lanes exchanging rows (65536 x 8 all non-diagonal, forward: QP 106 -> 65 us,
         // QCQP 116 -> 84; one problem in 10: 95 -> 68, 109 -> 82; tools/probe_sparse_dense_lpp.py).  Below that share two
         // lanes stay: since non-diagonal problems are handed to the general solve one by one (the kernel above), a sparse
         // few cost one pass of it per affected 16-problem block -- one in 1000: 46 / 52 us, what four lanes per problem took.
         // The same bits either way: neither the diagonal arithmetic nor the general solve depends on the lane layout, and
         // which of the two a problem gets depends on the problem alone.
-        if (a.layout == DQQ_P_AUTO && fuse && a.N == 8 && kind < 2 && lpp == 2 && knob_fwd_feedback() != 0) {
-            if (2 * worklist_predicted_in_blocks(kind, a.N, a.B) >= a.B && hint_allowed_on(s)) {
-                lpp = 1;
-                g_fwd_feedback_routes.fetch_add(1, std::memory_order_relaxed);
-            }
+        if (a.layout == DQQ_P_AUTO && fuse && a.N == 8 && kind < 2 && lpp == 2 && knob_fwd_feedback() != 0 &&
+            (a.hints & DQQ_F_EXPECT_DENSE) != 0) {
+            lpp = 1;
+            g_fwd_feedback_routes.fetch_add(1, std::memory_order_relaxed);
         }
     }
     if (needs_fallback) *needs_fallback = (a.layout == DQQ_P_AUTO) && !fuse;

@@ -154,43 +154,30 @@ static DQQ_D void worklist_release(int* ws, long count, int participants)
 }
 #endif
 
-// ---- feedback from the drain launches (round 4).  Which kernel drains a work-list best depends on how long the list is: the
-// team kernel (bwd_small.hip) for a few thousand problems, the lane-per-problem kernel (bwd_lane_dense.hip) when the list
-// fills the chip -- and the host, which picks the kernel, never sees the length (it sits in device memory and nothing on
-// this path may wait for the device).  With a feedback buffer registered (dqq_set_feedback: 128 bytes of host memory the
-// device can write) every drain launch of the N <= 8 QP / QCQP backward stores (B, entries it found) in the word of its
-// (kind, N) -- when it differs from what the same workspace stored there last --; the NEXT backward of that kind, N and B
-// reads the word -- whatever launch wrote it last -- and routes by it.
-// A hint, never a dependency: both kernels drain ANY list, with the same bits (tests/test_gpu_parity.py), so a stale or racy
-// word costs time only; no buffer, a first call, another B: the team kernel, as before.
-constexpr int kFeedbackWords = 16;   // 8-byte words: kind (QP, QCQP) x N (2, 4, 6, 8), the rest spare
-extern std::atomic<unsigned long long*> g_feedback_dev;          // device-side address of the buffer, or nullptr
-extern std::atomic<const volatile unsigned long long*> g_feedback_host;
-inline int worklist_feedback_index(int kind, int N)
-{
-    return ((kind == 0 || kind == 1) && N >= 2 && N <= 8 && N % 2 == 0) ? kind * 4 + N / 2 - 1 : -1;
-}
-inline unsigned long long* worklist_feedback_slot(int kind, int N)
-{
-    unsigned long long* fb = g_feedback_dev.load(std::memory_order_relaxed);
-    const int i = worklist_feedback_index(kind, N);
-    return (fb != nullptr && i >= 0) ? fb + i : nullptr;
-}
+// ---- the report word and the route hints (round 4; stateless since round 5).  Which kernel drains a work-list best depends
+// on how long the list is: the team kernel (bwd_small.hip) for a few thousand problems, the lane-per-problem kernel
+// (bwd_lane_dense.hip) when the list fills the chip -- and the host, which picks the kernel, never sees the length (it sits in
+// device memory and nothing on this path may wait for the device).  So the CALLER may hand a backward call one 8-byte word
+// of host memory the device can write (`report`): the drain launch stores (B, entries it found) there -- when that differs from
+// what the same workspace stored there last --, and the caller turns the word into hint flags for its NEXT calls of that kind,
+// N and B with dqq_hint_flags(), a pure function: DQQ_F_EXPECT_LONG_LIST (drain with the lane kernel), DQQ_F_EXPECT_DENSE
+// (backward: the lane kernel takes the whole batch, no classifying launch; forward of N = 8: one lane per problem).
+// A hint, never a dependency: the routes give the same bits on ANY input (tests/test_gpu_parity.py), so a stale, racy or
+// wrong hint costs time only.  The library keeps no state: where the word lives, for how long, per which device or stream,
+// and whether to hint at all (not under stream capture: a graph is replayed on batches the word knows nothing about) is the
+// caller's business -- diffqcqp_amd/_capi.py keeps one word per (device, kind, N).
 // The word: bits 0..30 entries found, bit 31 "the entries are single problems" (with the forward's hand-off the fast path
 // queues only the non-diagonal problems of a classified tile; otherwise whole tiles of 128 / N), 32..61 B (mod 2^30),
 // 62..63 how many times IN A ROW before this one the same workspace reported "three quarters of the batch or more"
 // (saturating at 3).
 constexpr unsigned long long kFbBMask = 0x3fffffffULL, kFbCountMask = 0x7fffffffULL, kFbPerProblem = 0x80000000ULL;
-// entries the last finished drain launch of (kind, N) found, if it ran on a batch of B problems; -1: not known.
+inline bool hint_applies(int kind, int N) { return (kind == 0 || kind == 1) && N >= 2 && N <= 8 && N % 2 == 0; }
+// entries the drain launch that wrote `w` found, if it ran on a batch of B problems; -1: not known.
 // *streak (optional): consecutive earlier reports of count >= 3/4 B.
-inline long worklist_predicted(int kind, int N, long B, int* streak = nullptr, bool* per_problem = nullptr)
+inline long report_count(unsigned long long w, long B, int* streak = nullptr, bool* per_problem = nullptr)
 {
-    const volatile unsigned long long* fb = g_feedback_host.load(std::memory_order_relaxed);
-    const int i = worklist_feedback_index(kind, N);
     if (streak != nullptr) *streak = 0;
     if (per_problem != nullptr) *per_problem = false;
-    if (fb == nullptr || i < 0) return -1;
-    const unsigned long long w = fb[i];
     if (w == 0 || ((w >> 32) & kFbBMask) != ((unsigned long long)B & kFbBMask)) return -1;
     if (streak != nullptr) *streak = (int)(w >> 62);
     if (per_problem != nullptr) *per_problem = (w & kFbPerProblem) != 0;
@@ -199,21 +186,14 @@ inline long worklist_predicted(int kind, int N, long B, int* streak = nullptr, b
 // problems that sit in a 16-problem block with a non-diagonal one (what the fused forward of N = 8 pays for: one pass of its
 // general solve per such block), from the word: the count itself when whole tiles were queued, an estimate for scattered
 // problems when single problems were
-inline long worklist_predicted_in_blocks(int kind, int N, long B)
+inline long report_count_in_blocks(unsigned long long w, long B)
 {
     bool per_problem = false;
-    const long c = worklist_predicted(kind, N, B, nullptr, &per_problem);
+    const long c = report_count(w, B, nullptr, &per_problem);
     if (c <= 0 || !per_problem) return c;
     double stay = 1.0 - (double)c / (double)B, p = stay;
     for (int k = 0; k < 4; ++k) p *= p;   // (1 - c/B)^16
     return (long)((double)B * (1.0 - p));
-}
-// A hint may change a route only OUTSIDE stream capture: a captured graph is replayed on batches the word knows nothing about,
-// so what goes into it is the argument-determined route (asked only when a hint is about to be followed: one runtime call).
-inline bool hint_allowed_on(hipStream_t s)
-{
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    return hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusNone;
 }
 #if defined(__HIPCC__)
 // Call from ONE lane of the launch.  The store goes to host memory, and a launch that has one in flight ends later
@@ -460,6 +440,7 @@ struct FwdArgs {
     unsigned char* flags_out;  // optional (B): 1 = the problem's tile was verified diagonal
     double* scratch = nullptr; // caller's scratch behind the work-list (dqq_scratch_bytes), global-memory kernels only
     bool ref_order = false;    // DQQ_F_REFERENCE_ORDER: 16 < N <= 64 on the reference-order kernels instead of the matrix cores
+    int hints = 0;             // DQQ_F_EXPECT_* of the call (routes of identical results)
 };
 
 struct BwdArgs {
@@ -485,6 +466,8 @@ struct BwdArgs {
     int* ws;
     double* scratch = nullptr; // see FwdArgs
     bool ref_order = false;    // see FwdArgs
+    int hints = 0;             // see FwdArgs
+    unsigned long long* report = nullptr;   // optional: where the drain launch stores what it found (device-writable host word)
 };
 
 // Which N can solve their non-diagonal tiles inside the fast kernel (no fallback launch: an empty
@@ -543,7 +526,7 @@ hipError_t launch_bwd_any(int kind, const BwdArgs& a, bool use_worklist, hipStre
 bool bwd_lane_dense_supported(int kind, int N, long B);
 hipError_t launch_bwd_lane_dense(int kind, const BwdArgs& a, int mode, hipStream_t s);
 // a DQQ_P_AUTO backward whose every problem was queued last time (feedback word): the lane kernel on the whole batch, reporting
-bool bwd_lane_takes_auto_batch(int kind, int N, long B, hipStream_t s);
+bool bwd_lane_takes_auto_batch(int kind, int N, long B, int hints);
 // statically sized team backward for even N <= 16, QP / QCQP (bwd_small.hip); launch_bwd_dense routes to it
 bool bwd_small_supported(int kind, int N);
 hipError_t launch_bwd_small(int kind, const BwdArgs& a, bool use_worklist, hipStream_t s);

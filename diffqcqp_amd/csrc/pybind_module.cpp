@@ -45,7 +45,14 @@ PYBIND11_MODULE(_dqq, m)
     });
     m.def("dqq_version", []() { return py::bytes(dqq_version()); });
     m.def("dqq_set_option", [](const py::bytes& name, int value) { return dqq_set_option(std::string(name).c_str(), value); });
-    m.def("dqq_set_feedback", [](O host_buffer, std::size_t bytes) { return dqq_set_feedback(ptr<void>(host_buffer), bytes); });
+    m.def("dqq_hint_flags", [](int kind, int pass, int N, std::int64_t B, unsigned long long last_report) {
+        return dqq_hint_flags(kind, pass, N, B, last_report);
+    });
+    m.def("dqq_device_pointer", [](O pinned_host) {
+        void* dev = nullptr;
+        const int rc = dqq_device_pointer(ptr<void>(pinned_host), &dev);
+        return py::make_tuple(rc, reinterpret_cast<std::uintptr_t>(dev));
+    });
     m.def("dqq_get_option", [](const py::bytes& name) {
         int v = 0;
         const int rc = dqq_get_option(std::string(name).c_str(), &v);
@@ -59,11 +66,11 @@ PYBIND11_MODULE(_dqq, m)
                               ptr<unsigned char>(flags_out), ptr<void>(ws), ws_bytes, ptr<void>(stream));
     });
     m.def("dqq_qp_bwd_f64", [](O P, O q, O x, O grad_x, O grad_P, O grad_q, std::int64_t B, int N, double epsilon,
-                               int p_layout, O ir_steps, O pdiag, O flags, O ws, std::size_t ws_bytes, O stream) {
+                               int p_layout, O ir_steps, O pdiag, O flags, O report, O ws, std::size_t ws_bytes, O stream) {
         return dqq_qp_bwd_f64(ptr<const double>(P), ptr<const double>(q), ptr<const double>(x), ptr<const double>(grad_x),
                               ptr<double>(grad_P), ptr<double>(grad_q), B, N, epsilon, p_layout, ptr<int>(ir_steps),
-                              ptr<const double>(pdiag), ptr<const unsigned char>(flags), ptr<void>(ws), ws_bytes,
-                              ptr<void>(stream));
+                              ptr<const double>(pdiag), ptr<const unsigned char>(flags), ptr<unsigned long long>(report),
+                              ptr<void>(ws), ws_bytes, ptr<void>(stream));
     });
     m.def("dqq_qcqp_fwd_f64", [](O P, O q, O l_n, O mu, O x, std::int64_t B, int N, double eps, double mu_prox,
                                  int max_iter, int adaptive_rho, int p_layout, O iters, O pdiag_out, O flags_out, O ws,
@@ -75,12 +82,13 @@ PYBIND11_MODULE(_dqq, m)
     });
     m.def("dqq_qcqp_bwd_f64", [](O P, O q, O l_n, O mu, O x, O grad_x, O grad_P, O grad_q, O grad_l_n, O grad_mu, O gamma,
                                  O dgamma, std::int64_t B, int N, double epsilon, int p_layout, O ir_steps, O pdiag,
-                                 O flags, O ws, std::size_t ws_bytes, O stream) {
+                                 O flags, O report, O ws, std::size_t ws_bytes, O stream) {
         return dqq_qcqp_bwd_f64(ptr<const double>(P), ptr<const double>(q), ptr<const double>(l_n), ptr<const double>(mu),
                                 ptr<const double>(x), ptr<const double>(grad_x), ptr<double>(grad_P), ptr<double>(grad_q),
                                 ptr<double>(grad_l_n), ptr<double>(grad_mu), ptr<double>(gamma), ptr<double>(dgamma), B, N,
                                 epsilon, p_layout, ptr<int>(ir_steps), ptr<const double>(pdiag),
-                                ptr<const unsigned char>(flags), ptr<void>(ws), ws_bytes, ptr<void>(stream));
+                                ptr<const unsigned char>(flags), ptr<unsigned long long>(report), ptr<void>(ws), ws_bytes,
+                                ptr<void>(stream));
     });
     m.def("dqq_boxqp_fwd_f64", [](O P, O q, O l_min, O l_max, O x, std::int64_t B, int N, double eps, double mu_prox,
                                   int max_iter, int adaptive_rho, int p_layout, O iters, O pdiag_out, O flags_out, O ws,

@@ -36,8 +36,8 @@ DQQ_KNOB(dense_teams, 1)            // general backward: 64/T problems per wave 
 DQQ_KNOB(small_fwd, 1)              // general forward N = 10..16: team-per-problem kernel
 DQQ_KNOB(small_bwd, 1)              // general backward even N <= 16: statically sized team kernel
 DQQ_KNOB(lane_bwd, 1)               // general backward N <= 8, B >= 16384: lane-per-problem kernel
-DQQ_KNOB(fwd_feedback, 1)           // with dqq_set_feedback: the forward reads the hint
-DQQ_KNOB(bwd_skip_classify, 1)      // with dqq_set_feedback: an all-non-diagonal batch skips the classifying launch
+DQQ_KNOB(fwd_feedback, 1)           // 0: the forward ignores DQQ_F_EXPECT_DENSE
+DQQ_KNOB(bwd_skip_classify, 1)      // 0: the backward ignores DQQ_F_EXPECT_DENSE (always classifies first)
 #undef DQQ_KNOB
 
 // Route counters (diagnostics, both builds): how often the feedback hint changed a route.  Read with dqq_get_option, reset by

@@ -45,23 +45,18 @@ _pinned = []           # workspaces handed out while a stream capture was going 
 _need_cache = {}       # (kind, pas, N, B, flags) -> bytes: dqq_workspace_bytes + dqq_scratch_bytes are functions of exactly these
 
 
-_feedback_tried = False
-
-
 def feedback_default():
-    """Once per process: register the feedback buffer of dqq_set_feedback (include/diffqcqp_hip.h) unless DQQ_FEEDBACK=0.
-    Through it the backward of a DQQ_P_AUTO batch of N <= 8 learns how many non-diagonal problems the previous one held and
-    picks the faster of two bit-identical kernels for them.  A failure to pin 128 bytes is not an error: the hint is
-    simply absent."""
-    global _feedback_tried
-    if _feedback_tried:
-        return
-    _feedback_tried = True
-    if os.environ.get("DQQ_FEEDBACK", "1") != "0" and torch.cuda.is_available():
-        try:
-            _capi.enable_feedback(True)
-        except (RuntimeError, ValueError, AttributeError):
-            pass
+    """(kept for callers of earlier rounds)  The route hints are on by default and need no registration any more: the report
+    words live in diffqcqp_amd/_capi.py (one per (device, kind, N)), the C library keeps no state."""
+    return None
+
+
+def _hints(kind, pas, N, B, layout, dev):
+    """(flags, report address) for this call: the caller's side of include/diffqcqp_hip.h's hint protocol.  Only DQQ_P_AUTO
+    batches of QP / QCQP, N <= 8; a caller that already passes hint flags in `layout` keeps them."""
+    if (layout & 0xff) != _capi.P_AUTO or N > 8 or kind > 1 or (layout & (_capi.F_EXPECT_DENSE | _capi.F_EXPECT_LONG_LIST)):
+        return 0, None
+    return _capi.hint(kind, pas, N, B, dev.index, _capturing())
 
 
 def _capturing():
@@ -181,10 +176,11 @@ def qp_forward(P, q, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, layout=_cap
     iters = torch.empty(B, dtype=torch.int32, device=q.device) if return_iters else None
     stream = _raw_stream(q.device.index)
     ws = _workspace(q.device, B, stream, 0, 0, N, workspace, layout)
+    hf, _ = _hints(0, 0, N, B, layout, q.device)
     with _device_guard(q.device):
         pd, fl = cache if cache is not None else (None, None)
         rc = _capi.lib().dqq_qp_fwd_f64(_ptr(P), _ptr(q), _ptr(x), B, N, float(eps), float(mu_prox), int(max_iter),
-                                        int(bool(adaptive_rho)), layout, _ptr(iters), _ptr(pd), _ptr(fl), _ptr(ws),
+                                        int(bool(adaptive_rho)), layout | hf, _ptr(iters), _ptr(pd), _ptr(fl), _ptr(ws),
                                         ws.numel() * 4, stream)
     _capi.check(rc, "dqq_qp_fwd_f64")
     return (x, iters) if return_iters else x
@@ -200,10 +196,11 @@ def qcqp_forward(P, q, l_n, mu, eps, max_iter, mu_prox=1e-7, adaptive_rho=True, 
     iters = torch.empty(B, dtype=torch.int32, device=q.device) if return_iters else None
     stream = _raw_stream(q.device.index)
     ws = _workspace(q.device, B, stream, 1, 0, N, workspace, layout)
+    hf, _ = _hints(1, 0, N, B, layout, q.device)
     with _device_guard(q.device):
         pd, fl = cache if cache is not None else (None, None)
         rc = _capi.lib().dqq_qcqp_fwd_f64(_ptr(P), _ptr(q), _ptr(l_n), _ptr(mu), _ptr(x), B, N, float(eps),
-                                          float(mu_prox), int(max_iter), int(bool(adaptive_rho)), layout, _ptr(iters),
+                                          float(mu_prox), int(max_iter), int(bool(adaptive_rho)), layout | hf, _ptr(iters),
                                           _ptr(pd), _ptr(fl), _ptr(ws), ws.numel() * 4, stream)
     _capi.check(rc, "dqq_qcqp_fwd_f64")
     return (x, iters) if return_iters else x
@@ -250,12 +247,11 @@ def qp_backward(P, q, x, grad_x, need_P=True, need_q=True, layout=_capi.P_AUTO, 
     steps = torch.empty(B, dtype=torch.int32, device=dev) if return_steps else None
     stream = _raw_stream(dev.index)
     ws = _workspace(dev, B, stream, 0, 1, N, workspace, layout)
-    if not _feedback_tried and (layout & 0xff) == _capi.P_AUTO and N <= 8:
-        feedback_default()
+    hf, report = _hints(0, 1, N, B, layout, dev)
     with _device_guard(dev):
         pd, fl = cache if cache is not None else (None, None)
         rc = _capi.lib().dqq_qp_bwd_f64(_ptr(P), _ptr(q), _ptr(x), _ptr(grad_x), _ptr(gP), _ptr(gq), B, N,
-                                        float(epsilon), layout, _ptr(steps), _ptr(pd), _ptr(fl), _ptr(ws),
+                                        float(epsilon), layout | hf, _ptr(steps), _ptr(pd), _ptr(fl), report, _ptr(ws),
                                         ws.numel() * 4, stream)
     _capi.check(rc, "dqq_qp_bwd_f64")
     return (gP, gq, steps) if return_steps else (gP, gq)
@@ -282,14 +278,14 @@ def qcqp_backward(P, q, l_n, mu, x, grad_x, need=(True, True, True, True), layou
     steps = torch.empty(B, dtype=torch.int32, device=dev) if return_steps else None
     stream = _raw_stream(dev.index)
     ws = _workspace(dev, B, stream, 1, 1, N, workspace, layout)
-    if not _feedback_tried and (layout & 0xff) == _capi.P_AUTO and N <= 8:
-        feedback_default()
+    hf, report = _hints(1, 1, N, B, layout, dev)
     with _device_guard(dev):
         gam, dgam = duals if duals is not None else (None, None)
         pd, fl = cache if cache is not None else (None, None)
         rc = _capi.lib().dqq_qcqp_bwd_f64(_ptr(P), _ptr(q), _ptr(l_n), _ptr(mu), _ptr(x), _ptr(grad_x), _ptr(gP),
                                           _ptr(gq), _ptr(gl), _ptr(gm), _ptr(gam), _ptr(dgam), B, N, float(epsilon),
-                                          layout, _ptr(steps), _ptr(pd), _ptr(fl), _ptr(ws), ws.numel() * 4, stream)
+                                          layout | hf, _ptr(steps), _ptr(pd), _ptr(fl), report, _ptr(ws), ws.numel() * 4,
+                                          stream)
     _capi.check(rc, "dqq_qcqp_bwd_f64")
     return (gP, gq, gl, gm, steps) if return_steps else (gP, gq, gl, gm)
 

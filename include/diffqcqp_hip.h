@@ -19,14 +19,14 @@
  *     the default stream) and the call returns without synchronising;
  *   - return value: 0 on success, <0 for an invalid argument (DQQ_E_*), >0 a
  *     hipError_t from the launch (the launch's own status: the calling thread's
- *     sticky HIP error is neither consumed nor cleared).  Nothing throws.  A call's
- *     results, bit for bit, are a function of its arguments alone (no history,
- *     thread-safe, any stream) -- and so are the kernels it launches.  The one piece
- *     of process-wide state is OPTIONAL and changes time only: with a feedback buffer
- *     registered (dqq_set_feedback) an N <= 8 DQQ_P_AUTO call is routed between
- *     kernels of identical results by what the previous backward of its kind found.
- *     There are no tuning knobs in this library (a developer build, -DDQQ_TUNING,
- *     has them: csrc/tuning.h);
+ *     sticky HIP error is neither consumed nor cleared).  Nothing throws.  The library
+ *     keeps NO state: a call's results, bit for bit, and the kernels it launches are
+ *     a function of its arguments alone (no history, thread-safe, any stream).  What
+ *     adapts to the data -- a steady stream of mostly non-diagonal N <= 8 batches
+ *     through DQQ_P_AUTO is faster on other kernels of identical results -- is in the
+ *     CALLER's hands: an optional report word the backward fills and hint flags the
+ *     caller derives from it (dqq_hint_flags, below).  There are no tuning knobs
+ *     (a developer build, -DDQQ_TUNING, has them: csrc/tuning.h);
  *   - like the reference (Solver.cpp:76, :100), numerical failure is not
  *     signalled: a non-PD P or L=0 yields NaNs in the output;
  *   - `warm_start` does not appear: the reference accepts it and overwrites it
@@ -60,6 +60,18 @@ extern "C" {
  * 8e-6 (grad_l_n, grad_mu) relative of the reference-order evaluation -- the evaluation-order noise of the reference's own
  * formulas.  10-30x slower; for parity studies.  No effect for N <= 16 (always reference order) or on diagonal tiles. */
 #define DQQ_F_REFERENCE_ORDER 0x100
+/* Per-call HINT flags, ORed into p_layout (DQQ_P_AUTO, QP / QCQP, N <= 8; ignored elsewhere).  They select between kernels of
+ * IDENTICAL results -- bit for bit, on any input -- so a wrong hint costs time and nothing else.  Obtain them from
+ * dqq_hint_flags(); never pass them on a stream that is being captured into a graph that will be replayed on other data.
+ *   DQQ_F_EXPECT_DENSE      most of the batch is non-diagonal.  Forward (N = 8): one lane per problem, the general solve with a
+ *                           problem's whole matrix in its lane's registers, the tile of P staged through LDS and read once.
+ *                           Backward (B >= 16384; N = 8: 24576): no classifying launch, the lane-per-problem kernel takes the
+ *                           whole batch (and recounts for `report`).
+ *   DQQ_F_EXPECT_LONG_LIST  backward: the work-list of non-diagonal problems will be long enough to fill the chip: the drain
+ *                           launch is the lane-per-problem kernel (2x faster there; its 512-register waves need an empty SIMD
+ *                           each, so it is never launched "just in case": behind a diagonal batch it would stall). */
+#define DQQ_F_EXPECT_DENSE 0x200
+#define DQQ_F_EXPECT_LONG_LIST 0x400
 
 #define DQQ_E_NULLPTR (-1)     /* a required pointer is NULL */
 #define DQQ_E_BAD_SIZE (-2)    /* B < 0, N < 1, odd N for QCQP */
@@ -127,11 +139,14 @@ int dqq_qp_fwd_f64(const double* P, const double* q, double* x, int64_t B, int N
  * (ctx.needs_input_grad).  epsilon is the dual-recovery threshold of
  * solveDerivativesQP (pybindings.cpp:24, default 1e-10; qcqp.py never overrides
  * it).  ir_steps (B ints) may be NULL.  pdiag / diag_flags: optional, what the forward of the same
- * (unchanged) P stored; P itself must still be passed (non-flagged problems read it). */
+ * (unchanged) P stored; P itself must still be passed (non-flagged problems read it).
+ * report: optional (NULL: none) -- the DEVICE address of one 8-byte word of pinned host memory the caller owns
+ * (dqq_device_pointer); the launch that solves the batch's non-diagonal problems stores what it found there, for
+ * dqq_hint_flags().  QP / QCQP, DQQ_P_AUTO, N <= 8; ignored otherwise. */
 int dqq_qp_bwd_f64(const double* P, const double* q, const double* x, const double* grad_x, double* grad_P,
                    double* grad_q, int64_t B, int N, double epsilon, int p_layout, int* ir_steps,
-                   const double* pdiag, const unsigned char* diag_flags, void* workspace, size_t workspace_bytes,
-                   void* stream);
+                   const double* pdiag, const unsigned char* diag_flags, unsigned long long* report, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 /* Replaces the loop qcqp.py:149-151 (QCQPFn2.forward -> diffqcqp.solveQCQP,
  * pybindings.cpp:54-60 -> Solver::solveQCQP, Solver.cpp:521-582).  l_n and mu
@@ -148,12 +163,12 @@ int dqq_qcqp_fwd_f64(const double* P, const double* q, const double* l_n, const 
  * NULL) expose the contact duals and their derivative terms, from which the
  * reference's per-problem return value (E1, E2, blgamma) can be rebuilt:
  * E1 = diag(2 gamma l_n^2 mu), E2 = diag(2 gamma l_n mu^2), blgamma = [dgamma; -grad_q].
- * epsilon: dual-recovery threshold (pybindings.cpp:62, default 1e-10). */
+ * epsilon: dual-recovery threshold (pybindings.cpp:62, default 1e-10).  report: as dqq_qp_bwd_f64. */
 int dqq_qcqp_bwd_f64(const double* P, const double* q, const double* l_n, const double* mu, const double* x,
                      const double* grad_x, double* grad_P, double* grad_q, double* grad_l_n, double* grad_mu,
                      double* gamma, double* dgamma, int64_t B, int N, double epsilon, int p_layout,
-                     int* ir_steps, const double* pdiag, const unsigned char* diag_flags, void* workspace,
-                     size_t workspace_bytes, void* stream);
+                     int* ir_steps, const double* pdiag, const unsigned char* diag_flags, unsigned long long* report,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- the box-constrained members of the same solver family ------------------
  *
@@ -189,37 +204,37 @@ int dqq_boxqp_bwd_f64(const double* P, const double* q, const double* l_min, con
                       const double* pdiag, const unsigned char* diag_flags, void* workspace, size_t workspace_bytes,
                       void* stream);
 
-/* Route counters (diagnostics): how many launches the feedback hint (dqq_set_feedback) has sent down its alternative
- * routes since the counter was last reset.  Names: "lane_list_drains" (drain launches on the lane-per-problem backward),
- * "bwd_whole_batches" (DQQ_P_AUTO backwards solved whole by that kernel), "fwd_feedback_routes" (N = 8 forwards on one
- * lane per problem).  dqq_set_option(name, v) stores v (0 resets); any other name -> DQQ_E_BAD_OPTION.  These are the only
- * names this library knows and none of them changes what a call does.  (A developer build, -DDQQ_TUNING, also accepts the
- * kernel-selection knobs of csrc/tuning.h; they change time, never results.) */
+/* ---- adapting to the data without state in the library -------------------------------------------------------------
+ *
+ * Behind the diagonal fast path's backward, a second launch solves the problems whose P is not diagonal.  Two kernels can do
+ * it -- a team of lanes per problem (best for up to a few thousand such problems) and a lane per problem (2x faster once they
+ * fill the chip: 65536 dense 8x8 QCQP problems 110 -> ~55 us) -- and how many there are is known on the device only.  A
+ * caller that presents the same kind of batch step after step (a training loop) can close that loop itself:
+ *   1. keep one 8-byte word of pinned host memory per (kind, N) -- zero-initialised; per device, per stream or per module as
+ *      it sees fit -- and pass its device address (dqq_device_pointer) as `report` to the backward calls;
+ *   2. before a call of (kind, pass, N, B), read the word (a plain host load: nothing waits for the device) and OR
+ *      dqq_hint_flags(kind, pass, N, B, word) into p_layout.
+ * dqq_hint_flags is a pure function; the flags only ever select between kernels of identical results.  First calls, other
+ * batch sizes, stream capture (pass no hints there): the argument-determined routes.  Measured, dense 8x8 QCQP, B = 65536,
+ * forward + backward: DQQ_P_DENSE 0.131 ms; DQQ_P_AUTO with hints 0.134 ms (from the third step on), without 0.231 ms.
+ * diffqcqp_amd/_capi.py does exactly this for the Python layer (one word per (device, kind, N); DQQ_FEEDBACK=0 turns it off).
+ *
+ * Word format (for the curious; callers only pass it through): bits 0..30 problems found, bit 31 "counted singly",
+ * 32..61 B mod 2^30, 62..63 consecutive earlier reports of >= 3/4 B. */
+int dqq_hint_flags(int kind, int pass, int N, int64_t B, unsigned long long last_report);
+
+/* The device-side address of 8-byte-aligned pinned (hipHostMalloc / hipHostRegister / torch pin_memory()) host memory:
+ * 0, DQQ_E_NULLPTR, DQQ_E_BAD_SIZE (misaligned) or the hipError_t of hipHostGetDevicePointer (not pinned memory). */
+int dqq_device_pointer(void* pinned_host, void** device);
+
+/* Route counters (diagnostics): how many launches the hint flags have sent down their alternative routes since the counter
+ * was last reset.  Names: "lane_list_drains" (drain launches on the lane-per-problem backward), "bwd_whole_batches"
+ * (DQQ_P_AUTO backwards solved whole by that kernel), "fwd_feedback_routes" (N = 8 forwards on one lane per problem).
+ * dqq_set_option(name, v) stores v (0 resets); any other name -> DQQ_E_BAD_OPTION.  These are the only names this library
+ * knows and none of them changes what a call does.  (A developer build, -DDQQ_TUNING, also accepts the kernel-selection knobs
+ * of csrc/tuning.h; they change time, never results.) */
 int dqq_set_option(const char* name, int value);
 int dqq_get_option(const char* name, int* value);
-
-/* Optional feedback buffer for the backward of DQQ_P_AUTO batches, N <= 8, QP / QCQP.
- *
- * Behind the diagonal fast path's backward, a second launch solves the problems whose P is not diagonal.  Two kernels can
- * do it -- a team of lanes per problem (best for up to a few thousand such problems) and a lane per problem (2x faster once
- * they fill the chip: 65536 dense 8x8 QCQP problems 100 -> ~60 us) -- and how many there are is known on the device only.
- * With a buffer registered, that launch stores the number it found in the buffer, and the NEXT backward of the same kind, N
- * and B picks its kernel by it (a training loop presents the same kind of batch step after step); the next FORWARD of that
- * kind, N = 8 and B gives every problem one lane instead of two when half of the batch or more was non-diagonal (the
- * in-kernel general solve with a problem's whole matrix in one lane's registers: all dense 126 -> 84 us per 65536 QCQPs);
- * and a backward whose last two
- * predecessors found at least three quarters of the batch non-diagonal skips the classifying launch: one launch of the lane-per-problem kernel
- * over the batch, which recounts for the call after it.  The two kernels give
- * the same results bit for bit on any list, so the word is a hint: stale, racy or absent, it changes the time of a call and
- * nothing else.  Nothing ever waits for the device.  A call on a stream that is being CAPTURED ignores the word: what goes
- * into a graph is the route its arguments determine.
- *
- * `host_buffer`: DQQ_FEEDBACK_BYTES of zero-initialised host memory that the device can write (hipHostMalloc /
- * hipHostRegister, or torch's pin_memory()), 8-byte aligned, valid until replaced or the process ends; NULL unregisters.
- * Returns 0, DQQ_E_BAD_SIZE (too small / misaligned), or the hipError_t of hipHostGetDevicePointer (not pinned memory).
- * The library never allocates: without a buffer the team kernel is always the one launched, as before round 4. */
-#define DQQ_FEEDBACK_BYTES 128
-int dqq_set_feedback(void* host_buffer, size_t bytes);
 
 /* "diffqcqp_hip <version> gfx950" */
 const char* dqq_version(void);

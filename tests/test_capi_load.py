@@ -69,9 +69,9 @@ def test_argument_validation_without_gpu(lib):
     g = lib.dqq_qcqp_fwd_f64
     assert g(one, one, one, one, one, 4, 7, 1e-7, 1e-7, 10, 1, 0, None, None, None, None, 0, None) == -2  # odd N
     assert lib.dqq_qcqp_bwd_f64(one, one, one, one, one, one, None, None, None, None, None, None, 4, 66, 1e-10, 2,
-                                None, None, None, None, 0, None) == -3
+                                None, None, None, None, None, 0, None) == -3
     assert lib.dqq_qcqp_bwd_f64(one, one, one, one, one, one, None, None, None, None, None, None, 4, 67, 1e-10, 1,
-                                None, None, None, None, 0, None) == -2  # odd N
+                                None, None, None, None, None, 0, None) == -2  # odd N
     # DQQ_P_DENSE beyond the register / LDS kernels: the scratch is the caller's, nothing is allocated inside
     assert f(one, one, one, 4, 80, 1e-7, 1e-7, 10, 1, 1, None, None, None, None, 0, None) == -5
     assert lib.dqq_set_option(b"no_such_knob", 1) == -6
@@ -91,7 +91,7 @@ def test_argument_validation_without_gpu(lib):
                      b"lane_defer", b"fwd_respread", b"fwd_compact", b"dense_teams", b"small_bwd", b"lane_bwd"):
             assert lib.dqq_set_option(name, 1) == -6, name
     # unknown flag bits in p_layout are refused; the reference-order flag is accepted with every layout
-    assert f(one, one, one, 4, 8, 1e-7, 1e-7, 10, 1, 0x200, None, None, None, None, 0, None) == -4
+    assert f(one, one, one, 4, 8, 1e-7, 1e-7, 10, 1, 0x800, None, None, None, None, 0, None) == -4
     assert f(one, one, one, 4, 8, 1e-7, 1e-7, 10, 1, 0x103, None, None, None, None, 0, None) == -4
     # the work-list hygiene entry points validate their arguments without touching the device
     assert lib.dqq_workspace_reset(None, 0, None) == -1 and lib.dqq_workspace_reset(one, 16, None) == -5
@@ -99,9 +99,27 @@ def test_argument_validation_without_gpu(lib):
         assert lib.dqq_workspace_status(None, 0, None, None) == -1 and lib.dqq_workspace_status(one, 16, None, ctypes.byref(v)) == -5
     else:
         assert lib.dqq_workspace_status(None, 0, None)[0] == -1 and lib.dqq_workspace_status(one, 16, None)[0] == -5
-    # the feedback buffer: NULL unregisters; a buffer too small or misaligned is refused before anything touches it
-    assert lib.dqq_set_feedback(None, 0) == 0
-    assert lib.dqq_set_feedback(4096, 64) == -2 and lib.dqq_set_feedback(4100, 128) == -2
+    # the hint protocol keeps its state with the caller: dqq_hint_flags is a pure function of the caller's report word
+    EXPECT_DENSE, EXPECT_LONG = 0x200, 0x400
+    B = 65536
+    word = lambda count, streak=0, single=0: (streak << 62) | (B << 32) | (single << 31) | count
+    assert lib.dqq_hint_flags(1, 1, 8, B, 0) == 0                                    # nothing known
+    assert lib.dqq_hint_flags(1, 1, 8, B, word(100)) == 0                            # a short list: the team kernel
+    assert lib.dqq_hint_flags(1, 1, 8, B, word(30000)) == EXPECT_LONG                # a list that fills the chip
+    assert lib.dqq_hint_flags(1, 1, 8, B, word(B)) == EXPECT_LONG                    # all of it, once: not yet "expect dense"
+    assert lib.dqq_hint_flags(1, 1, 8, B, word(B, streak=1)) == EXPECT_LONG | EXPECT_DENSE
+    assert lib.dqq_hint_flags(1, 1, 8, B // 2, word(B, streak=1)) == 0               # a word about another batch size
+    assert lib.dqq_hint_flags(1, 0, 8, B, word(B // 2)) == EXPECT_DENSE and lib.dqq_hint_flags(1, 0, 8, B, word(B // 2 - 1)) == 0
+    assert lib.dqq_hint_flags(0, 0, 4, B, word(B)) == 0                              # the forward's other layout exists at N = 8 only
+    assert lib.dqq_hint_flags(2, 1, 8, B, word(B, streak=3)) == 0 and lib.dqq_hint_flags(0, 1, 16, B, word(B, streak=3)) == 0
+    assert lib.dqq_hint_flags(1, 1, 8, 1000, (1 << 62) | (1000 << 32) | 1000) == 0   # batches the lane kernel does not take
+    # hint flags are accepted in p_layout (and checked like any other argument); dqq_device_pointer refuses garbage
+    assert f(one, one, one, 4, 8, 1e-7, 1e-7, 10, 1, EXPECT_DENSE | EXPECT_LONG, None, None, None, None, 0, None) == -5
+    if isinstance(lib, ctypes.CDLL):
+        out = ctypes.c_void_p(0)
+        assert lib.dqq_device_pointer(None, ctypes.byref(out)) == -1 and lib.dqq_device_pointer(4100, ctypes.byref(out)) == -2
+    else:
+        assert lib.dqq_device_pointer(None)[0] == -1 and lib.dqq_device_pointer(4100)[0] == -2
 
 
 def test_python_layer_fails_loudly_without_gpu():

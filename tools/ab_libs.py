@@ -13,9 +13,11 @@ def bind(path):
     L = ctypes.CDLL(path)
     L.dqq_workspace_bytes.argtypes, L.dqq_workspace_bytes.restype = [i64], sz
     L.dqq_qp_fwd_f64.argtypes = [vp, vp, vp, i64, i32, dbl, dbl, i32, i32, i32, vp, vp, vp, vp, sz, vp]
-    L.dqq_qp_bwd_f64.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, dbl, i32, vp, vp, vp, vp, sz, vp]
+    L.has_report = hasattr(L, "dqq_hint_flags")   # builds since the stateless hint protocol: one more pointer (`report`) in the backward
+    rep = [vp] if L.has_report else []
+    L.dqq_qp_bwd_f64.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, dbl, i32, vp, vp, vp] + rep + [vp, sz, vp]
     L.dqq_qcqp_fwd_f64.argtypes = [vp, vp, vp, vp, vp, i64, i32, dbl, dbl, i32, i32, i32, vp, vp, vp, vp, sz, vp]
-    L.dqq_qcqp_bwd_f64.argtypes = [vp] * 12 + [i64, i32, dbl, i32, vp, vp, vp, vp, sz, vp]
+    L.dqq_qcqp_bwd_f64.argtypes = [vp] * 12 + [i64, i32, dbl, i32, vp, vp, vp] + rep + [vp, sz, vp]
     return L
 
 
@@ -37,13 +39,14 @@ def main():
     res = {}
     outs = []
     for li, L in enumerate(libs):
+        rep = (None,) if L.has_report else ()
         wsb = L.dqq_workspace_bytes(B)
         ws = torch.zeros((wsb + 3) // 4, dtype=torch.int32, device=dev)
         calls = {
             "qp_fwd": lambda L=L, ws=ws, wsb=wsb: L.dqq_qp_fwd_f64(p(P), p(q), p(x), B, N, 1e-7, 1e-7, 1000, 1, 0, None, p(pd), p(fl), p(ws), wsb, s),
-            "qp_bwd": lambda L=L, ws=ws, wsb=wsb: L.dqq_qp_bwd_f64(p(P), p(q), p(x), p(gx), p(gP), p(gq), B, N, 1e-10, 0, None, p(pd), p(fl), p(ws), wsb, s),
+            "qp_bwd": lambda L=L, ws=ws, wsb=wsb, rep=rep: L.dqq_qp_bwd_f64(p(P), p(q), p(x), p(gx), p(gP), p(gq), B, N, 1e-10, 0, None, p(pd), p(fl), *rep, p(ws), wsb, s),
             "qcqp_fwd": lambda L=L, ws=ws, wsb=wsb: L.dqq_qcqp_fwd_f64(p(P), p(q), p(ln), p(mu), p(x), B, N, 1e-7, 1e-7, 1000, 1, 0, None, p(pd), p(fl), p(ws), wsb, s),
-            "qcqp_bwd": lambda L=L, ws=ws, wsb=wsb: L.dqq_qcqp_bwd_f64(p(P), p(q), p(ln), p(mu), p(x), p(gx), p(gP), p(gq), p(gl), p(gm), None, None, B, N, 1e-10, 0, None, p(pd), p(fl), p(ws), wsb, s),
+            "qcqp_bwd": lambda L=L, ws=ws, wsb=wsb, rep=rep: L.dqq_qcqp_bwd_f64(p(P), p(q), p(ln), p(mu), p(x), p(gx), p(gP), p(gq), p(gl), p(gm), None, None, B, N, 1e-10, 0, None, p(pd), p(fl), *rep, p(ws), wsb, s),
         }
         res[li] = {k: [] for k in calls}
         res[li]["_calls"] = calls
