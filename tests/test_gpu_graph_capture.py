@@ -82,7 +82,7 @@ def test_forward_backward_captured_into_a_graph_and_replayed(oracle, ops, kind, 
 
 @pytest.mark.parametrize("kind", ["qp", "qcqp"])
 def test_a_captured_call_ignores_the_feedback_word(ops, kind):
-    """dqq_set_feedback: the word may move a call to another lane layout or kernel -- never inside a stream capture, where the
+    """the caller-side hints (dqq_hint_flags, _capi.py): the word may move a call to another lane layout or kernel -- never inside a stream capture, where the
     route must be the one the arguments determine (a graph is replayed on batches the word knows nothing about)."""
     from diffqcqp_amd import _capi
     N, B = 8, 57344 + 2048

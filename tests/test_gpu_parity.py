@@ -416,7 +416,7 @@ def test_lane_per_problem_backward_is_the_team_kernel_bit_for_bit(oracle, ops, k
 @pytest.mark.parametrize("N,B,ndiag", [(8, 24576 + 10240 + 13, 10240), (4, 16384 + 6144 + 500, 6144)])
 def test_feedback_routes_a_long_work_list_to_the_lane_kernel_same_bits(ops, kind, N, B, ndiag):
     """DQQ_P_AUTO, a batch that is (almost) all dense: the drain launch behind the diagonal backward reports the length of its
-    work-list to the feedback word (dqq_set_feedback); the next backward of the same kind, N and B drains with the
+    work-list to the report word (include/diffqcqp_hip.h: dqq_hint_flags); the next backward of the same kind, N and B drains with the
     lane-per-problem kernel (bwd_lane_dense.hip, LIST) instead of the team kernel.  Same bits, whichever drains; the
     work-list header is left clean (a third call); a stale word (the list has become short, or empty) costs time only."""
     from diffqcqp_amd import _capi
@@ -911,7 +911,7 @@ WS_HEADER_INTS = 32 + 2 * 32 * 32
 
 def header_is_clean(ws):
     """Count, exit tickets, pick-up index, segment counters: zero after every launch.  Ints 4..7 (kWsFbShadow) are not part
-    of the list: the last word this workspace's drain launches sent to the feedback buffer (dqq_set_feedback), and where."""
+    of the list: the last word this workspace's drain launches sent to the report word (dqq_hint_flags), and where."""
     h = ws[:WS_HEADER_INTS].clone()
     h[4:8] = 0
     return int(h.abs().sum()) == 0

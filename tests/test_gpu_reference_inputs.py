@@ -180,7 +180,7 @@ def test_rank_deficient_batches(oracle, ops, family, N, kind):
 @pytest.mark.parametrize("kind", ["qp", "qcqp"])
 @pytest.mark.parametrize("family", ["lowrank", "duprows", "psd_eps"])
 def test_rank_deficient_batches_on_one_two_and_four_lanes_per_problem(ops, family, kind):
-    """The forward picks its lane layout at N = 8 by batch size and by a hint (dqq_set_feedback); x and the iteration counts
+    """The forward picks its lane layout at N = 8 by batch size and by a hint (DQQ_F_EXPECT_DENSE); x and the iteration counts
     must be the same bits on every layout -- also on singular P, where a third of the QPs run into max_iter and some
     factorisations fail (NaN outputs: compared as bit patterns).  A third of the batch is made diagonal: both branches of
     the fused kernel run in every layout."""

@@ -1,7 +1,7 @@
 """Randomised parity of the backward routes against the oracle (x from the oracle on both sides): random kind, N, batch
 size, structure, layout, fused / work-list fallback, with and without the forward's diagonal hand-off.
 usage: python tools/fuzz_bwd.py [trials] [seed] [big | lane]   (lane: only the batches the lane-per-problem backward takes --
-N <= 8, QP / QCQP, B >= 16384 -- declared dense or through DQQ_P_AUTO with the feedback word of dqq_set_feedback poked)"""
+N <= 8, QP / QCQP, B >= 16384 -- declared dense or through DQQ_P_AUTO with the report word of _capi.py poked)"""
 import os, sys
 import numpy as np
 import torch
@@ -54,7 +54,7 @@ for t in range(trials):
     P, q, gx = d["P"].numpy(), d["q"].numpy(), d["grad_x"].numpy()
     ref_flag = apply_opts(opts)
     if B >= 16384 and layout == 0 and kind != "box":
-        # the feedback word of dqq_set_feedback, set to anything: a "long list" sends the lane-per-problem kernel (LIST) after
+        # the report word (_capi.py), set to anything: a "long list" sends the lane-per-problem kernel (LIST) after
         # whatever list this batch has -- full, every other tile, empty; a hint must never change a result
         _capi.enable_feedback(True)
         word = (int(rng.integers(4)) << 62) | (B << 32) | int(rng.choice([0, 30000, B, B]))   # (streak, B, entries): launch.h
