@@ -5,4 +5,4 @@ QCQPFn2); `diffqcqp_amd.ops` exposes the same launches without autograd;
 `diffqcqp_amd.parallel` shards a batch over the GPUs of a node.  The compute is
 in libdiffqcqp_hip.so (csrc/, C ABI in include/diffqcqp_hip.h).
 """
-__version__ = "0.1.0"
+__version__ = "0.2.0"

@@ -118,7 +118,7 @@ int dqq_workspace_status(const void* workspace, size_t workspace_bytes, void* st
 
 int dqq_max_n(int kind, int p_layout) { return dqq::public_max_n(kind, ref_order_of(p_layout)); }
 
-const char* dqq_version(void) { return "diffqcqp_hip 0.1.0 gfx950"; }
+const char* dqq_version(void) { return "diffqcqp_hip 0.2.0 gfx950"; }
 
 int dqq_set_option(const char* name, int value)
 {
