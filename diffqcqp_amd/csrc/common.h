@@ -80,12 +80,22 @@ DQQ_HD double fast_rsqrt(double x)
 DQQ_HD double fast_rcp(double x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+#if defined(DQQ_RCP_TWO_NEWTON)   // (the form of rounds 1-4: two Newton steps, four dependent instructions behind the seed)
     double y = __builtin_amdgcn_rcp(x);
     double e = fma(-x, y, 1.0);
     y = fma(y, e, y);
     e = fma(-x, y, 1.0);
     y = fma(y, e, y);
     return y;
+#else
+    // one second-order step, like fast_rsqrt above: with e = 1 - x y0, 1/x = y0 (1 + e + e^2 + O(e^3)); e ~ 2^-26 from the
+    // hardware seed, so the truncation error is ~2^-78 and the result is rounding-limited -- three dependent instructions
+    // behind the seed instead of four
+    const double y0 = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, y0, 1.0);
+    const double t = fma(e, e, e);
+    return fma(y0, t, y0);
+#endif
 #else
     return 1.0 / x;
 #endif
