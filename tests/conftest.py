@@ -16,8 +16,8 @@ def pytest_configure(config):
 # ---- kernel-selection knobs in the tests -----------------------------------------------------------------------------------
 # The shipped library has none (csrc/tuning.h: compile-time constants; dqq_set_option knows the three route counters only).
 # Tests that drive the alternative kernels -- other lane layouts, the queued instead of the fused fallback, ... -- need the
-# DEVELOPER build (DQQ_EXTRA_FLAGS=-DDQQ_TUNING python -m diffqcqp_amd.build) and SKIP on the shipped one; profiles/ holds
-# the log of the suite run on that build.  The two former knobs that change NUMERICS ("dense_wave64", "wave_qcqp_bwd": the
+# DEVELOPER build (python -m diffqcqp_amd.build --tuning) and SKIP on the shipped one -- and run a second time, bound to that
+# build, from tests/test_gpu_developer_build.py: one `pytest -m gpu` covers both.  The two former knobs that change NUMERICS ("dense_wave64", "wave_qcqp_bwd": the
 # reference-order kernels for 16 < N <= 64) are a per-call flag of the C ABI now (DQQ_F_REFERENCE_ORDER): `knob` keeps a
 # test-side switch for them and `OpsWithFlags` (the `ops` fixture of test_gpu_parity.py) ORs the flag into every call's layout.
 KNOB_DEFAULTS = {"fwd_lpp": 0, "wpb": 0, "fuse_fallback": -1, "fwd_respread": 16, "fwd_respread2": 8,
