@@ -56,7 +56,10 @@ def _hints(kind, pas, N, B, layout, dev):
     batches of QP / QCQP, N <= 8; a caller that already passes hint flags in `layout` keeps them."""
     if (layout & 0xff) != _capi.P_AUTO or N > 8 or kind > 1 or (layout & (_capi.F_EXPECT_DENSE | _capi.F_EXPECT_LONG_LIST)):
         return 0, None
-    return _capi.hint(kind, pas, N, B, dev.index, _capturing())
+    flags, report = _capi.hint(kind, pas, N, B, dev.index)
+    if flags and _capturing():   # (asked only when a hint is about to be followed) a graph is replayed on batches the word
+        flags = 0                # knows nothing about: what goes into it is the argument-determined route
+    return flags, report
 
 
 def _capturing():

@@ -91,6 +91,22 @@ def _worker_async_out(rank, world, port, B, q_out):
         work.wait()
         ok &= bool(torch.equal(out, full + rep))
         ok &= bool(work.wait())          # idempotent
+    # a caller that POLLS instead of waiting: once is_completed() says so, `out` holds the gathered batch -- on the
+    # ragged path too, where the trim of the padded blocks has to have run by then
+    import time
+    out.fill_(-1.0)
+    res, work = parallel.gather_batch((full[lo:hi] + 7).clone(), B, async_op=True, out=out, scratch=scratch)
+    t0 = time.time()
+    while not work.is_completed() and time.time() - t0 < 60:
+        time.sleep(0.001)
+    ok &= bool(work.is_completed()) and bool(torch.equal(out, full + 7))
+    # a scratch of another dtype is refused up front, not inside the collective
+    if rows:
+        try:
+            parallel.gather_batch(full[lo:hi].clone(), B, out=out, scratch=scratch.float())
+            ok = False
+        except AssertionError:
+            pass
     res = parallel.gather_batch(full[lo:hi].clone(), B, out=out, scratch=scratch)   # synchronous, same buffers
     ok &= res is out and bool(torch.equal(out, full))
     q_out.put((rank, ok))
