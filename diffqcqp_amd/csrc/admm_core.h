@@ -89,7 +89,6 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
     // reductions are symmetric) and keeps its state in place under the execution mask -- as a wave-uniform loop
     // around a `done` flag the same code carried a dozen register copies per iteration.
     int rho_up = 0, cpt = 0, iters = 0;
-    DQQ_TL(3);
     if (valid) {
         for (int it = 0; it < max_iter; ++it) {
 #define DQQ_ADMM_ON_STOP break
@@ -97,7 +96,6 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
 #undef DQQ_ADMM_ON_STOP
         }
     }
-    DQQ_TL(4);
     bad = G::max(bad ? 1.0 : 0.0) > 0.0;
 #pragma unroll
     for (int e = 0; e < E; ++e) x[e] = bad ? NAN : l2[e];

@@ -755,11 +755,7 @@ static hipError_t launch_lane_bwd(const BwdArgs& a, hipStream_t s)
 // 65536 37 / 22, 131072 68 / 42;  QP N = 6: 65536 21 / 12;  N <= 4: launch-bound up to 65536, 131072: 46 / 25 (QCQP N = 4)
 bool bwd_lane_dense_supported(int kind, int N, long B)
 {
-#if defined(DQQ_LANE_BWD_MIN_B)
-    const long min_b = DQQ_LANE_BWD_MIN_B;   // developer sweep (tools/probe_lane_bwd.py --sweep)
-#else
     const long min_b = (N == 8) ? 24576 : 16384;
-#endif
     return (kind == kKindQP || kind == kKindQCQP) && (N == 2 || N == 4 || N == 6 || N == 8) && B >= min_b;
 }
 

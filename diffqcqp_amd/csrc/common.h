@@ -20,31 +20,6 @@
 #define DQQ_HD inline
 #endif
 
-// Debug-only wave timeline (tools/ubench/build_timeline.sh builds a second library with -DDQQ_TIMELINE; the
-// product library compiles DQQ_TL to nothing): lane 0 of every wave drops the 100 MHz constant clock into slot k
-// of its 32-slot record after draining its outstanding memory operations.
-#if defined(DQQ_TIMELINE) && defined(__HIPCC__)
-static __device__ unsigned long long* dqq_timeline_buf = nullptr;
-#endif
-#if defined(DQQ_TIMELINE) && defined(__HIP_DEVICE_COMPILE__)
-#define DQQ_TL(k)                                                                                                     \
-    do {                                                                                                              \
-        if (dqq_timeline_buf != nullptr) {                                                                            \
-            __builtin_amdgcn_s_waitcnt(0);                                                                            \
-            const unsigned long long t_ = wall_clock64();                                                             \
-            if ((threadIdx.x & 63) == 0)                                                                              \
-                dqq_timeline_buf[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32 + (k)] = t_;       \
-        }                                                                                                             \
-    } while (0)
-#define DQQ_TL_VAL(k, v)                                                                                              \
-    do {                                                                                                              \
-        if (dqq_timeline_buf != nullptr && (threadIdx.x & 63) == 0)                                                   \
-            dqq_timeline_buf[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32 + (k)] = (v);          \
-    } while (0)
-#else
-#define DQQ_TL(k) ((void)0)
-#define DQQ_TL_VAL(k, v) ((void)0)
-#endif
 
 namespace dqq {
 

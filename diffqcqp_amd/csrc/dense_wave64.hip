@@ -50,32 +50,6 @@ static DQQ_D void load_tiles_transposed(v4d (&G)[NT][NT], const double* __restri
             }
 }
 
-// G <- tile layout of the symmetric matrix whose lower triangle is A's (what LLT reads, Solver.cpp:76):
-// S[a][b] = A[max(a,b)][min(a,b)].  Off-diagonal tiles are statically one side or the other; inside the diagonal
-// tiles the side depends on the lane.
-template <int NT, bool PAD>
-static DQQ_D void load_tiles_lower_symmetric(v4d (&G)[NT][NT], const double* __restrict__ A, int n, int lane)
-{
-    const int g = lane >> 4, l = lane & 15;
-    const unsigned rowmajor = g * n + l;   // + (16ti + 4r) * n + 16tj : A[16ti+4r+g][16tj+l]
-    const unsigned colmajor = l * n + g;   // + (16tj) * n + 16ti + 4r : A[16tj+l][16ti+4r+g]
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < NT; ++tj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int a = 16 * ti + 4 * r + g, b = 16 * tj + l;
-                const int o_row = (16 * ti + 4 * r) * n + 16 * tj, o_col = (16 * tj) * n + 16 * ti + 4 * r;
-                double v;
-                if (PAD && !(a < n && b < n)) v = (a == b) ? 1.0 : 0.0;
-                else if (ti > tj) v = (A + o_row)[rowmajor];
-                else if (ti < tj) v = (A + o_col)[colmajor];
-                else v = (A + o_row)[(4 * r + g >= l) ? rowmajor : colmajor + (unsigned)(o_col - o_row)];
-                G[ti][tj][r] = v;
-            }
-}
-
 // Diagonal of the matrix <- d (one element per lane: lane l = entry l).  In tile (t,t) lane (g,l) holds the diagonal
 // entry 16t+l in register l >> 2 iff (l & 3) == g.
 template <int NT>
@@ -105,29 +79,7 @@ struct LowerLds {
     static constexpr int tile_base(int ti, int tj) { return (ti * (ti - 1) / 2 + tj) * 16 * kLowLd; } // ti > tj
 };
 
-// G (tile layout of the symmetric matrix, as load_tiles_lower_symmetric leaves it) -> LDS
-template <int NT>
-static DQQ_D void store_lower_to_lds(const v4d (&G)[NT][NT], double* __restrict__ lds, int lane)
-{
-    using L = LowerLds<NT>;
-    const int g = lane >> 4, l = lane & 15;
-    const int rowpart = g * kLowLd + l;                 // entry (4 r + g, l) of a tile: + 4 r * kLowLd
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-        for (int tj = 0; tj <= ti; ++tj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (ti > tj) {
-                    lds[L::tile_base(ti, tj) + 4 * r * kLowLd + rowpart] = G[ti][tj][r];
-                } else {
-                    const int a = 4 * r + g;                                // row inside the diagonal tile
-                    if (a >= l) lds[L::DIAG0 + 136 * ti + a * (a + 1) / 2 + l] = G[ti][ti][r];
-                }
-            }
-}
-
-// The same LDS image written from the TRANSPOSED tile layout the power iteration leaves in registers
+// The LDS image, written from the TRANSPOSED tile layout the power iteration leaves in registers
 // (load_tiles_transposed: T[ti][tj][r] of lane (g,l) = A[16 tj + l][16 ti + 4 r + g]): the lower triangle of A is all in
 // there, so the first factorisation needs no second pass over P in memory (round 5: that pass re-read the lower triangle
 // row-wise AND column-wise -- 0.55 GB of the 2.76 GB a 65536 x 64 forward moved, 1.25x its algorithmic bytes).

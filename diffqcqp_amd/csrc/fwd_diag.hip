@@ -90,12 +90,6 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const long tile = (long)blockIdx.x * WPB + wave;
     const long first = tile * PPW;
-#if defined(DQQ_PROBE_SCRATCH)
-    // developer probe (tools/probe_scratch_cost.py): a private segment that is never touched at run time -- what does its
-    // mere presence cost a launch?
-    volatile double junk[DQQ_PROBE_SCRATCH];
-    if (B < 0) junk[lane % DQQ_PROBE_SCRATCH] = eps;
-#endif
     if (first >= B) return; // whole wave leaves before any workgroup barrier
     // this launch may fill the work-list: the words only its drain writes must be zero (launch.h, work-list hygiene) -- loaded
     // here by the first wave, looked at where the tile is queued
@@ -104,7 +98,6 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
     if constexpr (!FUSE) {
         if (prepares) idle = worklist_prepare_begin(ws, lane);
     }
-    DQQ_TL(0);
     const int nvalid = (B - first) < PPW ? (int)(B - first) : PPW;
     const int pl = lane / LPP;
     const bool valid = pl < nvalid;
@@ -210,8 +203,6 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
         }
     }
 
-    DQQ_TL(1);
-    DQQ_TL(2);
     int it = 0;
     // `mine`: this lane's problem is solved by the diagonal arithmetic below.  A tile with non-diagonal problems hands THOSE
     // to the general solve, problem by problem (round 4, late): which routine solves a problem -- and with it the last
@@ -264,14 +255,6 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
             it = admm_fwd_diag<KIND, E, LaneGroup<LPP>>(p, qv, rad, N, eps, mu_prox, max_iter, adaptive, mine, xv, lo,
                                                         hi, sg);
     }
-#ifdef DQQ_TIMELINE
-    {
-        int m = mine ? it : 0, s = mine ? it : 0;
-        for (int o = 32; o; o >>= 1) { m = max(m, __shfl_xor(m, o)); s += __shfl_xor(s, o); }
-        DQQ_TL_VAL(6, (unsigned long long)m);
-        DQQ_TL_VAL(7, (unsigned long long)s);
-    }
-#endif
 
     if (mine) {
         if (!moved) {
@@ -305,7 +288,6 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
             }
         }
     }
-    DQQ_TL(5);
 }
 
 template <int KIND, int N, int LPP, int WPB, bool FUSE>
@@ -481,10 +463,3 @@ hipError_t launch_fwd_diag(int kind, const FwdArgs& a, int lpp, int wpb, int fus
 
 } // namespace dqq
 
-#ifdef DQQ_TIMELINE
-// debug library only (tools/ubench/build_timeline.sh): where the waves of fwd_diag_kernel drop their clocks
-extern "C" __attribute__((visibility("default"))) int dqq_debug_set_timeline(void* buf)
-{
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(dqq_timeline_buf), &buf, sizeof(buf));
-}
-#endif
