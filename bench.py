@@ -251,6 +251,10 @@ WORKLOADS = {
         "backward]", [("qp", 8, "diag", True)], 65536, "weak", 16384),
     9: ("qp_pair_large: B=1048576 N=8 diagonal-P (dense (B,8,8) layout) QP forward+backward on one stream (the batch that "
         "fills the chip)", [("qp", 8, "diag", True)], 1048576, "weak", 16384),
+    # one rank's share of BASELINE configs[3] on an 8-GPU node (32768 of the 262144 problems), on this one GPU: what the
+    # kernels leave of linear strong scaling BEFORE the exchange step -- measured, not a multi-GPU figure
+    10: ("one eighth of BASELINE configs[3] (B=32768 N=32 diagonal-P QP forward+backward): the shard a rank of an 8-GPU run "
+         "solves", [("qp", 32, "diag", True)], 32768, "weak", 4096),
 }
 
 
@@ -393,7 +397,7 @@ def measure(cfg, args, ctx, light=False):
     if cfg == 4 and args.steps == 100:
         steps = 20
     if light:
-        steps, repeats, warmup = {2: 50, 3: 50, 4: 10, 5: 3, 0: 50, 6: 10, 7: 10, 8: 50, 9: 10}[cfg], 3, 3
+        steps, repeats, warmup = {2: 50, 3: 50, 4: 10, 5: 3, 0: 50, 6: 10, 7: 10, 8: 50, 9: 10, 10: 30}[cfg], 3, 3
 
     chains = [Chain(f[0], B_rank, f[1], f[2], f[3], dev, 1000 + 17 * (0 if cfg >= 8 else min(cfg, 6)) + 7919 * rank + 31 * i,
                     layout=(f[4] if len(f) > 4 else 0)) for i, f in enumerate(families)]
@@ -645,7 +649,7 @@ def measure(cfg, args, ctx, light=False):
     # HBM traffic: measured by THIS run when it can (live_pmc: two rocprofv3 --pmc passes over a child process that issues
     # this workload's launches); the VALU instruction counts and, as a fall-back, the traffic come from the committed
     # summary of the same workload (tools/profile.sh), with their provenance
-    tag = {0: "", 2: "_cfg2", 3: "_cfg3", 4: "_cfg4", 5: "_cfg5", 6: "_cfg6", 7: "_cfg7", 8: "_cfg2", 9: None}[cfg]
+    tag = {0: "", 2: "_cfg2", 3: "_cfg3", 4: "_cfg4", 5: "_cfg5", 6: "_cfg6", 7: "_cfg7", 8: "_cfg2", 9: None, 10: None}[cfg]
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest%s.json" % tag) if tag is not None else None
     if pmc_path and os.path.exists(pmc_path):
         try:
@@ -746,7 +750,7 @@ def measure(cfg, args, ctx, light=False):
     out.update(extra)
     if not args.no_check:
         out["parity_max_abs_err_vs_oracle_sample"] = {c.names[0][:-4]: c.check(256 if c.N >= 32 else 2048) for c in chains}
-    if world == 1 and not args.no_cpu_baseline and cfg != 9:   # (cfg 9 is cfg 8's family at another batch size)
+    if world == 1 and not args.no_cpu_baseline and cfg not in (9, 10):   # (cfg 9 / 10: cfg 8's / cfg 4's family at another batch size)
         from oracle import oracle as O
         cores = O.max_threads()
         n = min(cpu_n, chains[0].B)
@@ -963,7 +967,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, default=None, choices=(0, 2, 3, 4, 5, 6, 7, 8, 9),
+    ap.add_argument("--config", type=int, default=None, choices=(0, 2, 3, 4, 5, 6, 7, 8, 9, 10),
                     help="BASELINE.json configs entry (1-based); 0 = the headline step (configs 2'+3).  Default: the "
                          "headline (distributed: on every rank, weak scaling; with_gather = with the RCCL all-gather of x) and "
                          "configs[3] (the batch split over the ranks) as the sub-record strong_config4")
@@ -1058,6 +1062,12 @@ def main():
                 cfgk.update(flat_summary("cfg%d" % cfg, per["config_%d" % cfg]))
                 details.update(flat_details("cfg%d" % cfg, per["config_%d" % cfg]))
             out["per_config"] = per
+            # one rank's share of configs[3] on an 8-GPU node, on this GPU: how much of linear strong scaling the kernels keep
+            # at the smaller batch, before the all-gather of x (8.4 MB per rank; SURVEY 8(e): ~55 us over 7 xGMI links)
+            sh = condensed(measure(10, args, ctx, light=True))
+            per["config_4_shard_1_of_8"] = sh
+            details["cfg4_shard8_ms_per_step"] = sh["ms_per_step"]
+            details["cfg4_shard8_kernel_scaling_efficiency"] = per["config_4"]["ms_per_step"] / (8.0 * sh["ms_per_step"])
             out["per_config_note"] = "BASELINE.json configs 2-5 (1-based) measured by THIS run, 3 regions each; config_4 " \
                                      "is the whole B=262144 batch on this one GPU; cfgK_moved_frac = the STEP's bytes that " \
                                      "move / step time / 8 TB/s"
