@@ -24,32 +24,38 @@ Workloads (`--config k` = k-th entry of BASELINE.json `configs`, 1-based as in B
             solves/s on 1 x MI355X with its HBM fraction") as one timed step;   9  `qp_pair_large`: the same at
             B=1048576, the batch size that fills the chip
 Timing: W warm-up steps, then R regions of EXACTLY K steps, each bracketed by barrier + torch.cuda.synchronize()
-on both sides and reduced with MAX over the ranks; `ms_per_step` / `value` are the MEDIAN region (min / max in
-`repeats`), so a short K is not a single sub-millisecond sample.
+on both sides and reduced with MAX over the ranks; `ms_per_step` / `value` are the MEDIAN region, so a short K is not a
+single sub-millisecond sample.  Step k works on input/output set k mod nsets (> 768 MiB of sets in total): a training
+loop presents new data every step, so `value` is the step that finds nothing in the 256 MiB Infinity Cache ("cold");
+the same step on one set, step after step, is reported beside it (`hot_*`).  --hot-only: one set.
+
+Output.  Rank 0 prints ONE line on stdout: the contract keys, `config` (workload + <= 20 scalars), `roofline` (<= 24
+scalars), `cpu_baseline` -- at most 6000 bytes, strict JSON, nothing nested (contract_line()).  The FULL record -- per-launch
+brackets, the sub-records below, the environment -- goes to bench_details.json next to this file (--details PATH) and,
+prefixed with "[bench details] ", to stderr.
 
 Default run (no --config): on ONE GPU the headline step, followed by short runs of the two qp_pair workloads, BASELINE
 configs 2, 3, 4, 5 (`per_config`: 3 regions each, dominant kernel, roofline fractions, CPU baseline) and the dense-P check
-(`dense_p_n8`), so that one driver-run line carries every workload.  Fractions: every key WITHOUT `algorithmic` in its name
-is computed from the bytes the launches really move (the backward takes the forward's 8N-byte verified diagonal instead of
-re-reading the 8N^2-byte P) and is physically bounded by 6.29 / 8.0 = 0.79; SURVEY.md 8(d)'s algorithmic bytes (which
-count that read) give the `*_algorithmic*` keys, which can exceed 1.  Under torch.distributed.run (WORLD_SIZE set; any number of
-ranks) the line is the SAME headline step on every rank (weak scaling, no data-path collective: value(N) / (N value(1)) is
-the scaling efficiency); `with_gather` = the same step with the path's optional exchange step -- the RCCL all-gather of both
-families' x, behind their forwards, beside their backwards --, and configs[3], the batch SPLIT over the ranks (strong
-scaling, with / without / serialised gather), is the sub-record `strong_config4`.
+(`dense_p_n8`); their step times and fractions are scalars of the line.  Fractions: every key WITHOUT `algorithmic` in
+its name is computed from the bytes the launches really move (the backward takes the forward's 8N-byte verified diagonal
+instead of re-reading the 8N^2-byte P) and is physically bounded by 6.29 / 8.0 = 0.79; SURVEY.md 8(d)'s algorithmic bytes
+(which count that read) give the `*_algorithmic*` keys, which can exceed 1.  Under torch.distributed.run (WORLD_SIZE set; any
+number of ranks) the line is the SAME headline step on every rank (weak scaling, no data-path collective: value(N) / (N
+value(1)) is the scaling efficiency); `with_gather` = the same step with the path's optional exchange step -- the RCCL
+all-gather of both families' x, behind their forwards, beside their backwards --, and configs[3], the batch SPLIT over the
+ranks (strong scaling, with / without / serialised gather), is the sub-record `strong_config4`.
 
-Rank 0 prints ONE JSON line.  Besides the contract keys:
   roofline      the launch with the largest mean duration: algorithmic bytes / its duration from
-                HIP events on the launch stream vs 8 TB/s; `moved` = the bytes that launch really reads + writes
-                (the backward takes the 64-byte verified diagonal from the forward instead of the 512-byte P);
-                `traffic` = HBM bytes of that launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) that THIS run
-                spawns over its own launches (`traffic_source` says so; the committed profiles/pmc_latest*.json is the
-                fall-back); for the compute-bound config 5 also the FP64 figure (`fp64`)
+                HIP events on the launch stream vs 8 TB/s; `moved_frac` = on the bytes that launch really reads + writes;
+                `traffic` = HBM bytes of that launch from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE), quoted from the
+                committed profiles/pmc_latest*.json (`traffic_source`; `pmc_matches_build` in the details says whether
+                that summary is of this build) or measured now with --live-pmc; `valu_busy_frac` = the share of the
+                kernel's cycles in which a SIMD's VALU was executing (counters of one run, only when they are of this
+                build); for the compute-bound config 5 also the FP64 figure (`fp64`)
   cpu_baseline  the oracle (C port of the reference algorithm) on this box's host cores, bounded sample; also the
                 reference's execution model -- a Python loop with one FFI call per problem (`python_loop_value`)
-  kernels       per-launch breakdown;   cold   the same step over rotating input/output sets (> 256 MiB cache)
-  environment   clocks / power cap (rocm-smi) and GPU_MAX_HW_QUEUES of this box; single_stream = the same step on one
-                stream -- boxes of the pool differ by up to ~9 %, compare rounds on both figures
+  details       kernels (per-launch breakdown), hot, single_stream, per_config, dense_p_n8, survey_8d_extras, environment
+                (clocks / power cap: boxes of the pool differ by up to ~9 %)
 """
 import argparse
 import json
@@ -98,6 +104,12 @@ def moved_bytes(kind, N, pas, diag_handoff):
     return b + 8 * N + 1 if pas == "fwd" else b - 8 * N * N + 8 * N + 1
 
 
+def csrc_sha16():
+    """The build's source hash (diffqcqp_amd/build.py: source_sha16) -- what a counter summary under profiles/ records."""
+    from diffqcqp_amd import build
+    return build.source_sha16()
+
+
 class Chain:
     """One problem family on one batch: forward [+ backward] launches with every pointer resolved once."""
 
@@ -105,6 +117,7 @@ class Chain:
         from diffqcqp_amd import _capi, ops
         self.lib, self.kind, self.B, self.N, self.backward, self.layout = _capi.lib(), kind, B, N, backward, layout
         self.structure, self.dev = structure, dev
+        self.seed = seed
         self.sets = [self._make_set(seed + 104729 * s) for s in range(nsets)]
         self.names = [kind + "_fwd"] + ([kind + "_bwd"] if backward else [])
         self.ws = {}
@@ -136,6 +149,14 @@ class Chain:
                 t["gl"], t["gm"] = e(B, N // 2, 1), e(B, N // 2, 1)
         t["pdiag"], t["flags"] = e(B, N), torch.empty(B, dtype=torch.uint8, device=dev)
         return t
+
+    def bytes_per_set(self):
+        return sum(v.numel() * v.element_size() for v in self.sets[0].values())
+
+    def add_sets(self, n):
+        """n more input / output sets (distinct seeds): a step that rotates over them never finds its data in the 256 MiB
+        Infinity Cache."""
+        self.sets += [self._make_set(self.seed + 104729 * s) for s in range(len(self.sets), len(self.sets) + n)]
 
     def workspace(self, stream):
         if stream not in self.ws:
@@ -375,8 +396,8 @@ def pmc_child(cfg):
 
 
 def measure(cfg, args, ctx, light=False):
-    """One workload -> its record (rank 0; None on the other ranks).  light: a per_config sub-record -- 3 regions, no
-    cold set, no single-stream context."""
+    """One workload -> its full record (rank 0; None on the other ranks).  light: a sub-record of the default run -- 3
+    regions, no hot / single-stream context."""
     rank, world, dev, use_dist = ctx["rank"], ctx["world"], ctx["dev"], ctx["use_dist"]
     dist, parallel, _capi = ctx["dist"], ctx["parallel"], ctx["capi"]
     desc, families, B_total, scaling, cpu_n = WORKLOADS[cfg]
@@ -401,6 +422,14 @@ def measure(cfg, args, ctx, light=False):
 
     chains = [Chain(f[0], B_rank, f[1], f[2], f[3], dev, 1000 + 17 * (0 if cfg >= 8 else min(cfg, 6)) + 7919 * rank + 31 * i,
                     layout=(f[4] if len(f) > 4 else 0)) for i, f in enumerate(families)]
+    # ---- rotating buffers: a training loop presents NEW data every step, so the step that `value` times never finds its
+    # inputs or outputs in the 256 MiB Infinity Cache: every chain gets enough distinct input / output sets for > 768 MiB
+    # in total and step k works on set k mod nsets.  (A workload whose single set is already that large needs no second
+    # one.)  --hot-only: one set, the same buffers every step (the cache-resident figure, reported as `hot_*` otherwise)
+    per_set = sum(c.bytes_per_set() for c in chains)
+    nsets = 1 if (args.hot_only or per_set >= 768 * 2**20) else max(3, int(np.ceil(768 * 2**20 / per_set)))
+    for c in chains:
+        c.add_sets(nsets - 1)
     main_stream = torch.cuda.current_stream()
     sh = main_stream.cuda_stream
     side = ctx["side"] if (len(chains) == 2 and args.streams == 2) else None
@@ -413,7 +442,16 @@ def measure(cfg, args, ctx, light=False):
             x_all[i] = torch.empty((B_gather, c.N, 1), dtype=F64, device=dev)
             gather_scratch[i] = torch.empty((rows, c.N, 1), dtype=F64, device=dev) if rows else None
 
-    def step(s=0):
+    ctr = [0]          # steps issued so far: step k works on set k mod nsets
+    last_set = [0]
+
+    def next_set():
+        s = ctr[0] % nsets
+        ctr[0] += 1
+        last_set[0] = s
+        return s
+
+    def step_on(s):
         """One pass of the hot path over this rank's batch (all chains; set s of each)."""
         if side is not None:  # interleave so that both streams are fed; the longer chain (the QCQP) first
             chains[1].launch(0, streams[1], s)
@@ -423,6 +461,12 @@ def measure(cfg, args, ctx, light=False):
         else:
             for c in chains:
                 c.run(sh, s)
+
+    def step():
+        step_on(next_set())
+
+    def hot_step():
+        step_on(0)
 
     def drain():
         if side is not None:
@@ -447,8 +491,8 @@ def measure(cfg, args, ctx, light=False):
             fn()
         enq[0] = time.perf_counter() - t0   # the host is done enqueueing here (no synchronise yet): host-bound iff ~ el
         # spin on the streams' completion before the synchronize() that closes the region: a blocked synchronize() wakes
-        # up ~30 us after the GPU is done (tools/probe_region_dissect.py: 1219 -> 1188 us for 20 headline steps), which is
-        # the host's scheduler, not the path being measured; the region still ends with synchronize() on both streams
+        # up ~30 us after the GPU is done, which is the host's scheduler, not the path being measured; the region still
+        # ends with synchronize() on both streams
         while not (main_stream.query() and (side is None or side.query())):
             pass
         drain()
@@ -462,18 +506,19 @@ def measure(cfg, args, ctx, light=False):
         enq_log.append((el, enq[0], k))
         return el
 
-    def gather_x(i, async_op):
-        """All-gather of chain i's x, ordered behind the work already enqueued on that chain's stream (RCCL synchronises
-        with torch's CURRENT stream: the side chain's collective is issued with its stream current)."""
+    def gather_x(i, async_op, s):
+        """All-gather of chain i's x (set s), ordered behind the work already enqueued on that chain's stream (RCCL
+        synchronises with torch's CURRENT stream: the side chain's collective is issued with its stream current)."""
         with torch.cuda.stream(tstreams[i]):
-            return parallel.gather_batch(chains[i].sets[0]["x"], B_gather, async_op=async_op, out=x_all[i],
+            return parallel.gather_batch(chains[i].sets[s]["x"], B_gather, async_op=async_op, out=x_all[i],
                                          scratch=gather_scratch[i])
 
     def step_and_gather_serial():
-        step()
+        s = next_set()
+        step_on(s)
         if use_dist:
             for i in range(len(chains)):
-                gather_x(i, False)
+                gather_x(i, False, s)
 
     def step_and_gather():
         """The path's one exchange step where it belongs: x is complete after the FORWARD, so its all-gather (RCCL's own
@@ -482,53 +527,53 @@ def measure(cfg, args, ctx, light=False):
         collectives)."""
         if not use_dist:
             return step()
+        s = next_set()
         order = list(range(len(chains)))[::-1]        # the longer chain (the QCQP of the headline) first
         for i in order:
-            chains[i].launch(0, streams[i])
-        works = [(i, gather_x(i, True)[1]) for i in order]
+            chains[i].launch(0, streams[i], s)
+        works = [(i, gather_x(i, True, s)[1]) for i in order]
         for i in order:
             for w in range(1, len(chains[i].names)):
-                chains[i].launch(w, streams[i])
+                chains[i].launch(w, streams[i], s)
         for i, work in works:
             with torch.cuda.stream(tstreams[i]):
                 work.wait()
 
     timed = step_and_gather if gather else step
 
-    # ---- per-launch pass FIRST (round 4): HIP events around every C-ABI call of the step, then runs of each call back to
-    # back -- about 10 ms of GPU work.  After an idle spell the chip takes 10-20 ms to come back to its clocks
-    # (tools/probe_region_gap.py: 10 ms of idleness before a region cost 6 us per step over the NEXT 100 steps), and a driver
-    # run with --warmup 5 --steps 20 has only 0.3 ms of warm-up before 12 ms of timed regions: run behind the diagnostics,
-    # the timed regions measure the kernels, not the ramp.
+    # ---- per-launch pass FIRST: HIP events around every C-ABI call of the step, then runs of each call back to back --
+    # about 10 ms of GPU work.  After an idle spell the chip takes 10-20 ms to come back to its clocks, and a driver run
+    # with --warmup 5 --steps 20 has only 0.3 ms of warm-up before 12 ms of timed regions: run behind the diagnostics, the
+    # timed regions measure the kernels, not the ramp.
     # A bracket holds one C-ABI CALL: one kernel for the N = 8 forwards (non-diagonal tiles are solved inside the kernel);
-    # the kernel plus the launch that drains its work-list -- empty on a diagonal batch, ~2.6 us -- for the backwards and
-    # for N >= 16 (round 5: the measurement-only knob that used to switch the drain launch off is gone from the library;
-    # rocprofv3's per-kernel durations, profiles/, are the kernel-alone figures).
+    # the kernel plus the launch that drains its work-list for the backwards and for N >= 16 (rocprofv3's per-kernel
+    # durations, profiles/, are the kernel-alone figures).  Launch r works on set r mod nsets, as the steps do.
     nrep = 5 if cfg == 5 else (20 if cfg in (4, 9) else (30 if light else 100))
     launches = [(c, w) for c in chains for w in range(len(c.names))]
     ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in launches]
           for _ in range(nrep)]
-    for c, w in launches:       # (first launches: module load, function attributes, workspace -- not part of any figure)
-        c.launch(w, sh)
+    for s in range(nsets):      # (first launches: module load, function attributes, workspace; every set gets its x,
+        for c, w in launches:   # pdiag and flags from a forward before any backward is timed alone)
+            c.launch(w, sh, s)
     torch.cuda.synchronize()
     for r in range(nrep):
         for j, (c, w) in enumerate(launches):
             ev[r][j][0].record(main_stream)
-            c.launch(w, sh)
+            c.launch(w, sh, r % nsets)
             ev[r][j][1].record(main_stream)
     torch.cuda.synchronize()
     # the same launches in RUNS: nrep launches of one kernel back to back between two events.  A bracket around a single
-    # launch also times the two event packets (~3 us on a 10-30 us kernel, which is why rocprofv3 read 2-3 us less than this
-    # line did: VERDICT r3); a run's mean is the kernel plus its launch gap and agrees with rocprofv3 to ~2 %
-    # (three runs per kernel, the median counts: one run in a few hundred catches a multi-millisecond stall of the box)
+    # launch also times the two event packets (~3 us on a 10-30 us kernel); a run's mean is the kernel plus its launch
+    # gap and agrees with rocprofv3 to ~2 % (three runs per kernel, the median counts: one run in a few hundred catches a
+    # multi-millisecond stall of the box)
     runs = []
     for c, w in launches:
         trio = []
         for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(main_stream)
-            for _ in range(nrep):
-                c.launch(w, sh)
+            for r in range(nrep):
+                c.launch(w, sh, r % nsets)
             e1.record(main_stream)
             trio.append((e0, e1))
         runs.append(trio)
@@ -552,8 +597,8 @@ def measure(cfg, args, ctx, light=False):
     elapsed = times[len(times) // 2]
     host_enqueue_us = sorted(e / k for _, e, k in enq_log)[len(enq_log) // 2] * 1e6
     # How much of a K-step region is fill / drain / synchronise latency rather than steady state?  The same step in
-    # regions of 5K steps: T(K) = F + s K from the two medians (the driver times --steps 20, the
-    # builder's profiles used to time --steps 100; the fixed ~90 us of a region are 8 % of the former, 1.6 % of the latter)
+    # regions of 5K steps: T(K) = F + s K from the two medians (the driver times --steps 20; the fixed ~90 us of a region
+    # are 8 % of that)
     region_fit = None
     if not light and cfg != 4:
         kl = 5 * steps
@@ -571,12 +616,12 @@ def measure(cfg, args, ctx, light=False):
                                 "allgather_bytes_per_rank": sum(c.B * c.N * 8 for c in chains),
                                 "rccl_world": dist.get_world_size(),
                                 "note": "x of every rank all-gathered in every step (one collective per family, behind its forward, "
-                                        "beside its backward); two torch.distributed calls per 56 us step: host-side cost included"}
+                                        "beside its backward); two torch.distributed calls per step: host-side cost included"}
     if (gather or gather_extra) and use_dist:
         torch.cuda.synchronize()
         lo_r, hi_r = parallel.shard_bounds(B_gather, rank, world)
         for i, c in enumerate(chains):
-            assert x_all[i].shape[0] == B_gather and torch.equal(x_all[i][lo_r:hi_r], c.sets[0]["x"]), "all-gather of x"
+            assert x_all[i].shape[0] == B_gather and torch.equal(x_all[i][lo_r:hi_r], c.sets[last_set[0]]["x"]), "all-gather of x"
     if gather and use_dist:   # the same regions with the gather behind the whole step instead of beside the backward
         tg = sorted(region(step_and_gather_serial, steps) for _ in range(max(repeats // 2, 1)))
         extra["gather_after_backward"] = {"ms_per_step": tg[len(tg) // 2] / steps * 1e3,
@@ -588,42 +633,28 @@ def measure(cfg, args, ctx, light=False):
                                    "value": units_per_step_all * steps / tn[len(tn) // 2],
                                    "allgather_bytes_per_rank": sum(c.B * c.N * 8 for c in chains),
                                    "rccl_world": dist.get_world_size() if use_dist else 1}
-    if side is not None and not light:   # context: the same steps strictly on one stream
+    if side is not None and not light and not args.no_hot:   # context: the same steps strictly on one stream
         save, side = side, None
         t1 = sorted(region(step, steps) for _ in range(3))
         side = save
         extra["single_stream"] = {"ms_per_step": t1[1] / steps * 1e3,
                                   "value_this_rank": sum(c.B for c in chains) * steps / t1[1],
                                   "note": "all launches of a step on one stream"}
-
-    # ---- cold variant: rotate input AND output sets so that a step never finds its data in the 256 MiB Infinity Cache
-    if cfg in (0, 2, 3) and not args.no_cold and world == 1 and not light:
-        per_set = sum(sum(v.numel() * v.element_size() for v in c.sets[0].values()) for c in chains)
-        nsets = max(3, int(np.ceil(768 * 2**20 / per_set)))
-        cold = [Chain(c.kind, c.B, c.N, c.structure, c.backward, dev, 5000 + 13 * i, nsets=nsets)
-                for i, c in enumerate(chains)]
-        hot, chains = chains, cold
-        ctr = [0]
-
-        def cold_step():
-            step(ctr[0] % nsets)
-            ctr[0] += 1
-        for _ in range(nsets):
-            cold_step()
+    # ---- hot variant: the same step on ONE set, step after step (everything a step touches fits the Infinity Cache when the
+    # set is < 256 MiB) -- context, never `value`
+    if nsets > 1 and not light and not args.no_hot:
+        for _ in range(3):
+            hot_step()
         drain()
-        tc = sorted(region(cold_step, steps) for _ in range(max(repeats // 2, 3)))
-        chains = hot
-        extra["cold"] = {"sets": nsets, "bytes_per_set": per_set, "ms_per_step": tc[len(tc) // 2] / steps * 1e3,
-                         "value": sum(c.B for c in chains) * steps / tc[len(tc) // 2],
-                         "note": "inputs and outputs rotate over `sets` distinct buffers (> 256 MiB in total)"}
-        del cold
-        torch.cuda.empty_cache()
+        th = sorted(region(hot_step, steps) for _ in range(max(repeats // 2, 3)))
+        extra["hot"] = {"ms_per_step": th[len(th) // 2] / steps * 1e3,
+                        "value": units_per_step_all * steps / th[len(th) // 2],
+                        "note": "the same buffers every step (%.0f MB: resident in the 256 MiB Infinity Cache)" % (per_set / 1e6)}
 
     dom = max(kernels, key=lambda k: kernels[k]["mean_us"])
     step_algo = sum(k["algorithmic_bytes_per_launch"] for k in kernels.values())
     step_moved = sum(k["moved_bytes_per_launch"] for k in kernels.values())
     step_s = elapsed / steps
-    # Key order matters: the driver's record keeps the first ~24 scalars of `roofline` and of `config`.
     # Naming rule: a fraction WITHOUT `algorithmic` in its name is computed from bytes that move and cannot exceed
     # 6.29 / 8.0 = 0.79; `frac` / `achieved` (the contract's keys: SURVEY 8(d) algorithmic bytes of the dominant launch) obey
     # it too because the dominant launch is a forward, whose algorithmic bytes are fewer than the bytes it moves.
@@ -641,48 +672,42 @@ def measure(cfg, args, ctx, light=False):
         "timing": "HIP events on the launch stream around a run of %d back-to-back C-ABI calls of the launch (mean)" % nrep,
         "host_enqueue_us_per_step": host_enqueue_us,
         "kernels_sum_us": sum(k["mean_us"] for k in kernels.values()),
+        "buffer_sets": nsets,
     }
     for k, v in kernels.items():
         roofline["kernel_us_" + k] = v["mean_us"]
     if region_fit:
         roofline.update(region_fit)
-    # HBM traffic: measured by THIS run when it can (live_pmc: two rocprofv3 --pmc passes over a child process that issues
-    # this workload's launches); the VALU instruction counts and, as a fall-back, the traffic come from the committed
-    # summary of the same workload (tools/profile.sh), with their provenance
+    # HBM traffic and the VALU counters: quoted from the committed counter summary of the same workload (tools/profile.sh ->
+    # profiles/pmc_latest*.json), with its provenance; `pmc_matches_build` says whether that summary was taken on THIS
+    # build (the sha of csrc/ it records); the counter-derived VALU figures are dropped when it was not.  --live-pmc: two
+    # rocprofv3 passes spawned by this run over its own launches measure the traffic now
     tag = {0: "", 2: "_cfg2", 3: "_cfg3", 4: "_cfg4", 5: "_cfg5", 6: "_cfg6", 7: "_cfg7", 8: "_cfg2", 9: None, 10: None}[cfg]
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest%s.json" % tag) if tag is not None else None
     if pmc_path and os.path.exists(pmc_path):
         try:
             allp = json.load(open(pmc_path))
             pmc = allp.get(dom, {})
-            src = "profiles/%s (rocprofv3 --pmc passes of tools/profile.sh, tag %s; not measured by this run)" % (
-                os.path.basename(pmc_path), allp.get("_tag", "?"))
+            fresh = allp.get("_csrc_sha16") == csrc_sha16()
             roofline["traffic"] = pmc.get("hbm_bytes_per_launch")
-            roofline["traffic_source"] = src
-            if "SQ_INSTS_VALU" in pmc:
-                floor_us = pmc["SQ_INSTS_VALU"] / 1024.0 * 2.08e-3
-                # the N = 8 forward kernels are bound by FP64 VALU issue, not by HBM: the binding
-                # roofline is reported next to the nominal one
-                roofline["fp64_valu_issue"] = {
-                    "bound": "fp64_valu_issue", "valu_insts_per_launch": pmc["SQ_INSTS_VALU"],
-                    "issue_floor_ns_per_wave_inst": 2.08, "floor_us": floor_us,
-                    "frac": floor_us / kernels[dom]["mean_us"], "source": src}
-                roofline["fp64_valu_issue_floor_us"] = floor_us
-                roofline["fp64_valu_issue_frac"] = floor_us / kernels[dom]["mean_us"]
-                if floor_us / kernels[dom]["mean_us"] > roofline["frac"]:
-                    roofline["binding"] = "fp64_valu_issue"
-            for k in ("valu_lane_utilisation", "SQ_WAIT_INST_ANY_frac", "SQ_WAIT_ANY_frac"):
-                if k in pmc:
-                    roofline["pmc_" + k] = pmc[k]
+            roofline["traffic_source"] = "profiles/%s tag %s" % (os.path.basename(pmc_path), allp.get("_tag", "?"))
+            roofline["pmc_matches_build"] = fresh
+            if roofline["traffic"]:
+                roofline["traffic_over_algorithmic"] = roofline["traffic"] / kernels[dom]["algorithmic_bytes_per_launch"]
+            if fresh:
+                # what binds the N = 8 forwards is VALU issue, not HBM: the share of the kernel's cycles in
+                # which a SIMD's VALU was executing, from the counters of one run (SQ_ACTIVE_INST_VALU: quad-cycles summed
+                # over the SIMDs; SQ_BUSY_CYCLES: cycles summed over the shader engines) -- a measured share, <= 1
+                for k in ("valu_busy_frac", "valu_lane_utilisation", "SQ_WAIT_INST_ANY_frac", "SQ_WAIT_ANY_frac"):
+                    if k in pmc:
+                        roofline[k if k.startswith("valu") else "pmc_" + k] = pmc[k]
         except Exception:
             pass
     if ctx.get("live_pmc") and rank == 0 and world == 1 and not light:
         live = live_pmc(cfg)
         if live and dom in live:
             roofline["traffic"] = live[dom]["hbm_bytes_per_launch"]
-            roofline["traffic_source"] = "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) spawned " \
-                                         "by this run over its own launches; HBM bytes = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB " \
-                                         "(MI355X_MICROARCH.md gfx950 correction), mean per launch"
+            roofline["traffic_source"] = "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run"
             roofline["traffic_kernels"] = live[dom]["kernels"]
             roofline["traffic_over_algorithmic"] = live[dom]["hbm_bytes_per_launch"] / kernels[dom]["algorithmic_bytes_per_launch"]
             roofline["live_pmc"] = live
@@ -710,15 +735,20 @@ def measure(cfg, args, ctx, light=False):
         roofline["fp64_TFLOPs"] = roofline["fp64"]["achieved"][dom]
     if "single_stream" in extra:
         roofline["single_stream_ms_per_step"] = extra["single_stream"]["ms_per_step"]
-    if "cold" in extra:
-        roofline["cold_ms_per_step"] = extra["cold"]["ms_per_step"]
+    # `value` is the rotating-buffer ("cold") step whenever the workload's buffers would otherwise fit the cache
+    roofline["cold_ms_per_step"], roofline["cold_value"] = (elapsed / steps * 1e3, units_per_step_all * steps / elapsed) \
+        if (nsets > 1 or per_set >= 768 * 2**20) else (None, None)
+    if "hot" in extra:
+        roofline["hot_ms_per_step"], roofline["hot_value"] = extra["hot"]["ms_per_step"], extra["hot"]["value"]
+    elif nsets == 1 and per_set < 768 * 2**20:
+        roofline["hot_ms_per_step"], roofline["hot_value"] = elapsed / steps * 1e3, units_per_step_all * steps / elapsed
 
     if rank != 0:
         del chains
         torch.cuda.empty_cache()
         return None
 
-    units_per_step = (B_total if scaling == "strong" else sum(c.B for c in chains) * world)
+    units_per_step = units_per_step_all
     out = {
         "metric": "QP+QCQP solves/sec (fwd+bwd)" if cfg != 2 else "QP forward solves/sec",
         "value": units_per_step * steps / elapsed, "unit": "solves/s",
@@ -728,8 +758,12 @@ def measure(cfg, args, ctx, light=False):
         "config": {
             "workload": desc + "; eps=1e-7 max_iter=1000 mu_prox=1e-7",
             "baseline_config": cfg if cfg else "2'+3 (headline)",
-            "B_total": B_total if scaling == "strong" else sum(c.B for c in chains) * world,
+            "B_total": units_per_step,
             "B_this_rank": [c.B for c in chains], "N": [c.N for c in chains],
+            "buffers": ("step k works on input/output set k mod %d (%.0f MB per set): no step finds its data in the 256 MiB "
+                        "Infinity Cache" % (nsets, per_set / 1e6)) if nsets > 1 else
+                       ("one set of %.0f MB" % (per_set / 1e6) + (" (larger than the cache)" if per_set >= 768 * 2**20 else
+                                                                   ", the same buffers every step (cache-resident)")),
             "p_layout": ("dense (declared)" if chains[0].layout == 1 else
                          "auto (off-diagonals verified in-kernel; non-diagonal tiles go to the general kernel)"),
             "launch": "eager, one C-ABI call per pass" + (", the two families on two streams" if side is not None else ""),
@@ -825,7 +859,8 @@ def condensed(rec):
                         "step_moved_frac": rl["step_moved_frac"], "step_moved_GBps": rl["step_moved_GBps"],
                         "step_algorithmic_frac": rl["step_algorithmic_frac"],
                         "traffic": rl.get("traffic"), "traffic_source": rl.get("traffic_source")}}
-    for k in ("fp64_frac", "fp64_TFLOPs", "fp64_valu_issue_frac", "pmc_valu_lane_utilisation", "traffic_over_algorithmic"):
+    for k in ("fp64_frac", "fp64_TFLOPs", "valu_busy_frac", "valu_lane_utilisation", "traffic_over_algorithmic",
+              "pmc_matches_build", "buffer_sets"):
         if k in rl:
             out["roofline"][k] = rl[k]
     for k in ("without_gather", "gather_after_backward", "parity_max_abs_err_vs_oracle_sample", "gpu_over_cpu_all_cores"):
@@ -856,13 +891,6 @@ def flat_details(prefix, rec):
         out[prefix + "_us_" + k] = v
     if "cpu_baseline" in rec:
         out[prefix + "_cpu_solves_per_s"] = rec["cpu_baseline"]["value"]
-    return out
-
-
-def reordered(d, first):
-    """d with the keys of `first` (those present) in front, in that order."""
-    out = {k: d[k] for k in first if k in d}
-    out.update({k: v for k, v in d.items() if k not in out})
     return out
 
 
@@ -962,6 +990,100 @@ def survey_extras_record(args, ctx):
     return rec
 
 
+# ---- the contract line -----------------------------------------------------------------------------------------------------
+LINE_LIMIT = 6000      # bytes of the one stdout line (the driver's record of a longer line was unreadable: round 5)
+CONFIG_KEYS = [        # `config`: workload + at most 20 scalars
+    "baseline_config", "B_total", "rccl_world", "buffers",
+    "cfg2_ms_per_step", "cfg2_moved_frac", "cfg3_ms_per_step", "cfg3_moved_frac", "cfg4_ms_per_step", "cfg4_moved_frac",
+    "cfg5_ms_per_step", "cfg5_fp64_frac", "dense8_auto_ms_per_step", "dense8_auto_no_hint_ms_per_step",
+    "dense8_dense_ms_per_step", "dense8_auto_no_hint_over_dense", "stress_p_u01_qp_fwd_ms", "ref_figure_qp_fwd_ms",
+    "ref_figure_qcqp_fwd_ms", "qcqp_grad_exit_flip_rate",
+    # distributed runs (the sub-records above are measured by plain one-GPU runs only)
+    "with_gather_ms_per_step", "with_gather_value", "strong_cfg4_ms_per_step", "strong_cfg4_value",
+    "strong_cfg4_without_gather_ms_per_step", "strong_cfg4_gather_after_backward_ms_per_step"]
+ROOFLINE_KEYS = [      # `roofline`: at most 24 scalars
+    "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_over_algorithmic",
+    "moved_frac", "valu_busy_frac", "cold_ms_per_step", "cold_value", "hot_ms_per_step", "hot_value",
+    "qp_pair_ms_per_step", "qp_pair_solves_per_s", "qp_pair_moved_frac", "qp_pair_algorithmic_frac",
+    "qp_pair_large_ms_per_step", "qp_pair_large_solves_per_s", "qp_pair_large_moved_frac", "step_moved_frac", "kernel_us"]
+CPU_KEYS = ["value", "unit", "cores", "kind", "sample", "single_thread_value", "python_loop_value"]
+TOP_KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data"]
+
+
+def _clean(v, digits=6, maxlen=160):
+    """A JSON-safe scalar: floats rounded to `digits` significant digits (NaN / inf -> None), strings cut to maxlen."""
+    if isinstance(v, bool) or v is None or isinstance(v, int):
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (digits, v))
+    if isinstance(v, str):
+        return v if len(v) <= maxlen else v[:maxlen - 3] + "..."
+    return _clean(float(v), digits, maxlen) if hasattr(v, "__float__") else str(v)[:maxlen]
+
+
+def contract_line(full, details_path="bench_details.json"):
+    """The ONE line bench.py prints: the contract keys, `config` (workload + <= 20 scalars), `roofline` (<= 24 scalars),
+    `cpu_baseline` (<= 7), nothing nested, at most LINE_LIMIT bytes, strict JSON.  Everything else of the full record --
+    per-kernel brackets, the sub-records of every BASELINE config, the environment -- is in bench_details.json."""
+    cf, rl = full.get("config", {}), dict(full.get("roofline", {}))
+    dom = rl.get("kernel")
+    if dom is not None and "kernel_us_" + str(dom) in rl:
+        rl["kernel_us"] = rl["kernel_us_" + dom]
+    line = {k: (full.get(k) if k in ("value", "ms_per_step") else _clean(full.get(k))) for k in TOP_KEYS}
+    for k in ("value", "ms_per_step"):    # (unrounded: value x ms_per_step = the units of a step, to the last digit)
+        if isinstance(line[k], float) and line[k] != line[k]:
+            line[k] = None
+    conf = {"workload": _clean(cf.get("workload", ""), maxlen=330)}
+    for k in CONFIG_KEYS:
+        if k in cf and not isinstance(cf[k], (dict, list)) and len(conf) < 21:
+            conf[k] = _clean(cf[k], maxlen=120)
+    line["config"] = conf
+    roof = {}
+    for k in ROOFLINE_KEYS:
+        if k in rl and not isinstance(rl[k], (dict, list)) and len(roof) < 24:
+            roof[k] = _clean(rl[k], maxlen=80)
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):   # the contract's keys are always there
+        roof.setdefault(k, None)
+    line["roofline"] = roof
+    if "cpu_baseline" in full:
+        cb = full["cpu_baseline"]
+        line["cpu_baseline"] = {k: _clean(cb[k], maxlen=120) for k in CPU_KEYS if k in cb}
+    line["details"] = details_path
+    text = json.dumps(line, allow_nan=False)
+    while len(text) > LINE_LIMIT and len(conf) > 1:      # (cannot happen with the limits above; never print an oversized line)
+        conf.popitem()
+        text = json.dumps(line, allow_nan=False)
+    return text
+
+
+def emit(full, real_stdout, details_path):
+    """bench_details.json (the full record), a copy of it on stderr (prefixed, so that nothing on stderr looks like the
+    contract line), and the contract line on the real stdout."""
+    def safe(o):
+        if isinstance(o, dict):
+            return {str(k): safe(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [safe(v) for v in o]
+        if isinstance(o, float) and (o != o or o in (float("inf"), float("-inf"))):
+            return None
+        return o
+    blob = json.dumps(safe(full), allow_nan=False)
+    shown = details_path
+    try:
+        with open(details_path, "w") as f:
+            f.write(blob + "\n")
+        if os.path.dirname(os.path.abspath(details_path)) == ROOT:
+            shown = os.path.basename(details_path)
+    except OSError as e:
+        shown = "stderr only (%s)" % type(e).__name__
+    sys.stderr.write("[bench details] " + blob + "\n")
+    sys.stderr.flush()
+    os.write(real_stdout, (contract_line(full, shown) + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -976,13 +1098,17 @@ def main():
                     help="headline only: 2 = the QP chain and the QCQP chain on two HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--no-cold", action="store_true")
-    ap.add_argument("--no-per-config", action="store_true", help="default run only: skip the per_config sub-records")
-    ap.add_argument("--no-live-pmc", action="store_true",
-                    help="do not spawn the two rocprofv3 counter passes that measure roofline.traffic (then quoted from profiles/)")
+    ap.add_argument("--hot-only", "--no-cold", dest="hot_only", action="store_true",
+                    help="one input/output set, the same buffers every step (default: steps rotate over > 768 MiB of sets)")
+    ap.add_argument("--no-hot", action="store_true", help="skip the hot / single-stream context regions")
+    ap.add_argument("--no-per-config", action="store_true", help="default run only: skip the sub-records of bench_details.json")
+    ap.add_argument("--live-pmc", action="store_true",
+                    help="spawn two rocprofv3 counter passes that measure roofline.traffic now (default: quoted from profiles/)")
+    ap.add_argument("--details", default=os.path.join(ROOT, "bench_details.json"), help="where the full record goes")
     ap.add_argument("--pmc-child", type=int, default=None, help=argparse.SUPPRESS)   # the process live_pmc() profiles
     args = ap.parse_args()
     if args.pmc_child is not None:
+        args.hot_only = False
         return pmc_child(args.pmc_child)
 
     # Everything the native libraries print on stdout (RCCL prints its version banner there) goes to
@@ -1021,27 +1147,38 @@ def main():
     _capi.lib()
     ctx = {"rank": rank, "world": world, "dev": dev, "use_dist": use_dist, "dist": dist, "parallel": parallel,
            "capi": _capi, "side": torch.cuda.Stream(),
-           # the counter passes run for a plain one-GPU run of a whole workload (not for sub-records, not under RCCL)
-           "live_pmc": world == 1 and not use_dist and not args.no_live_pmc}
+           # the counter passes run only when asked for, for a plain one-GPU run of a whole workload
+           "live_pmc": world == 1 and not use_dist and args.live_pmc}
 
     default_run = args.config is None
-    # No --config: the headline step, on one GPU and on N (round 4: ONE workload across the driver's N = 1, 2, 4, 8 lines, so
-    # that value(N) / (N value(1)) is a scaling efficiency; the solve needs no collective).  Distributed, the same step is also
+    # No --config: the headline step, on one GPU and on N (ONE workload across the driver's N = 1, 2, 4, 8 lines, so that
+    # value(N) / (N value(1)) is a scaling efficiency; the solve needs no collective).  Distributed, the same step is also
     # timed with the path's optional exchange step (`with_gather`), and configs[3], the batch SPLIT over the ranks with the
     # all-gather of x (strong scaling), is the sub-record `strong_config4`.
     primary = args.config if args.config is not None else 0
     out = measure(primary, args, ctx)
+    if rank == 0:
+        for k in ("with_gather", "without_gather", "gather_after_backward"):
+            if k in out:
+                out["config"][k + "_ms_per_step"], out["config"][k + "_value"] = out[k]["ms_per_step"], out[k]["value"]
+        par = out.get("parity_max_abs_err_vs_oracle_sample", {}).get("qcqp", {})
+        if "refinement_exit_flip_rate" in par:
+            out["config"]["qcqp_grad_exit_flip_rate"] = par["refinement_exit_flip_rate"]
     if default_run:
         if use_dist:
             sub = measure(4, args, ctx, light=True)
             if rank == 0:
-                out["strong_config4"] = condensed(sub)
-                out["strong_config4"]["note"] = "BASELINE configs[3]: B=262144 N=32 split over the ranks, all-gather of x " \
-                                                "behind the forward (strong scaling); N=1 reference: per_config.config_4 of a plain run"
-                out["config"].update(flat_summary("strong_cfg4", out["strong_config4"]))
-                out["config"].update(flat_details("strong_cfg4", out["strong_config4"]))
+                s4 = out["strong_config4"] = condensed(sub)
+                s4["note"] = "BASELINE configs[3]: B=262144 N=32 split over the ranks, all-gather of x behind the forward " \
+                             "(strong scaling); N=1 reference: per_config.config_4 of a plain run"
+                out["config"].update(flat_summary("strong_cfg4", s4))
+                out["config"]["strong_cfg4_value"] = s4["value"]
+                for k in ("without_gather", "gather_after_backward"):
+                    if k in s4:
+                        out["config"]["strong_cfg4_%s_ms_per_step" % k] = s4[k]["ms_per_step"]
+                out["config"].update(flat_details("strong_cfg4", s4))
         elif not args.no_per_config:
-            cfgk, rlk = {}, {}     # scalars for `config` / `roofline`, most important first (the driver keeps ~24 of each)
+            cfgk, rlk = {}, {}     # scalars for `config` / `roofline` of the contract line
             # north_star's target sentence, measured: N = 8 QP forward+backward as ONE step on one stream, at the bench
             # batch and at the batch that fills the chip; fractions on the bytes that move (1538 B per pair)
             pairs = {}
@@ -1076,10 +1213,9 @@ def main():
             cfgk["dense8_auto_ms_per_step"] = d8["auto"]["ms_per_step"]
             if "auto_no_hint_ms_per_fwd_bwd" in d8:
                 cfgk["dense8_auto_no_hint_ms_per_step"] = d8["auto_no_hint_ms_per_fwd_bwd"]
+                cfgk["dense8_auto_no_hint_over_dense"] = d8["auto_no_hint_ms_per_fwd_bwd"] / d8["dense"]["ms_per_step"]
             cfgk["dense8_dense_ms_per_step"] = d8["dense"]["ms_per_step"]
             cfgk["dense8_auto_over_dense"] = d8["auto_over_dense"]
-            if d8["auto"]["roofline"].get("traffic"):
-                cfgk["dense8_auto_traffic_over_algorithmic"] = d8["auto"]["roofline"]["traffic"] / (algo_bytes("qcqp", 8, "fwd") * 65536)
             details.update(flat_details("dense8_auto", d8["auto"]))
             details.update(flat_details("dense8_dense", d8["dense"]))
             out["survey_8d_extras"] = survey_extras_record(args, ctx)
@@ -1092,22 +1228,13 @@ def main():
             out["config"].update(cfgk)
             out["config"].update(details)
             out["roofline"].update(rlk)
-            out["config"] = reordered(out["config"], ["workload", "baseline_config", "B_total", "rccl_world"] + list(cfgk))
-    if rank == 0:
-        # the driver's record keeps the first ~24 scalars of `roofline`: the contract's seven, what binds the dominant
-        # kernel, the cold step, north_star's sentence (qp_pair*), the physical fractions, the four kernel durations
-        out["roofline"] = reordered(out["roofline"], [
-            "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "binding", "fp64_valu_issue_frac",
-            "pmc_valu_lane_utilisation", "cold_ms_per_step", "qp_pair_ms_per_step", "qp_pair_solves_per_s",
-            "qp_pair_moved_frac", "qp_pair_algorithmic_frac", "qp_pair_large_ms_per_step", "qp_pair_large_solves_per_s",
-            "qp_pair_large_moved_frac", "moved_frac", "step_moved_frac", "kernel_us_qp_fwd", "kernel_us_qp_bwd",
-            "kernel_us_qcqp_fwd", "kernel_us_qcqp_bwd", "traffic_over_algorithmic", "single_stream_ms_per_step"])
     if rank == 0:
         out["scaling_note"] = ("`value` = the headline step on every rank (weak scaling, no collective; with_gather = with the "
                                "all-gather of x); configs[3] split over the ranks (strong scaling) = strong_config4 (N>1) / "
                                "per_config.config_4 (plain N=1 run)")
         out["environment"] = gpu_environment()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        out["csrc_sha16"] = csrc_sha16()
+        emit(out, real_stdout, args.details)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -52,6 +52,22 @@ def _sources():
 STAMP = os.path.join(LIBDIR, "build_flags.txt")
 
 
+def source_sha16():
+    """sha256 (16 hex digits) over what decides the library's contents: csrc/*, include/diffqcqp_hip.h, the flags.  A
+    counter summary under profiles/ records it (tools/summarize_prof.py); bench.py quotes counter-derived figures only from
+    a summary of THIS build."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        h.update(f.encode())
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    with open(os.path.join(INCLUDE, "diffqcqp_hip.h"), "rb") as fh:
+        h.update(fh.read())
+    h.update(" ".join(COMMON + [u + " " + " ".join(f) for u, f in sorted(UNITS.items())]).encode())
+    return h.hexdigest()[:16]
+
+
 def _flag_stamp():
     """Everything besides the sources that decides what the library contains (DQQ_EXTRA_FLAGS: developer -D flags)."""
     return " ".join(COMMON) + " | " + os.environ.get("DQQ_EXTRA_FLAGS", "")

@@ -29,18 +29,21 @@ def _torchrun(nproc, port, *cmd, timeout=900):
 
 
 @two_gpus
-def test_bench_line_on_two_ranks():
-    """The driver's own scaling command at N = 2: one JSON line, rccl_world 2, the headline workload on every rank."""
+def test_bench_line_on_two_ranks(tmp_path):
+    """The driver's own scaling command at N = 2: one short JSON line, rccl_world 2, the headline workload on every rank;
+    the gather and strong-scaling figures are scalars of the line, their sub-records are in the details file."""
+    det = str(tmp_path / "details.json")
     r = _torchrun(2, 29611, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--repeats", "2",
-                  "--no-cpu-baseline")
+                  "--no-cpu-baseline", "--details", det)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    assert len(lines) == 1 and len(lines[0].encode()) <= 6000, r.stdout[-2000:]
+    d, full = json.loads(lines[0]), json.load(open(det))
     assert d["n_gpus"] == 2 and d["config"]["rccl_world"] == 2 and d["scaling"] == "weak"
     assert d["config"]["B_total"] == 2 * 131072
-    assert d["with_gather"]["rccl_world"] == 2 and d["with_gather"]["ms_per_step"] > 0
-    assert d["strong_config4"]["without_gather"]["rccl_world"] == 2
+    assert d["config"]["with_gather_ms_per_step"] > 0 and d["config"]["strong_cfg4_ms_per_step"] > 0
+    assert full["with_gather"]["rccl_world"] == 2 and full["with_gather"]["ms_per_step"] > 0
+    assert full["strong_config4"]["without_gather"]["rccl_world"] == 2
     assert d["value"] > 0 and abs(d["value"] - d["config"]["B_total"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
 
 

@@ -15,7 +15,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT $R/gpurun_out/prof_summary
 export TMPDIR=/tmp
 cd /tmp
-COMMON="--no-cpu-baseline --no-cold --no-per-config --streams 1"
+COMMON="--no-cpu-baseline --no-hot --no-per-config --streams 1"
 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python $R/bench.py --steps 20 --warmup 5 --repeats 3 $COMMON "$@" > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES -d $OUT/sq -o sq -- python $R/bench.py --steps 2 --warmup 1 --repeats 1 --no-check $COMMON "$@" > /dev/null 2> $OUT/sq.err
 # second SQ pass (8 slots per pass): VALU lane utilisation and where the wave-cycles go.  SQ_WAVE_CYCLES,

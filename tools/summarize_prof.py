@@ -21,6 +21,9 @@ import sqlite3
 import sys
 
 
+N_SIMD, N_SE = 1024, 32    # MI355X: 256 CUs x 4 SIMDs; 8 XCDs x 4 shader engines
+
+
 def short(name):
     m = re.search(r"dqq::(\w+)<([^>]*)>", name)
     if m:
@@ -77,6 +80,12 @@ def main():
         # instruction was active x 64 lanes)
         if v.get("SQ_ACTIVE_INST_VALU") and "SQ_THREAD_CYCLES_VALU" in v:
             v["valu_lane_utilisation"] = v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64.0)
+        # share of the kernel's cycles in which a SIMD's VALU was executing an instruction -- from counters of ONE pass:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's 1024 SIMDs, SQ_BUSY_CYCLES cycles summed over its 32
+        # shader engines (8 XCDs x 4; checked against the kernels' durations: 2.0 M / 32 = 62.5 k cycles = 26 us at 2.4 GHz for
+        # the 28 us QCQP forward).  A measured share: it cannot exceed 1, whatever the mix of FP64 and other instructions
+        if v.get("SQ_ACTIVE_INST_VALU") and v.get("SQ_BUSY_CYCLES"):
+            v["valu_busy_frac"] = (4.0 * v["SQ_ACTIVE_INST_VALU"] / N_SIMD) / (v["SQ_BUSY_CYCLES"] / N_SE)
         if v.get("SQ_WAVE_CYCLES"):
             for cn in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"):
                 if cn in v:
@@ -98,7 +107,7 @@ def main():
                 e["main_kernel"] = k
                 for extra in ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES",
                               "SQ_INSTS_SALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES",
-                              "valu_lane_utilisation", "SQ_WAIT_INST_ANY_frac", "SQ_WAIT_ANY_frac", "SQ_ACTIVE_INST_ANY_frac",
+                              "valu_lane_utilisation", "valu_busy_frac", "SQ_WAIT_INST_ANY_frac", "SQ_WAIT_ANY_frac", "SQ_ACTIVE_INST_ANY_frac",
                               "SQ_ACTIVE_INST_VALU_frac"):
                     if extra in v:
                         e[extra] = v[extra]
@@ -108,6 +117,12 @@ def main():
         if e.get("SQ_WAVES"):
             e["valu_insts_per_wave"] = e["SQ_INSTS_VALU"] / e["SQ_WAVES"]
     latest["_tag"] = tag
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:   # which build these counters are of (bench.py quotes counter-derived figures only from a summary of its own build)
+        from diffqcqp_amd import build as _b
+        latest["_csrc_sha16"] = _b.source_sha16()
+    except Exception as e:  # noqa: BLE001
+        latest["_csrc_sha16"] = "unknown (%s)" % type(e).__name__
     json.dump(pmc, open(os.path.join(outdir, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
     json.dump(latest, open(os.path.join(outdir, "pmc_latest%s.json" % suffix), "w"), indent=1, sort_keys=True)
     for r in rows[:10]:
