@@ -45,12 +45,6 @@ _pinned = []           # workspaces handed out while a stream capture was going 
 _need_cache = {}       # (kind, pas, N, B, flags) -> bytes: dqq_workspace_bytes + dqq_scratch_bytes are functions of exactly these
 
 
-def feedback_default():
-    """(kept for callers of earlier rounds)  The route hints are on by default and need no registration any more: the report
-    words live in diffqcqp_amd/_capi.py (one per (device, kind, N)), the C library keeps no state."""
-    return None
-
-
 def _hints(kind, pas, N, B, layout, dev):
     """(flags, report address) for this call: the caller's side of include/diffqcqp_hip.h's hint protocol.  Only DQQ_P_AUTO
     batches of QP / QCQP, N <= 8; a caller that already passes hint flags in `layout` keeps them."""

@@ -11,7 +11,7 @@
  * from-scratch dense restatement of qcqplib/Solver.cpp in plain C, following
  * the reference statement by statement; what pins it is listed in
  * oracle/README.md (closed forms, KKT residuals, finite differences, and the
- * author's hard-coded seed-5 inputs).  Third-party arithmetic restated here:
+ * seed-5 inputs the reference left as four-digit constants in comments).  Third-party arithmetic restated here:
  * Eigen3 (version unpinned by the reference's CMake): LLT = unblocked lower
  * Cholesky, solveInPlace(Identity) = forward + backward substitution per
  * column, normalize() = divide by the 2-norm when it is > 0, norm() = sqrt of

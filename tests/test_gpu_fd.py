@@ -111,7 +111,11 @@ def to_dev(d, keys):
 # ------------------------------------------------------------------------------------------------------------------
 def test_seed5_problem_of_the_reference_script():
     """test_script.py:23-43 verbatim (n = 2, torch.manual_seed(5), P = S S^T, q = -rand - 0.1, eps 1e-12, max_iter 1e4,
-    d x[0,1] / dP by central differences at 1e-8); the author's run printed grad_P[1,1] = -16.0827925 against -16.08282."""
+    d x[0,1] / dP by central differences at 1e-8).  The script only PRINTS its analytic and numeric gradients and nothing under
+    /root/reference holds their values: the constant below, grad_P[1,1] = -16.0827925 (central differences: -16.08282), is what
+    SURVEY.md section 4 / Appendix C's throwaway numpy restatement of Solver.cpp computed for these inputs -- a second reading of
+    the source, not an output of the reference binary.  What this test pins by itself is the loop below: the HIP forward's
+    own central differences against the Function's gradients."""
     QPFn2 = fns()["qp"]
     torch.manual_seed(5)
     n = 2
@@ -122,7 +126,7 @@ def test_seed5_problem_of_the_reference_script():
     lf = QPFn2.apply(P, q, ws, 1e-12, 10000)
     lf[0, 1].backward()
     gP, gq = P.grad.clone(), q.grad.clone()
-    assert abs(gP[0, 1, 1].item() - (-16.0827925)) < 2e-3      # (the constant is the reference author's own printout)
+    assert abs(gP[0, 1, 1].item() - (-16.0827925)) < 2e-3      # (SURVEY.md App. C's numpy restatement; NOT a reference output)
     with torch.no_grad():
         Pd, qd = P.detach(), q.detach()
         for i in range(n):

@@ -20,9 +20,10 @@ GENERIC_FIXTURES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
                           if not os.path.basename(p).startswith(("ref_", "rd_")))
 
 
-def test_seed5_inputs_match_authors_constants():
-    """test_script.py:23-29 inputs reproduce the constants the author hard-coded at
-    test_script.py:153-154 and Solver.cpp:783,796 (0.4979/0.3295/0.2432, -0.3661/-0.9514)."""
+def test_seed5_inputs_match_the_constants_in_the_reference_comments():
+    """test_script.py:23-29 inputs reproduce the four-digit constants left in comments at
+    test_script.py:153-154 and Solver.cpp:783,796 (0.4979/0.3295/0.2432, -0.3661/-0.9514) -- INPUTS only: the reference
+    holds no expected solution or gradient for them."""
     d = np.load(os.path.join(GOLDEN, "qp_seed5.npz"))
     P, q = d["P"][0], d["q"][0, :, 0]
     assert np.allclose(P, [[0.4979, 0.3295], [0.3295, 0.2432]], atol=5e-5)
@@ -33,7 +34,9 @@ def test_seed5_inputs_match_authors_constants():
 
 
 def test_seed5_solution_and_fd_gradient(oracle):
-    """The FD check of test_script.py:23-43: analytic dP of x[1] vs central differences."""
+    """The FD check of test_script.py:23-43: analytic dP of x[1] vs central differences.  (The expected x, the 123
+    iterations and grad_P[1,1] = -16.0827925 are SURVEY.md section 4's values, computed by the survey session's separate numpy
+    restatement of Solver.cpp -- two readings of the source agreeing, not a reference output.)"""
     d = np.load(os.path.join(GOLDEN, "qp_seed5.npz"))
     P, q = d["P"][0], d["q"][0, :, 0]
     x, it = oracle.solveQP(P, q, np.zeros(2), 1e-12, 1e-7, 10000, True, return_iters=True)
