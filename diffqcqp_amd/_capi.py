@@ -8,6 +8,7 @@ raises -- there is no CPU or PyTorch fallback behind it.
 """
 import ctypes
 import os
+import threading
 
 # torch ships its own libamdhip64.so; it must be the HIP runtime of the process.  Loading our library
 # first would pull in /opt/rocm's copy and give the two halves of the process different runtimes
@@ -182,9 +183,17 @@ def enable_feedback(on=True):
         _feedback = _words(0)[0]
 
 
+_hint_lock = threading.Lock()
+
+
 def _words(dev_index):
     st = _hint_store.get(dev_index)
-    if st is None:
+    if st is not None:
+        return st
+    with _hint_lock:   # two threads making a device's first backward call: ONE buffer, never a dropped one (its device
+        st = _hint_store.get(dev_index)   # address may already be in a launch's arguments)
+        if st is not None:
+            return st
         buf = torch.zeros(HINT_WORDS, dtype=torch.int64).pin_memory()
         if binding() == "pybind11":
             rc, dev = lib().dqq_device_pointer(buf.data_ptr())

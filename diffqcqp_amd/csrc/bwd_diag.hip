@@ -30,9 +30,25 @@ namespace dqq {
 // zero): it will not be solved by this call -- its gradients say so.  Lane j of the problem's N/2 lanes.
 template <int KIND, int N>
 static DQQ_D void poison_problem_grads(double* __restrict__ grad_P, double* __restrict__ grad_q, double* __restrict__ g0,
-                                       double* __restrict__ g1, long prob, int j)
+                                       double* __restrict__ g1, double* __restrict__ gamma_out,
+                                       double* __restrict__ dgamma_out, int* __restrict__ ir_steps, long prob, int j)
 {
     const double nan = __builtin_nan("");
+    // the optional diagnostics too (they come from torch.empty): NaN duals, -1 refinement steps
+    if (KIND == 1) {
+        if (gamma_out != nullptr) gamma_out[prob * (N / 2) + j] = nan;
+        if (dgamma_out != nullptr) dgamma_out[prob * (N / 2) + j] = nan;
+    } else if (KIND == 2) {
+        for (int c = 0; c < 4; ++c) {   // (B, 2N): this lane's two coordinates of both halves
+            const long o = prob * (2 * N) + (c >> 1) * N + 2 * j + (c & 1);
+            if (gamma_out != nullptr) gamma_out[o] = nan;
+            if (dgamma_out != nullptr) dgamma_out[o] = nan;
+        }
+    }
+    if (ir_steps != nullptr && j == 0) {
+        if (KIND == 2) { ir_steps[2 * prob] = -1; ir_steps[2 * prob + 1] = -1; }
+        else ir_steps[prob] = -1;
+    }
     if (grad_q != nullptr) { grad_q[prob * N + 2 * j] = nan; grad_q[prob * N + 2 * j + 1] = nan; }
     if (grad_P != nullptr)
         for (int c = 0; c < 2 * N; ++c) grad_P[prob * (long)(N * N) + 2 * j * N + c] = nan;   // this lane's two rows
@@ -140,12 +156,12 @@ __global__ __launch_bounds__(64 * WPB, (FUSE ? (KIND == 0 ? 5 : (KIND == 1 ? 4 :
                 const bool ok = worklist_push_entries<AGG, worklist_segmented(N)>(ws, B, __popcll(qm), queued,
                                                                                   __popcll(qm & ((1ull << lane) - 1)), (int)(first + pl), lane, s_cnt);
                 if (lane == 0 && qm != 0) ws[kWsPerProblem] = 1;   // (launch.h: how the drain's report is to be read)
-                if (!ok && valid && f == 2) poison_problem_grads<KIND, N>(grad_P, grad_q, grad_l_n, grad_mu, first + pl, j);
+                if (!ok && valid && f == 2) poison_problem_grads<KIND, N>(grad_P, grad_q, grad_l_n, grad_mu, gamma_out, dgamma_out, ir_steps, first + pl, j);
                 valid = valid && f == 1;
             } else {
                 const bool ok = worklist_push<AGG, worklist_segmented(N)>(ws, B, first, tile_dense ? nvalid : 0, lane, s_cnt);
                 if (tile_dense) {
-                    if (!ok && valid) poison_problem_grads<KIND, N>(grad_P, grad_q, grad_l_n, grad_mu, first + pl, j);
+                    if (!ok && valid) poison_problem_grads<KIND, N>(grad_P, grad_q, grad_l_n, grad_mu, gamma_out, dgamma_out, ir_steps, first + pl, j);
                     return;
                 }
             }

@@ -189,6 +189,7 @@ __global__ __launch_bounds__(64 * WPB) DQQ_FWD_DIAG_OCCUPANCY(KIND, N, LPP, FUSE
                     double* xx = x + first * N + lane * E;
 #pragma unroll
                     for (int e = 0; e < E; ++e) xx[e] = __builtin_nan("");
+                    if (iters != nullptr && (lane % LPP) == 0) iters[first + pl] = -1;   // (it comes from torch.empty)
                 }
                 return;
             }

@@ -378,10 +378,12 @@ __global__ __launch_bounds__(64, 1) void fwd_lane_dense_kernel(const double* __r
 #pragma unroll
                 for (int c = 0; c < N / 2; ++c) {                                 // prox_circle, :505-519
                     const double a = z[2 * c], b = z[2 * c + 1];
-                    const double n2 = a * a + b * b;
+                    const double n2 = __builtin_fma(b, b, a * a);
                     const double rn = fast_rsqrt(n2);
-                    const double nrm = n2 * rn;
-                    if (nrm > rad[c]) {
+                    // |l_(c)| > r tested on the squares, |l|^2 > r |r|, with the SAME expressions as the diagonal / group body
+                    // (admm_diag_body.inc: one prox_circle for every forward that seeds its rsqrt -- ADVICE r5: which kernel
+                    // serves a DQQ_P_DENSE N = 8 batch depends on B, the projection rule must not)
+                    if (n2 > rad[c] * fabs(rad[c])) {
                         const double sc = rad[c] * rn;
                         z[2 * c] = a * sc;
                         z[2 * c + 1] = b * sc;

@@ -211,10 +211,9 @@ __global__ __launch_bounds__(256, N >= 14 ? 1 : 2) void fwd_small_kernel(const d
             } else {                                                              // prox_circle, :505-519
                 const double other = partner<1>(z);
                 const double a = (tl & 1) ? other : z, b = (tl & 1) ? z : other; // both lanes: the same expression
-                const double n2 = a * a + b * b;
+                const double n2 = __builtin_fma(b, b, a * a);
                 const double rn = fast_rsqrt(n2);
-                const double nrm = n2 * rn;
-                if (nrm > rad) z = z * (rad * rn);
+                if (n2 > rad * fabs(rad)) z = z * (rad * rn);   // (on the squares: admm_diag_body.inc, fwd_lane_dense.hip)
             }
             u += rho * (w - z);                                                   // :83 / :543
             const double rd = G::max(actn ? fabs(z - l2) : 0.0);

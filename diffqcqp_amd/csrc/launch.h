@@ -24,6 +24,7 @@ constexpr int kWsTicket = 1;
 constexpr int kWsNext = 2; // work-list mode with dynamic pick-up: next unclaimed entry
 constexpr int kWsRepTop = 8;    // [8..9] bwd_lane_dense.hip, REPORT mode: 64-bit (groups arrived, problems counted); zero between launches
 constexpr int kWsFbShadow = 4;  // [4..7]: what this workspace's drain launches last wrote to the feedback buffer, and where (below)
+constexpr int kWsFbSkips = 10;    // unchanged reports not sent since the last one that was (worklist_feedback)
 constexpr int kWsPerProblem = 11; // bwd_diag.hip: 1 = this list holds single problems of classified mixed tiles (not whole tiles); cleared by the drain
 constexpr int kWsDirty = 12;      // sticky: 1 = a kernel found this header inconsistent (see "work-list hygiene" below); dqq_workspace_status reads it, dqq_workspace_reset clears it
 constexpr int kWsSubTickets = 32;   // first of 32 sub-tickets, kWsSubStride ints apart
@@ -213,7 +214,11 @@ static DQQ_D void worklist_feedback(unsigned long long* fb, int* ws, long B, lon
     if (same_place && ((prev >> 32) & kFbBMask) == bb && 4 * (long)(prev & kFbCountMask) >= 3 * B && 4 * count >= 3 * B)
         streak = (prev >> 62) < 3 ? (prev >> 62) + 1 : 3;
     const unsigned long long v = (streak << 62) | (bb << 32) | (per_problem ? kFbPerProblem : 0ULL) | (unsigned long long)count;
-    if (prev == v && same_place) return;
+    // (the shadow is per WORKSPACE, the word may be shared by several -- diffqcqp_amd/_capi.py keeps one per (device, kind,
+    // N) --: another workspace's launch may have overwritten a word this one believes unchanged.  Every 64th unchanged
+    // report is therefore sent anyway, so that a word can be stale for a bounded number of calls only: ADVICE r5)
+    if (prev == v && same_place && ws[kWsFbSkips] < 63) { ws[kWsFbSkips] += 1; return; }
+    ws[kWsFbSkips] = 0;
     shadow[0] = v;
     shadow[1] = reinterpret_cast<unsigned long long>(fb);
     __hip_atomic_store(fb, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

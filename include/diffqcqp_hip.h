@@ -20,8 +20,11 @@
  *   - return value: 0 on success, <0 for an invalid argument (DQQ_E_*), >0 a
  *     hipError_t from the launch (the launch's own status: the calling thread's
  *     sticky HIP error is neither consumed nor cleared).  Nothing throws.  The library
- *     keeps NO state: a call's results, bit for bit, and the kernels it launches are
- *     a function of its arguments alone (no history, thread-safe, any stream).  What
+ *     keeps no state that a result or a route depends on: a call's results, bit for
+ *     bit, and the kernels it launches are a function of its arguments alone (no
+ *     history, thread-safe, any stream).  The one piece of process state is three
+ *     diagnostic route counters (dqq_get_option: "lane_list_drains",
+ *     "bwd_whole_batches", "fwd_feedback_routes"), bumped on the launch path.  What
  *     adapts to the data -- a steady stream of mostly non-diagonal N <= 8 batches
  *     through DQQ_P_AUTO is faster on other kernels of identical results -- is in the
  *     CALLER's hands: an optional report word the backward fills and hint flags the
@@ -92,13 +95,15 @@ size_t dqq_workspace_bytes(int64_t B);
  * REPAIRED by the next DQQ_P_AUTO call where that is possible (exit tickets and pick-up counters are re-zeroed by the fast
  * kernel; a stale or out-of-range count is clamped; an entry that is not a problem of the batch is replaced by problem 0,
  * which is then solved once more to the same values) and REPORTED where it is not (problems that cannot be queued get NaN
- * outputs): nothing is read or written out of bounds and no problem is silently left unsolved.  Either way a sticky "dirty"
- * word is set in the header.
+ * outputs, -1 in iters / ir_steps): nothing is read or written out of bounds and no problem is silently left unsolved.  A
+ * sticky "dirty" word is set in the header whenever a COUNT or an ENTRY had to be clamped, replaced or dropped; stale exit
+ * tickets and pick-up counters alone (idle words of the drain, re-zeroed before they are used) are repaired silently.
  *   dqq_workspace_reset   zero-fills the header on `stream` (asynchronous): the state a fresh workspace must be in.  The
  *                         recommended way to initialise one (a plain zero-fill of the first dqq_workspace_bytes(0) bytes is
  *                         equivalent).
  *   dqq_workspace_status  *dirty = 1 if any kernel has found the header inconsistent since the last reset.  SYNCHRONISES
- *                         `stream` (a 4-byte read-back): a diagnostic, never on a hot path. */
+ *                         `stream` (a 4-byte read-back): a diagnostic, never on a hot path, and not
+ *                         allowed on a stream that is being captured (the synchronisation fails: a hipError_t is returned). */
 int dqq_workspace_reset(void* workspace, size_t workspace_bytes, void* stream);
 int dqq_workspace_status(const void* workspace, size_t workspace_bytes, void* stream, int* dirty);
 

@@ -15,7 +15,23 @@ if [ ! -f "$REF/qcqplib/Solver.cpp" ]; then
     echo "ref_build: $REF/qcqplib/Solver.cpp not found (no reference checkout on this machine): nothing built"; exit 0
 fi
 INC=""
-for d in "$EIGEN3_INCLUDE_DIR" /usr/include/eigen3 /usr/local/include/eigen3 /opt/conda/include/eigen3; do
+# where Eigen3 headers could be: the usual prefixes, a conda environment, and Python wheels that ship them (cmeel-eigen /
+# eigenpy put them under site-packages/cmeel.prefix/include/eigen3; some wheels under <pkg>/include/eigen3) -- none exist
+# in this image today; the day one does, the first build() / pytest run pins the oracle without an edit
+PYDIRS=$(python3 - <<'PY' 2>/dev/null
+import glob, os, sys
+seen = []
+for p in sys.path:
+    if p and os.path.isdir(p):
+        for pat in ("cmeel.prefix/include/eigen3", "*/include/eigen3", "*/*/include/eigen3", "*/include"):
+            for d in glob.glob(os.path.join(p, pat)):
+                if os.path.isfile(os.path.join(d, "Eigen", "Dense")) and d not in seen:
+                    seen.append(d)
+print(" ".join(seen))
+PY
+)
+for d in "$EIGEN3_INCLUDE_DIR" /usr/include/eigen3 /usr/local/include/eigen3 /opt/conda/include/eigen3 \
+         "${CONDA_PREFIX:+$CONDA_PREFIX/include/eigen3}" /usr/include /usr/local/include $PYDIRS; do
     if [ -n "$d" ] && [ -f "$d/Eigen/Dense" ]; then INC=$d; break; fi
 done
 if [ -z "$INC" ]; then

@@ -32,14 +32,15 @@ def _inputs(kind, B, N, seed):
 
 
 def _run(ops, kind, g, ws, x=None):
-    """forward (x is None) or backward through DQQ_P_AUTO on the caller's workspace -> list of output tensors"""
+    """forward (x is None) or backward through DQQ_P_AUTO on the caller's workspace -> list of output tensors
+    (the optional diagnostics with them: iteration counts / refinement steps -- int tensors, -1 on a problem that was not solved)"""
     if x is None:
         if kind == "qp":
-            return [ops.qp_forward(g["P"], g["q"], 1e-7, 1000, workspace=ws)]
-        return [ops.qcqp_forward(g["P"], g["q"], g["l_n"], g["mu"], 1e-7, 1000, workspace=ws)]
+            return list(ops.qp_forward(g["P"], g["q"], 1e-7, 1000, workspace=ws, return_iters=True))
+        return list(ops.qcqp_forward(g["P"], g["q"], g["l_n"], g["mu"], 1e-7, 1000, workspace=ws, return_iters=True))
     if kind == "qp":
-        return list(ops.qp_backward(g["P"], g["q"], x, g["grad_x"], workspace=ws))
-    return list(ops.qcqp_backward(g["P"], g["q"], g["l_n"], g["mu"], x, g["grad_x"], workspace=ws))
+        return list(ops.qp_backward(g["P"], g["q"], x, g["grad_x"], workspace=ws, return_steps=True))
+    return list(ops.qcqp_backward(g["P"], g["q"], g["l_n"], g["mu"], x, g["grad_x"], workspace=ws, return_steps=True))
 
 
 def _header_is_idle(ws):
@@ -108,10 +109,17 @@ def test_a_poisoned_header_is_repaired_or_reported(ops, kind, N, B, pas, poison)
     dirty = _capi.workspace_status(ws)
     assert dirty or not must_be_dirty, "an inconsistent header went unnoticed"
     unsolved = torch.zeros(B, dtype=torch.bool, device=x.device)
+    ints_flagged = torch.zeros(B, dtype=torch.bool, device=x.device)
     for o, r in zip(out, ref):
         if o is None:
             continue
         o2, r2 = o.reshape(B, -1), r.reshape(B, -1)
+        if not o.is_floating_point():     # iteration counts / refinement steps: the clean call's, or the sentinel -1
+            flagged = (o2 == -1).any(dim=1)
+            assert bool(((o2 == r2).all(dim=1) | flagged).float().mean() > 0.99), (poison, "a diagnostic is neither the clean call's nor -1")
+            assert bool((o2[~flagged] > 0).all()), (poison, "garbage in a diagnostic of a solved problem")
+            ints_flagged = flagged
+            continue
         nan = torch.isnan(o2).any(dim=1)
         unsolved |= nan
         # every problem: the clean call's answer (to rounding: a problem queued once more is solved by the general kernel),
@@ -121,6 +129,8 @@ def test_a_poisoned_header_is_repaired_or_reported(ops, kind, N, B, pas, poison)
         assert bool((torch.isnan(o2) | (o2 == r2))[~nan].float().mean() > 0.99)   # and bit-identical on (nearly) all of them
     if not dirty:
         assert not bool(unsolved.any()), "NaN outputs without the dirty word"
+    #  the diagnostics of a problem reported as failed are sentinels, never what torch.empty left there
+    assert bool((ints_flagged == unsolved).all()), (poison, "sentinel -1 exactly on the problems whose outputs are NaN")
     assert bool((~unsolved).float().mean() > 0.5)      # the diagonal tiles never depend on the list
     # every word of the protocol is sane again (the drain re-zeroed it, or the fast kernel / the clamp repaired it): the next
     # call on the SAME workspace, without a reset, is clean.  (Words outside the protocol keep what the poison wrote.)
