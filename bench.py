@@ -123,7 +123,7 @@ class Chain:
         self.ws = {}
         self.calls = {}
         self.ops, self.capi = ops, _capi
-        self.handoff = structure == "diag" and layout == 0
+        self.handoff = structure == "diag" and (layout & 0xff) == 0
         self.kidx = 0 if kind == "qp" else 1
         self.hinted = layout == 0 and N <= 8
 
@@ -173,7 +173,7 @@ class Chain:
         lay = self.layout | flags
         # the verified-diagonal hand-off exists for DQQ_P_AUTO only (diffqcqp_amd/qcqp.py: _cache_for): a batch declared
         # dense passes no pdiag / flags (with them the C ABI would clear the flags with a memset launch per forward)
-        pd, fl = (p(t["pdiag"]), p(t["flags"])) if self.layout == 0 else (None, None)
+        pd, fl = (p(t["pdiag"]), p(t["flags"])) if (self.layout & 0xff) == 0 else (None, None)
         if which == 0 and self.kind == "qp":
             return L.dqq_qp_fwd_f64, (p(t["P"]), p(t["q"]), p(t["x"]), B, N, EPS, MU_PROX, MAX_ITER, 1, lay, None,
                                       pd, fl, p(ws), wsb, stream)
@@ -267,6 +267,9 @@ WORKLOADS = {
         [("qcqp", 8, "dense", True, 0)], 65536, "weak", 16384),
     7: ("dense-P B=65536 N=8 QCQP forward+backward, P declared dense (DQQ_P_DENSE)",
         [("qcqp", 8, "dense", True, 1)], 65536, "weak", 16384),
+    11: ("dense-P B=65536 N=8 QCQP forward+backward through DQQ_P_AUTO | DQQ_F_EXPECT_DENSE given EXPLICITLY by the caller (no "
+         "report word): what a first call or a captured graph runs when the caller says what it expects",
+         [("qcqp", 8, "dense", True, 0x200)], 65536, "weak", 16384),
     # north_star's target sentence as ONE timed step: N = 8 QP forward+backward on one stream
     8: ("qp_pair: B=65536 N=8 diagonal-P (dense (B,8,8) layout) QP forward+backward on one stream [BASELINE configs[1] + its "
         "backward]", [("qp", 8, "diag", True)], 65536, "weak", 16384),
@@ -418,7 +421,7 @@ def measure(cfg, args, ctx, light=False):
     if cfg == 4 and args.steps == 100:
         steps = 20
     if light:
-        steps, repeats, warmup = {2: 50, 3: 50, 4: 10, 5: 3, 0: 50, 6: 10, 7: 10, 8: 50, 9: 10, 10: 30}[cfg], 3, 3
+        steps, repeats, warmup = {2: 50, 3: 50, 4: 10, 5: 3, 0: 50, 6: 10, 7: 10, 8: 50, 9: 10, 10: 30, 11: 10}[cfg], 3, 3
 
     chains = [Chain(f[0], B_rank, f[1], f[2], f[3], dev, 1000 + 17 * (0 if cfg >= 8 else min(cfg, 6)) + 7919 * rank + 31 * i,
                     layout=(f[4] if len(f) > 4 else 0)) for i, f in enumerate(families)]
@@ -682,7 +685,7 @@ def measure(cfg, args, ctx, light=False):
     # profiles/pmc_latest*.json), with its provenance; `pmc_matches_build` says whether that summary was taken on THIS
     # build (the sha of csrc/ it records); the counter-derived VALU figures are dropped when it was not.  --live-pmc: two
     # rocprofv3 passes spawned by this run over its own launches measure the traffic now
-    tag = {0: "", 2: "_cfg2", 3: "_cfg3", 4: "_cfg4", 5: "_cfg5", 6: "_cfg6", 7: "_cfg7", 8: "_cfg2", 9: None, 10: None}[cfg]
+    tag = {0: "", 2: "_cfg2", 3: "_cfg3", 4: "_cfg4", 5: "_cfg5", 6: "_cfg6", 7: "_cfg7", 8: "_cfg2", 9: None, 10: None, 11: None}[cfg]
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest%s.json" % tag) if tag is not None else None
     if pmc_path and os.path.exists(pmc_path):
         try:
@@ -765,6 +768,7 @@ def measure(cfg, args, ctx, light=False):
                        ("one set of %.0f MB" % (per_set / 1e6) + (" (larger than the cache)" if per_set >= 768 * 2**20 else
                                                                    ", the same buffers every step (cache-resident)")),
             "p_layout": ("dense (declared)" if chains[0].layout == 1 else
+                         "auto + DQQ_F_EXPECT_DENSE given by the caller (verified in-kernel all the same)" if chains[0].layout == 0x200 else
                          "auto (off-diagonals verified in-kernel; non-diagonal tiles go to the general kernel)"),
             "launch": "eager, one C-ABI call per pass" + (", the two families on two streams" if side is not None else ""),
             "sharding": (("batch split over the ranks" if scaling == "strong" else "every rank its own batch (weak scaling)") +
@@ -910,6 +914,9 @@ def dense_p_record(args, ctx):
         capi.enable_feedback(False)
         try:
             rec["auto_no_hint_ms_per_fwd_bwd"] = measure(6, args, ctx, light=True)["ms_per_step"]
+            # ... and what the same caller gets, still without a report word (first call, captured graph), by SAYING what it
+            # expects: DQQ_P_AUTO | DQQ_F_EXPECT_DENSE as an argument (diffqcqp_amd.qcqp.set_default_layout("auto_expect_dense"))
+            rec["auto_explicit_flag_ms_per_fwd_bwd"] = measure(11, args, ctx, light=True)["ms_per_step"]
         finally:
             capi.enable_feedback(True)   # (the words as they were)
     return rec
@@ -996,7 +1003,7 @@ CONFIG_KEYS = [        # `config`: workload + at most 20 scalars
     "baseline_config", "B_total", "rccl_world", "buffers",
     "cfg2_ms_per_step", "cfg2_moved_frac", "cfg3_ms_per_step", "cfg3_moved_frac", "cfg4_ms_per_step", "cfg4_moved_frac",
     "cfg5_ms_per_step", "cfg5_fp64_frac", "dense8_auto_ms_per_step", "dense8_auto_no_hint_ms_per_step",
-    "dense8_dense_ms_per_step", "dense8_auto_no_hint_over_dense", "stress_p_u01_qp_fwd_ms", "ref_figure_qp_fwd_ms",
+    "dense8_auto_explicit_flag_ms_per_step", "dense8_dense_ms_per_step", "dense8_auto_no_hint_over_dense", "ref_figure_qp_fwd_ms",
     "ref_figure_qcqp_fwd_ms", "qcqp_grad_exit_flip_rate",
     # distributed runs (the sub-records above are measured by plain one-GPU runs only)
     "with_gather_ms_per_step", "with_gather_value", "strong_cfg4_ms_per_step", "strong_cfg4_value",
@@ -1089,7 +1096,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, default=None, choices=(0, 2, 3, 4, 5, 6, 7, 8, 9, 10),
+    ap.add_argument("--config", type=int, default=None, choices=(0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11),
                     help="BASELINE.json configs entry (1-based); 0 = the headline step (configs 2'+3).  Default: the "
                          "headline (distributed: on every rank, weak scaling; with_gather = with the RCCL all-gather of x) and "
                          "configs[3] (the batch split over the ranks) as the sub-record strong_config4")
@@ -1214,6 +1221,8 @@ def main():
             if "auto_no_hint_ms_per_fwd_bwd" in d8:
                 cfgk["dense8_auto_no_hint_ms_per_step"] = d8["auto_no_hint_ms_per_fwd_bwd"]
                 cfgk["dense8_auto_no_hint_over_dense"] = d8["auto_no_hint_ms_per_fwd_bwd"] / d8["dense"]["ms_per_step"]
+            if "auto_explicit_flag_ms_per_fwd_bwd" in d8:
+                cfgk["dense8_auto_explicit_flag_ms_per_step"] = d8["auto_explicit_flag_ms_per_fwd_bwd"]
             cfgk["dense8_dense_ms_per_step"] = d8["dense"]["ms_per_step"]
             cfgk["dense8_auto_over_dense"] = d8["auto_over_dense"]
             details.update(flat_details("dense8_auto", d8["auto"]))

@@ -34,12 +34,16 @@ _FAST_N = (2, 4, 8, 16, 32, 64)
 # off-diagonals are verified in-kernel, diagonal tiles take the fast path, the others the general kernels -- nothing is
 # assumed.  "dense": straight to the general kernels, for callers who know their P is dense (a Delassus matrix): saves
 # the verifying pass.  A module-level default because the reference's signatures (qcqp.py:24, 144) have no slot for it.
-_LAYOUTS = {"auto": ops._capi.P_AUTO, "dense": ops._capi.P_DENSE}
+# "auto_expect_dense": "auto" with the hint flag DQQ_F_EXPECT_DENSE given by the CALLER instead of derived from a report word --
+# still verified in-kernel, bit-identical results on any input (a wrong expectation costs time only), but an ARGUMENT: it
+# holds on a first call and inside a captured HIP graph, where the report word's hints do not.
+_LAYOUTS = {"auto": ops._capi.P_AUTO, "dense": ops._capi.P_DENSE,
+            "auto_expect_dense": ops._capi.P_AUTO | ops._capi.F_EXPECT_DENSE}
 _default_layout = ops._capi.P_AUTO
 
 
 def set_default_layout(layout):
-    """layout: "auto" or "dense".  Returns the previous setting (as a string)."""
+    """layout: "auto", "dense" or "auto_expect_dense".  Returns the previous setting (as a string)."""
     global _default_layout
     prev = [k for k, v in _LAYOUTS.items() if v == _default_layout][0]
     if layout not in _LAYOUTS:
@@ -55,7 +59,7 @@ def get_default_layout():
 def _cache_for(ctx, qd, n_inputs):
     """Buffers for the verified diagonal of P (forward -> backward of the same problems), only when a backward
     can follow (some input requires grad) and the diagonal fast path exists for this N."""
-    if _default_layout == ops._capi.P_AUTO and qd.shape[1] in _FAST_N and any(ctx.needs_input_grad[:n_inputs]):
+    if (_default_layout & 0xff) == ops._capi.P_AUTO and qd.shape[1] in _FAST_N and any(ctx.needs_input_grad[:n_inputs]):
         return ops.diag_cache(qd)
     return None
 

@@ -125,6 +125,57 @@ def test_a_captured_call_ignores_the_feedback_word(ops, kind):
         _capi.enable_feedback(was_on)
 
 
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+def test_a_graph_captured_with_explicit_hint_flags_replays_the_same_bits_on_any_data(ops, kind):
+    """VERDICT r5 #3 (ii).  A captured graph gets no hints from the report word -- but a caller who KNOWS what the graph will
+    be replayed on may say so: `layout = P_AUTO | F_EXPECT_DENSE` is an argument, and arguments are captured.  The flag
+    selects routes of identical results: the graph captured on dense data replays the un-flagged eager call's bits on dense
+    data AND on diagonal data put into the captured buffers afterwards (there the flag only costs time)."""
+    from diffqcqp_amd import _capi
+    N, B = 8, 57344 + 1024
+    dd, dg = make_problem(kind, B, N, 8400, "dense"), make_problem(kind, B, N, 8401, "diag")
+    keys = [k for k in ("P", "q", "grad_x", "l_n", "mu") if k in dd]
+    t = {k: dd[k].cuda().clone() for k in keys}
+    e = lambda *shape: torch.empty(*shape, device="cuda", dtype=torch.float64)
+    t.update(x=e(B, N, 1), gP=e(B, N, N), gq=e(B, N, 1), gl=e(B, N // 2, 1), gm=e(B, N // 2, 1))
+    outs = ("x", "gP", "gq") + (("gl", "gm") if kind == "qcqp" else ())
+    flagged = _capi.P_AUTO | _capi.F_EXPECT_DENSE
+    was_on = _capi._feedback is not None
+    _capi.enable_feedback(False)                    # nothing below comes from a report word
+    try:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            _run(ops, kind, t, 0)                   # the argument-determined routes, eager: the reference bits (dense data)
+        torch.cuda.synchronize()
+        eager_dense = {k: t[k].clone() for k in outs}
+        for name in ("fwd_feedback_routes", "bwd_whole_batches", "lane_list_drains"):
+            knob(name, 0)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            _run(ops, kind, t, flagged)
+        # the capture holds the hinted routes: one lane per problem forward, whole-batch lane-per-problem backward
+        assert _capi.get_option("fwd_feedback_routes") == 1 and _capi.get_option("bwd_whole_batches") == 1
+        for k in outs:
+            t[k].zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        for k in outs:
+            assert torch.equal(t[k], eager_dense[k]), "flagged graph differs from the un-flagged eager call on dense data (%s)" % k
+        for k in keys:                              # diagonal data in the captured buffers: the flag is wrong now
+            t[k].copy_(dg[k].cuda())
+        graph.replay()
+        torch.cuda.synchronize()
+        replayed = {k: t[k].clone() for k in outs}
+        with torch.cuda.stream(s):
+            _run(ops, kind, t, 0)
+        torch.cuda.synchronize()
+        for k in outs:
+            assert torch.equal(t[k], replayed[k]), "flagged graph differs from the un-flagged eager call on diagonal data (%s)" % k
+    finally:
+        _capi.enable_feedback(was_on)
+
+
 def test_output_buffers_of_the_wrong_type_are_refused(ops):
     d = make_problem("qp", 16, 8, 8500)
     P, q = d["P"].cuda(), d["q"].cuda()
@@ -256,7 +307,7 @@ def test_functions_take_the_layout_from_the_module_default(oracle, ops):
     ws = torch.zeros(512, 8, 1, device="cuda", dtype=torch.float64)
     res = {}
     assert qcqp.get_default_layout() == "auto"
-    for lay in ("auto", "dense"):
+    for lay in ("auto", "dense", "auto_expect_dense"):
         prev = qcqp.set_default_layout(lay)
         try:
             a = [t.clone().requires_grad_(True) for t in args]
@@ -268,6 +319,8 @@ def test_functions_take_the_layout_from_the_module_default(oracle, ops):
     assert qcqp.get_default_layout() == "auto"
     for u, v in zip(res["auto"], res["dense"]):
         assert torch.allclose(u, v, rtol=1e-9, atol=1e-12)
+    for u, v in zip(res["auto"], res["auto_expect_dense"]):     # the caller's explicit hint flag: routes of identical results
+        assert torch.equal(u, v)
     xo, _ = oracle.qcqp_fwd_batch(d["P"].numpy(), d["q"].numpy(), d["l_n"].numpy(), d["mu"].numpy(), 1e-7, 1000, nthreads=8)
     assert np.abs(res["dense"][0].cpu().numpy() - xo).max() <= 1e-6
     with pytest.raises(ValueError):

@@ -911,9 +911,12 @@ WS_HEADER_INTS = 32 + 2 * 32 * 32
 
 def header_is_clean(ws):
     """Count, exit tickets, pick-up index, segment counters: zero after every launch.  Ints 4..7 (kWsFbShadow) are not part
-    of the list: the last word this workspace's drain launches sent to the report word (dqq_hint_flags), and where."""
+    of the list: the last word this workspace's drain launches sent to the report word (dqq_hint_flags), and where; int 10
+    (kWsFbSkips) counts the unchanged reports not sent since (at most 63)."""
     h = ws[:WS_HEADER_INTS].clone()
+    assert 0 <= int(h[10]) <= 63
     h[4:8] = 0
+    h[10] = 0
     return int(h.abs().sum()) == 0
 
 
