@@ -207,6 +207,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, NT == 4 ?
                 inv_rho = 1.0 / rho;
             }
             it_done = it + 1;
+#if defined(DQQ_SALU_PROBE)
+            // measurement only (tools/ab_salu_probe.sh): DQQ_SALU_PROBE extra scalar instructions per ADMM
+            // iteration.  Result (profiles/r07_ab_salu_probe.txt): +32 per iteration = +5.2 % of the kernel, +64 = +12.6 % --
+            // the scalar stream is NOT hidden behind the other wave's vector work at two waves per SIMD; a scalar
+            // instruction costs this kernel about what a vector one does.  Of the ~49 an iteration executes, 15 are
+            // hazard nops on the true dependencies of the residual reduction and ~22 the rho schedule's wave-uniform
+            // control flow (dearer as vector code); splitting the loop into factorisation epochs removed 4: 3655 vs
+            // 3660 us, no measurable change, not kept.
+#pragma unroll
+            for (int sp = 0; sp < DQQ_SALU_PROBE; ++sp) { int sd; asm volatile("s_mov_b32 %0, 0" : "=s"(sd)); }
+#endif
             const double l = W.matvec((u + qp) - rho * l2, xsrc);        // :80 / :539 (W.G holds MINUS the inverse)
             qp = qi - mu * l;                                            // :81 / :540
             double z = kAlpha * l + (1 - kAlpha) * l2 + u * inv_rho;     // :82 / :541 (inv_rho = 1/rho)

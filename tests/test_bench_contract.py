@@ -141,6 +141,27 @@ def test_emit_writes_the_details_file_and_keeps_stderr_unlike_a_contract_line(tm
     assert err.startswith("[bench details] ") and not any(l.startswith("{") for l in err.splitlines())
 
 
+def test_inputs_follow_the_surveys_recipe():
+    """float64 inputs generated on the CPU with torch.Generator().manual_seed(1000 + cfg), then copied to the
+    device -- cfg 2: p ~ U(0.1, 1.1) -> diag_embed, q ~ U(-1, 1); cfg 3: + l_n, mu ~ U(0, 1), grad_l ~ N(0, 1)."""
+    import torch
+    b = _bench()
+    assert [b.workload_seed(0, 0), b.workload_seed(0, 1)] == [1002, 1003]
+    assert [b.workload_seed(c, 0) for c in (2, 3, 4, 5, 8, 9, 10)] == [1002, 1003, 1004, 1005, 1002, 1002, 1004]
+    c = b.Chain("qcqp", 16, 8, "diag", True, torch.device("cpu"), b.workload_seed(3, 0))
+    g = torch.Generator().manual_seed(1003)
+    r = lambda *s: torch.rand(*s, generator=g, dtype=torch.float64)
+    t = c.sets[0]
+    assert torch.equal(t["P"], torch.diag_embed(r(16, 8) + 0.1)) and torch.equal(t["q"], 2 * r(16, 8, 1) - 1)
+    assert torch.equal(t["l_n"], r(16, 4, 1)) and torch.equal(t["mu"], r(16, 4, 1))
+    assert torch.equal(t["g"], torch.randn(16, 8, 1, generator=g, dtype=torch.float64))
+    c.add_sets(2)                       # rotating buffers: distinct data
+    assert len(c.sets) == 3 and not torch.equal(c.sets[1]["q"], t["q"]) and not torch.equal(c.sets[2]["q"], c.sets[1]["q"])
+    d = b.Chain("qp", 4, 64, "dense", False, torch.device("cpu"), b.workload_seed(5, 0)).sets[0]["P"]
+    S = torch.rand(4, 64, 64, generator=torch.Generator().manual_seed(1005), dtype=torch.float64)
+    assert torch.allclose(d, torch.bmm(S, S.transpose(1, 2)) / 64 + 0.1 * torch.eye(64, dtype=torch.float64), rtol=0, atol=1e-14)
+
+
 def test_bench_refuses_to_run_without_a_gpu_and_never_falls_back():
     """There is no CPU path: on a box without a GPU the bench must stop with a message, not print a number."""
     import torch
