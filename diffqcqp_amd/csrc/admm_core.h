@@ -89,12 +89,19 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
     // reductions are symmetric) and keeps its state in place under the execution mask -- as a wave-uniform loop
     // around a `done` flag the same code carried a dozen register copies per iteration.
     int rho_up = 0, cpt = 0, iters = 0;
-    if (valid) {
-        for (int it = 0; it < max_iter; ++it) {
+    {   // (the lean body: see admm_diag_resume)
+        const bool adaptive_on = adaptive != 0;
+        int badi = bad ? 1 : 0;
+        if (valid) {
+            for (int it = 0; it < max_iter; ++it) {
+#define DQQ_ADMM_LEAN 1
 #define DQQ_ADMM_ON_STOP break
 #include "admm_diag_body.inc"
 #undef DQQ_ADMM_ON_STOP
+#undef DQQ_ADMM_LEAN
+            }
         }
+        bad = badi != 0;
     }
     bad = G::max(bad ? 1.0 : 0.0) > 0.0;
 #pragma unroll
@@ -122,17 +129,27 @@ DQQ_D void admm_diag_resume(double (&M)[E], double (&Minv)[E], const double (&q)
     more = false;
     it_next = it0;
     double itau_inc = fast_rcp(tau_inc), itau_dec = fast_rcp(tau_dec);   // (state of the body; a function of the taus)
-    if (valid) {
-        for (int it = it0; it < max_iter; ++it) {
+    // per-lane loop (a lane leaves it when its problem stops), with the lean body: `bad` as an int in a VGPR (a bool live
+    // across the divergent exits costs three scalar instructions at every join), `adaptive` folded into `fire`, the QCQP's
+    // second stopping test behind a wave-uniform branch
+    {
+        const bool adaptive_on = adaptive != 0;
+        int badi = bad ? 1 : 0;
+        if (valid) {
+            for (int it = it0; it < max_iter; ++it) {
+#define DQQ_ADMM_LEAN 1
 #define DQQ_ADMM_ON_STOP break
 #include "admm_diag_body.inc"
 #undef DQQ_ADMM_ON_STOP
-            if (lanes_at > 0 && __popcll(__ballot(true)) <= lanes_at) {
-                more = it + 1 < max_iter;
-                it_next = it + 1;
-                break;
+#undef DQQ_ADMM_LEAN
+                if (lanes_at > 0 && __popcll(__ballot(true)) <= lanes_at) {
+                    more = it + 1 < max_iter;
+                    it_next = it + 1;
+                    break;
+                }
             }
         }
+        bad = badi != 0;
     }
 }
 
@@ -163,18 +180,25 @@ DQQ_D int admm_fwd_diag_respread(const double (&p)[4], const double (&q)[4], con
     int rho_up = 0, cpt = 0, iters = 0, it_next = 0;
     bool more = false;
     const int lanes_at = 2 * respread_at;
-    if (valid) {
-        for (int it = 0; it < max_iter; ++it) {
+    {   // (per-lane loop with the lean body: see admm_diag_resume)
+        const bool adaptive_on = adaptive != 0;
+        int badi = bad ? 1 : 0;
+        if (valid) {
+            for (int it = 0; it < max_iter; ++it) {
+#define DQQ_ADMM_LEAN 1
 #define DQQ_ADMM_ON_STOP break
 #include "admm_diag_body.inc"
 #undef DQQ_ADMM_ON_STOP
-            // lanes still in this loop = the execution mask
-            if (__popcll(__ballot(true)) <= lanes_at) {
-                more = it + 1 < max_iter;
-                it_next = it + 1;
-                break;
+#undef DQQ_ADMM_LEAN
+                // lanes still in this loop = the execution mask
+                if (__popcll(__ballot(true)) <= lanes_at) {
+                    more = it + 1 < max_iter;
+                    it_next = it + 1;
+                    break;
+                }
             }
         }
+        bad = badi != 0;
     }
     moved = more;
     const unsigned long long mm = __ballot(more);
