@@ -71,6 +71,11 @@ static DQQ_D unsigned long long stream_tile_diag_pmask8(const double* __restrict
 {
     constexpr int N = 8;
     static_assert(NCH <= 32, "at most 64 problems per tile");
+    // (Round 6 tried the lane-constant form of this loop -- for N = 8 a chunk is two whole matrices, so WHICH of a lane's two
+    // doubles is a diagonal entry and where it goes in sd does not depend on the chunk: one execution-mask region per group
+    // instead of two per chunk, ~165 instead of ~435 instructions per tile.  The forwards read 0.35 us SLOWER, A/B on one box
+    // (profiles/r07_ab_lean_stream_rejected.txt): this phase waits on HBM, its instructions are hidden, and the leaner
+    // form waits for all sixteen loads before it looks at the first.)
     // every chunk's verdict is kept (NCH <= 16 registers, live only here, next to the 2 * U of the loads in flight) and only
     // OR-ed on the path a diagonal tile takes; the ballots that turn them into a per-problem mask run for a tile that HAS a
     // non-zero off-diagonal.  (With a ballot per chunk on every tile the headline's forwards read 1-1.5 % slower, A/B.)
