@@ -1,5 +1,5 @@
 import sys, numpy as np, torch
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import os; R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,R); sys.path.insert(0,os.path.join(R,"tests"))
 from diffqcqp_amd import ops
 from oracle import oracle as O
 B,N=65536,64
