@@ -132,7 +132,26 @@ DQQ_D void admm_diag_resume(double (&M)[E], double (&Minv)[E], const double (&q)
     // per-lane loop (a lane leaves it when its problem stops), with the lean body: `bad` as an int in a VGPR (a bool live
     // across the divergent exits costs three scalar instructions at every join), `adaptive` folded into `fire`, the QCQP's
     // second stopping test behind a wave-uniform branch
-    {
+    if constexpr (E == 1) {
+        // The last survivors of a tile, one coordinate per lane: by now most waves of the launch have retired and this one
+        // is (nearly) alone on its SIMD -- what an iteration costs it is the length of its dependent chain, not its
+        // instruction count, and the plain body schedules better there: the scalar mask bookkeeping of its exits sits in the
+        // hazard slots of the residual reductions, and the reference's figure workload (one problem at 25 000 iterations)
+        // reads 4.2-4.6 ms with it against 5.2-5.7 with the lean body (A/B on one box, three alternations, with the interleaved
+        // residual reductions in both: profiles/r07_ab_tail_body.txt).
+        if (valid) {
+            for (int it = it0; it < max_iter; ++it) {
+#define DQQ_ADMM_ON_STOP break
+#include "admm_diag_body.inc"
+#undef DQQ_ADMM_ON_STOP
+                if (lanes_at > 0 && __popcll(__ballot(true)) <= lanes_at) {
+                    more = it + 1 < max_iter;
+                    it_next = it + 1;
+                    break;
+                }
+            }
+        }
+    } else {
         const bool adaptive_on = adaptive != 0;
         int badi = bad ? 1 : 0;
         if (valid) {

@@ -167,6 +167,7 @@ struct HostGroup {
     static constexpr int kLanes = 1;
     static DQQ_HD double sum(double v) { return v; }
     static DQQ_HD double max(double v) { return v; }
+    static DQQ_HD void max2(double&, double&) {}
     static DQQ_HD bool wave_all(bool b) { return b; }
     // x^0.4 and x^0.15 (rho and tau of Solver.cpp:72-73)
     static DQQ_HD void pow_pair(double x, double& p40, double& p15) { p40 = pow(x, .4); p15 = pow(x, .15); }
@@ -251,6 +252,18 @@ struct LaneGroup {
         if constexpr (LPP >= 32) v = max_raw(v, partner<16>(v));
         if constexpr (LPP >= 64) v = max_raw(v, partner<32>(v));
         return v;
+    }
+    // two maxima at once, level by level: the two butterflies are independent chains (DPP move -> hazard slot -> v_max per
+    // level) and a wave that is alone on its SIMD -- the last survivors of a launch -- pays every dependent step in full;
+    // written one after the other the compiler also scheduled them one after the other.  Same bits as max() twice.
+    static DQQ_D void max2(double& a, double& b)
+    {
+        if constexpr (LPP >= 2) { const double pa = partner<1>(a), pb = partner<1>(b); a = max_raw(a, pa); b = max_raw(b, pb); }
+        if constexpr (LPP >= 4) { const double pa = partner<2>(a), pb = partner<2>(b); a = max_raw(a, pa); b = max_raw(b, pb); }
+        if constexpr (LPP >= 8) { const double pa = partner<4>(a), pb = partner<4>(b); a = max_raw(a, pa); b = max_raw(b, pb); }
+        if constexpr (LPP >= 16) { const double pa = partner<8>(a), pb = partner<8>(b); a = max_raw(a, pa); b = max_raw(b, pb); }
+        if constexpr (LPP >= 32) { const double pa = partner<16>(a), pb = partner<16>(b); a = max_raw(a, pa); b = max_raw(b, pb); }
+        if constexpr (LPP >= 64) { const double pa = partner<32>(a), pb = partner<32>(b); a = max_raw(a, pa); b = max_raw(b, pb); }
     }
     static DQQ_D bool wave_all(bool b) { return __all(b); }
 };

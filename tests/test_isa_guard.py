@@ -5,7 +5,7 @@ coordinates per lane, non-diagonal problems solved inside the kernel) and `bwd_d
   * at most 128 VGPRs (4 waves per SIMD; `amdgpu_waves_per_eu(4, 8)` in fwd_diag.hip -- with (8, 8) the diagonal loops spill);
   * the spills the forward does have (the in-kernel general solve needs more than 128 registers) lie OUTSIDE the diagonal
     ADMM region -- the region every tile executes; NOTES.md records the time they slipped into it: headline step 56 -> 69 us;
-  * the steady-state ADMM loop is 80 (QP) / 131 (QCQP) instructions for 4 coordinates per lane (round 5: 91 / 139; an
+  * the steady-state ADMM loop is 79 (QP) / 130 (QCQP) instructions for 4 coordinates per lane (round 5: 91 / 139; an
     instruction of that loop costs the kernel ~0.085 us whether it is scalar or vector, tools/ab_salu_probe_diag.sh).
 A compiler or ROCm bump, or an edit that lengthens a live range, then fails HERE instead of silently costing 20 %.
 
@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 # kernel (mangled-name fragment) -> (VGPR limit, steady-state loop instructions today, None = no loop check)
-FWD = {"fwd_diag_kernelILi0ELi8ELi2ELi4ELb1E": (128, 80), "fwd_diag_kernelILi1ELi8ELi2ELi4ELb1E": (128, 131)}
+FWD = {"fwd_diag_kernelILi0ELi8ELi2ELi4ELb1E": (128, 79), "fwd_diag_kernelILi1ELi8ELi2ELi4ELb1E": (128, 130)}
 BWD = {"bwd_diag_kernelILi0ELi8ELi4ELb0E": (128, None), "bwd_diag_kernelILi1ELi8ELi4ELb0E": (128, None)}
 SLACK = 1.05
 
