@@ -440,8 +440,12 @@ def measure(cfg, args, ctx, light=False):
     # inputs or outputs in the 256 MiB Infinity Cache: every chain gets enough distinct input / output sets for > 768 MiB
     # in total and step k works on set k mod nsets.  (A workload whose single set is already that large needs no second
     # one.)  --hot-only: one set, the same buffers every step (the cache-resident figure, reported as `hot_*` otherwise)
+    # Enough sets that even ONE launch repeated back to back (the per-launch runs below) wraps around more than 768 MiB of its
+    # own buffers: the smallest launch of a step touches about P + three vectors of one family (38 MB at B = 65536, N = 8:
+    # 21 sets; rotating over 5 sets, 168 MB of P, the forward runs found their matrices in the cache: 24.2 against 26.5 us).
     per_set = sum(c.bytes_per_set() for c in chains)
-    nsets = 1 if (args.hot_only or per_set >= 768 * 2**20) else max(3, int(np.ceil(768 * 2**20 / per_set)))
+    per_launch = min(c.B * (c.N * c.N + 3 * c.N) * 8 for c in chains)
+    nsets = 1 if (args.hot_only or per_launch >= 768 * 2**20) else min(32, max(3, int(np.ceil(768 * 2**20 / per_launch))))
     for c in chains:
         c.add_sets(nsets - 1)
     main_stream = torch.cuda.current_stream()
@@ -656,7 +660,7 @@ def measure(cfg, args, ctx, light=False):
                                   "note": "all launches of a step on one stream"}
     # ---- hot variant: the same step on ONE set, step after step (everything a step touches fits the Infinity Cache when the
     # set is < 256 MiB) -- context, never `value`
-    if nsets > 1 and not light and not args.no_hot:
+    if nsets > 1 and (not light or cfg == 8) and not args.no_hot:   # (qp_pair: north_star's sentence, cold AND hot in the line)
         for _ in range(3):
             hot_step()
         drain()
@@ -751,10 +755,10 @@ def measure(cfg, args, ctx, light=False):
         roofline["single_stream_ms_per_step"] = extra["single_stream"]["ms_per_step"]
     # `value` is the rotating-buffer ("cold") step whenever the workload's buffers would otherwise fit the cache
     roofline["cold_ms_per_step"], roofline["cold_value"] = (elapsed / steps * 1e3, units_per_step_all * steps / elapsed) \
-        if (nsets > 1 or per_set >= 768 * 2**20) else (None, None)
+        if (nsets > 1 or per_launch >= 768 * 2**20) else (None, None)
     if "hot" in extra:
         roofline["hot_ms_per_step"], roofline["hot_value"] = extra["hot"]["ms_per_step"], extra["hot"]["value"]
-    elif nsets == 1 and per_set < 768 * 2**20:
+    elif nsets == 1 and per_launch < 768 * 2**20:
         roofline["hot_ms_per_step"], roofline["hot_value"] = elapsed / steps * 1e3, units_per_step_all * steps / elapsed
 
     if rank != 0:
@@ -776,7 +780,7 @@ def measure(cfg, args, ctx, light=False):
             "B_this_rank": [c.B for c in chains], "N": [c.N for c in chains],
             "buffers": ("step k works on input/output set k mod %d (%.0f MB per set): no step finds its data in the 256 MiB "
                         "Infinity Cache" % (nsets, per_set / 1e6)) if nsets > 1 else
-                       ("one set of %.0f MB" % (per_set / 1e6) + (" (larger than the cache)" if per_set >= 768 * 2**20 else
+                       ("one set of %.0f MB" % (per_set / 1e6) + (" (larger than the cache)" if per_launch >= 768 * 2**20 else
                                                                    ", the same buffers every step (cache-resident)")),
             "p_layout": ("dense (declared)" if chains[0].layout == 1 else
                          "auto + DQQ_F_EXPECT_DENSE given by the caller (verified in-kernel all the same)" if chains[0].layout == 0x200 else
@@ -807,14 +811,15 @@ def measure(cfg, args, ctx, light=False):
             n = max(n // 4, 256)
         for c in chains:
             c.cpu_solves_per_s(min(n, 512), cores)   # spin up the OpenMP team
-        rates = [max(c.cpu_solves_per_s(n, cores) for _ in range(2)) for c in chains]
+        passes = 2 if light else 5   # (the box's host cores are shared: single passes of ~25 ms vary several-fold)
+        rates = [max(c.cpu_solves_per_s(n, cores) for _ in range(passes)) for c in chains]
         tot = sum(n for _ in chains) / sum(n / r for r in rates)
         n1 = max(n // 64, 64)
         one = sum(n1 for _ in chains) / sum(n1 / c.cpu_solves_per_s(n1, 1) for c in chains)
         out["cpu_baseline"] = {
             "value": tot, "unit": "solves/s", "cores": cores, "kind": "port",
-            "sample": "oracle/diffqcqp_oracle.c (dense C port of the reference algorithm, OpenMP over the batch), best of "
-                      "2 passes over the first %d problems of each family of this workload" % n,
+            "sample": "oracle/diffqcqp_oracle.c, OpenMP over the batch, best of %d passes over the first %d problems of each family; "
+                      "a dense C port of the reference algorithm" % (passes, n),
             "single_thread_value": one, "single_thread_sample": "same, 1 thread, first %d problems" % n1}
         if not light:
             out["cpu_baseline"].update(python_loop_baseline(chains))
@@ -1022,7 +1027,7 @@ CONFIG_KEYS = [        # `config`: workload + at most 20 scalars
 ROOFLINE_KEYS = [      # `roofline`: at most 24 scalars
     "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_over_algorithmic",
     "moved_frac", "valu_busy_frac", "cold_ms_per_step", "cold_value", "hot_ms_per_step", "hot_value",
-    "qp_pair_ms_per_step", "qp_pair_solves_per_s", "qp_pair_moved_frac", "qp_pair_algorithmic_frac",
+    "qp_pair_ms_per_step", "qp_pair_solves_per_s", "qp_pair_moved_frac", "qp_pair_hot_ms_per_step",
     "qp_pair_large_ms_per_step", "qp_pair_large_solves_per_s", "qp_pair_large_moved_frac", "step_moved_frac", "kernel_us"]
 CPU_KEYS = ["value", "unit", "cores", "kind", "sample", "single_thread_value", "python_loop_value"]
 TOP_KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -1208,6 +1213,9 @@ def main():
                 rlk[name + "_moved_frac"] = c["roofline"]["step_moved_frac"]
                 if name == "qp_pair":
                     rlk[name + "_algorithmic_frac"] = c["roofline"]["step_algorithmic_frac"]
+                    if "hot" in rec:
+                        rlk[name + "_hot_ms_per_step"] = rec["hot"]["ms_per_step"]
+                        c["hot"] = rec["hot"]
                 c["bytes_per_pair"] = {"moved": moved_bytes("qp", 8, "fwd", True) + moved_bytes("qp", 8, "bwd", True),
                                        "algorithmic": algo_bytes("qp", 8, "fwd") + algo_bytes("qp", 8, "bwd")}
             out["qp_pair"], out["qp_pair_large"] = pairs["qp_pair"], pairs["qp_pair_large"]

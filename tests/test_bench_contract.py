@@ -99,7 +99,7 @@ def test_contract_line_is_one_short_strict_json_line():
     # the verdict's named scalars are inside the kept ones
     d = _strict(b.contract_line(_canned_full(b)))
     for k in ("cold_ms_per_step", "cold_value", "hot_ms_per_step", "hot_value", "qp_pair_moved_frac", "qp_pair_large_moved_frac",
-              "qp_pair_solves_per_s", "traffic_over_algorithmic", "valu_busy_frac", "kernel_us"):
+              "qp_pair_solves_per_s", "qp_pair_hot_ms_per_step", "traffic_over_algorithmic", "valu_busy_frac", "kernel_us"):
         assert k in d["roofline"], k
     for k in ("cfg2_ms_per_step", "cfg3_ms_per_step", "cfg4_ms_per_step", "cfg4_moved_frac", "cfg5_ms_per_step",
               "dense8_auto_no_hint_ms_per_step", "dense8_dense_ms_per_step", "ref_figure_qp_fwd_ms", "qcqp_grad_exit_flip_rate"):

@@ -138,7 +138,7 @@ def test_default_line_answers_the_north_star_sentence():
     d, full = _run(hot_only=False)
     rl, cf = d["roofline"], d["config"]
     for k in ("frac", "traffic", "traffic_source", "qp_pair_ms_per_step", "qp_pair_solves_per_s", "qp_pair_moved_frac",
-              "qp_pair_algorithmic_frac", "qp_pair_large_ms_per_step", "qp_pair_large_moved_frac", "moved_frac",
+              "qp_pair_hot_ms_per_step", "qp_pair_large_ms_per_step", "qp_pair_large_moved_frac", "moved_frac",
               "step_moved_frac", "kernel_us", "cold_ms_per_step", "cold_value", "hot_ms_per_step", "hot_value"):
         assert k in rl, (k, list(rl))
     for k in ("cfg2_ms_per_step", "cfg2_moved_frac", "cfg3_ms_per_step", "cfg3_moved_frac", "cfg4_ms_per_step",
@@ -150,7 +150,8 @@ def test_default_line_answers_the_north_star_sentence():
     assert rl["qp_pair_solves_per_s"] > 1e8 and rl["qp_pair_large_solves_per_s"] > 1e8
     assert abs(rl["qp_pair_solves_per_s"] - 65536 / (rl["qp_pair_ms_per_step"] * 1e-3)) < 1e-4 * rl["qp_pair_solves_per_s"]
     assert abs(rl["qp_pair_moved_frac"] - 1538 * 65536 / (rl["qp_pair_ms_per_step"] * 1e-3) / 8e12) < 1e-4
-    assert abs(rl["qp_pair_algorithmic_frac"] / rl["qp_pair_moved_frac"] - 1920 / 1538) < 1e-4
+    assert abs(full["roofline"]["qp_pair_algorithmic_frac"] / full["roofline"]["qp_pair_moved_frac"] - 1920 / 1538) < 1e-9
+    assert 0 < rl["qp_pair_hot_ms_per_step"] < 2 * rl["qp_pair_ms_per_step"]
     assert full["qp_pair"]["bytes_per_pair"] == {"moved": 1538, "algorithmic": 1920}
     # physical bound on everything that does not say `algorithmic`
     def walk(m, path=""):
