@@ -53,17 +53,26 @@ STAMP = os.path.join(LIBDIR, "build_flags.txt")
 
 
 def source_sha16():
-    """sha256 (16 hex digits) over what decides the library's contents: csrc/*, include/diffqcqp_hip.h, the flags.  A
+    """sha256 (16 hex digits) over what decides the library's contents: the CODE of csrc/* and include/diffqcqp_hip.h
+    (comments and blank lines stripped) and the flags.  A
     counter summary under profiles/ records it (tools/summarize_prof.py); bench.py quotes counter-derived figures only from
     a summary of THIS build."""
     import hashlib
+    import re
+
+    def code(path):
+        """The file without comments and blank lines: a comment-only edit is the same build."""
+        with open(path, "r", errors="replace") as fh:
+            text = fh.read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        lines = [re.sub(r"//.*$", "", ln).rstrip() for ln in text.split("\n")]
+        return "\n".join(ln for ln in lines if ln.strip()).encode()
+
     h = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)):
         h.update(f.encode())
-        with open(os.path.join(CSRC, f), "rb") as fh:
-            h.update(fh.read())
-    with open(os.path.join(INCLUDE, "diffqcqp_hip.h"), "rb") as fh:
-        h.update(fh.read())
+        h.update(code(os.path.join(CSRC, f)))
+    h.update(code(os.path.join(INCLUDE, "diffqcqp_hip.h")))
     h.update(" ".join(COMMON + [u + " " + " ".join(f) for u, f in sorted(UNITS.items())]).encode())
     return h.hexdigest()[:16]
 
