@@ -114,13 +114,13 @@ DQQ_HD int admm_fwd_diag(const double (&p)[E], const double (&q)[E], const doubl
 // The loop of admm_fwd_diag from iteration it0 on, over state that already exists (admm_fwd_diag_respread's later
 // phases).  Returns through the state; `iters` is the number of iterations executed in total.  lanes_at > 0: the loop is
 // also left -- with more = true on the lanes whose problems still run, and the next iteration in it_next -- once at
-// most that many lanes of the wave are still in it.
+// most that many lanes of the wave are still in it and at least exit_from iterations have been executed.
 template <int KIND, int E, class G>
 DQQ_D void admm_diag_resume(double (&M)[E], double (&Minv)[E], const double (&q)[E], double (&qp)[E], double (&l2)[E],
                             double (&u)[E], const double* rad, double& rho, double& inv_rho, double& tau_inc,
                             double& tau_dec, double& Mmin, int& rho_up, int& cpt, bool& bad, int& iters, int it0,
                             int max_iter, double eps, double mu, int adaptive, bool valid, int lanes_at, bool& more,
-                            int& it_next)
+                            int& it_next, int exit_from = 0)
 {
     constexpr bool QP_LIKE = (KIND != 1);
     static_assert(KIND < 2, "QP / QCQP");
@@ -139,16 +139,12 @@ DQQ_D void admm_diag_resume(double (&M)[E], double (&Minv)[E], const double (&q)
         // hazard slots of the residual reductions, and the reference's figure workload (one problem at 25 000 iterations)
         // reads 4.2-4.6 ms with it against 5.2-5.7 with the lean body (A/B on one box, three alternations, with the interleaved
         // residual reductions in both: profiles/r07_ab_tail_body.txt).
+        // (the last stage: nothing leaves this loop early -- lanes_at is 0 here)
         if (valid) {
             for (int it = it0; it < max_iter; ++it) {
 #define DQQ_ADMM_ON_STOP break
 #include "admm_diag_body.inc"
 #undef DQQ_ADMM_ON_STOP
-                if (lanes_at > 0 && __popcll(__ballot(true)) <= lanes_at) {
-                    more = it + 1 < max_iter;
-                    it_next = it + 1;
-                    break;
-                }
             }
         }
     } else {
@@ -161,7 +157,7 @@ DQQ_D void admm_diag_resume(double (&M)[E], double (&Minv)[E], const double (&q)
 #include "admm_diag_body.inc"
 #undef DQQ_ADMM_ON_STOP
 #undef DQQ_ADMM_LEAN
-                if (lanes_at > 0 && __popcll(__ballot(true)) <= lanes_at) {
+                if (lanes_at > 0 && it + 1 >= exit_from && __popcll(__ballot(true)) <= lanes_at) {
                     more = it + 1 < max_iter;
                     it_next = it + 1;
                     break;
@@ -289,7 +285,7 @@ DQQ_D int admm_fwd_diag_respread(const double (&p)[4], const double (&q)[4], con
         bool more2 = false;
         admm_diag_resume<KIND, E2, G4>(M2, Minv2, q2, qp2, l22, u2, rad2, rho2, inv_rho2, tau_inc2, tau_dec2, Mmin2,
                                        rho_up2, cpt2, bad2, iters2, it0, max_iter, eps, mu, adaptive, valid2,
-                                       4 * respread2_at, more2, it_next2);
+                                       4 * (respread2_at & 0xff), more2, it_next2, respread2_at >> 8);
         const unsigned long long mm2 = __ballot(more2);
         if (!more2) {
             bad2 = G4::max(bad2 ? 1.0 : 0.0) > 0.0;

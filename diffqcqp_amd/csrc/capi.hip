@@ -11,7 +11,7 @@ namespace dqq {
 // developer build: the knobs of tuning.h as process-wide atomics (defined here, declared there)
 #define DQQ_KNOB_DEF(name, dflt) std::atomic<int> g_##name{dflt};
 DQQ_KNOB_DEF(fwd_lpp, 0) DQQ_KNOB_DEF(wpb, 0) DQQ_KNOB_DEF(fuse_fallback, -1)
-DQQ_KNOB_DEF(fwd_respread, 16) DQQ_KNOB_DEF(fwd_respread2, 8) DQQ_KNOB_DEF(lane_dense, 1) DQQ_KNOB_DEF(lane_defer, 0)
+DQQ_KNOB_DEF(fwd_respread, 16) DQQ_KNOB_DEF(fwd_respread2, 8) DQQ_KNOB_DEF(fwd_respread2_from, 48) DQQ_KNOB_DEF(lane_dense, 1) DQQ_KNOB_DEF(lane_defer, 0)
 DQQ_KNOB_DEF(dense_teams, 1) DQQ_KNOB_DEF(small_fwd, 1) DQQ_KNOB_DEF(small_bwd, 1) DQQ_KNOB_DEF(lane_bwd, 1)
 DQQ_KNOB_DEF(fwd_feedback, 1) DQQ_KNOB_DEF(bwd_skip_classify, 1)
 #undef DQQ_KNOB_DEF
@@ -32,7 +32,7 @@ Option g_options[] = {{"lane_list_drains", &dqq::g_lane_list_drains},
 #if defined(DQQ_TUNING)
 #define DQQ_KNOB_OPT(name) {#name, &dqq::g_##name},
                       DQQ_KNOB_OPT(fwd_lpp) DQQ_KNOB_OPT(wpb) DQQ_KNOB_OPT(fuse_fallback)
-                      DQQ_KNOB_OPT(fwd_respread) DQQ_KNOB_OPT(fwd_respread2) DQQ_KNOB_OPT(lane_dense) DQQ_KNOB_OPT(lane_defer)
+                      DQQ_KNOB_OPT(fwd_respread) DQQ_KNOB_OPT(fwd_respread2) DQQ_KNOB_OPT(fwd_respread2_from) DQQ_KNOB_OPT(lane_dense) DQQ_KNOB_OPT(lane_defer)
                       DQQ_KNOB_OPT(dense_teams) DQQ_KNOB_OPT(small_fwd) DQQ_KNOB_OPT(small_bwd) DQQ_KNOB_OPT(lane_bwd)
                       DQQ_KNOB_OPT(fwd_feedback) DQQ_KNOB_OPT(bwd_skip_classify)
 #undef DQQ_KNOB_OPT

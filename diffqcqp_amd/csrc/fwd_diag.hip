@@ -38,6 +38,7 @@ namespace dqq {
 // knob fwd_respread (tuning.h): once at most this many (0..16) of a wave's 32 problems are still iterating, they move onto
 // twice the lanes (admm_core.h admm_fwd_diag_respread; N = 8, two lanes per problem, QP / QCQP).  0 = never.
 // Results do not depend on it (bit-identical, tests/test_gpu_respread.py).
+// knob fwd_respread2_from: ... from this iteration on only (the kernel's `respread2_at` argument carries both: at2 | from << 8).
 // knob fwd_respread2: once at most this many (0..8) of the re-spread problems are still iterating, they move again,
 // onto EIGHT lanes per problem (one coordinate per lane).  0 = never.  Bit-identical results.
 int lane_defer_for(int kind); // fwd_lane_dense.hip: the general routines' deferred refactorisation (option lane_defer)
@@ -301,7 +302,9 @@ static hipError_t launch_one(const FwdArgs& a, hipStream_t s)
     return launch((fwd_diag_kernel<KIND, N, LPP, WPB, FUSE>), dim3((unsigned)nblocks), dim3(64 * WPB), 0, s, a.P, a.q,
                        a.l_n, a.mu, a.v, a.x, a.B, a.eps, a.mu_prox, a.max_iter, a.adaptive, a.layout, a.iters, a.ws,
                        a.pdiag_out, a.flags_out, std::min(16, std::max(0, knob_fwd_respread())),
-                       std::min(8, std::max(0, knob_fwd_respread2())), lane_defer_for(KIND));
+                       // (the second move's threshold and the iteration from which it applies travel in one int: at2 | from << 8)
+                       std::min(8, std::max(0, knob_fwd_respread2())) | (std::min(1 << 20, std::max(0, knob_fwd_respread2_from())) << 8),
+                       lane_defer_for(KIND));
 }
 
 // What the shipped build instantiates is what its routing can reach (tuning.h: the knobs are constants there): four waves

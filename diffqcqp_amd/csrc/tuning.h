@@ -30,6 +30,9 @@ DQQ_KNOB(wpb, 0)                    // waves per workgroup of the diagonal kerne
 DQQ_KNOB(fuse_fallback, -1)         // non-diagonal tiles inside the fast kernel (1), queued (0), by (N, B) (-1)
 DQQ_KNOB(fwd_respread, 16)          // N = 8 forward on two lanes: tail of <= this many problems moves to four lanes
 DQQ_KNOB(fwd_respread2, 8)          // ... and of <= this many to eight lanes
+DQQ_KNOB(fwd_respread2_from, 48)    // ... but not before this iteration: a tile whose problems are done by then (the
+                                    // well-conditioned bench shape: tile maxima 24-38) skips the second move, which costs it
+                                    // more than its last few iterations on four lanes (QP forward 26.0 -> 25.4 us, round 6)
 DQQ_KNOB(lane_dense, 1)             // general forward N <= 8: lane-per-problem kernel
 DQQ_KNOB(lane_defer, 0)             // general forward N <= 16: refactorisation every k trips (0 = 4 QCQP / 6 others)
 DQQ_KNOB(dense_teams, 1)            // general backward: 64/T problems per wave for small N

@@ -20,7 +20,7 @@ def pytest_configure(config):
 # build, from tests/test_gpu_developer_build.py: one `pytest -m gpu` covers both.  The two former knobs that change NUMERICS ("dense_wave64", "wave_qcqp_bwd": the
 # reference-order kernels for 16 < N <= 64) are a per-call flag of the C ABI now (DQQ_F_REFERENCE_ORDER): `knob` keeps a
 # test-side switch for them and `OpsWithFlags` (the `ops` fixture of test_gpu_parity.py) ORs the flag into every call's layout.
-KNOB_DEFAULTS = {"fwd_lpp": 0, "wpb": 0, "fuse_fallback": -1, "fwd_respread": 16, "fwd_respread2": 8,
+KNOB_DEFAULTS = {"fwd_lpp": 0, "wpb": 0, "fuse_fallback": -1, "fwd_respread": 16, "fwd_respread2": 8, "fwd_respread2_from": 48,
                  "lane_dense": 1, "lane_defer": 0, "dense_teams": 1, "small_fwd": 1, "small_bwd": 1, "lane_bwd": 1,
                  "fwd_feedback": 1, "bwd_skip_classify": 1}
 COUNTERS = ("lane_list_drains", "bwd_whole_batches", "fwd_feedback_routes")

@@ -29,16 +29,20 @@ def _run(kind, d, eps, max_iter, _unused=0, layout=0):
         return x.cpu().numpy(), it.cpu().numpy()
 
 
-def _run_respread(kind, d, eps, max_iter, at, lpp=2, at2=0):
+def _run_respread(kind, d, eps, max_iter, at, lpp=2, at2=0, from2=0):
+    """from2: the iteration from which the second move applies ("fwd_respread2_from"; shipped: 48 -- these well-conditioned
+    problems are done by then, so the tests set 0 to drive the eight-lane stage, and 20 / 48 for the gate itself)."""
     from diffqcqp_amd import _capi
     knob("fwd_respread", at)
     knob("fwd_respread2", at2)
+    knob("fwd_respread2_from", from2)
     knob("fwd_lpp", lpp)
     try:
         return _run(kind, d, eps, max_iter, 0)
     finally:
         knob("fwd_respread", 16)  # the defaults
         knob("fwd_respread2", 8)
+        knob("fwd_respread2_from", 48)
         knob("fwd_lpp", 0)
 
 
@@ -64,6 +68,10 @@ def test_respread_bit_identical(kind, B):
             xb, ib = _run_respread(kind, d, eps, max_iter, at, at2=at2)
             assert np.array_equal(ia, ib), (eps, max_iter, at, at2)
             assert np.array_equal(xa, xb, equal_nan=True), (eps, max_iter, at, at2)
+        # ... gated by the iteration count ("fwd_respread2_from": the shipped 48, and a gate that falls inside these solves)
+        for from2 in (20, 48):
+            xb, ib = _run_respread(kind, d, eps, max_iter, 16, at2=8, from2=from2)
+            assert np.array_equal(ia, ib) and np.array_equal(xa, xb, equal_nan=True), (eps, max_iter, from2)
     assert np.isnan(xa[3::41]).all() and np.isfinite(np.delete(xa, np.s_[3::41], axis=0)).all()
 
 

@@ -46,7 +46,7 @@ for t in range(trials):
             "lane_dense": int(rng.choice([0, 1])), "small_fwd": int(rng.choice([0, 1])), "fuse_fallback": int(rng.choice([-1, 0, 1])),
             "fwd_compact": int(rng.choice([0, 1])), "wpb": int(rng.choice([0, 1, 4])),
             "lane_defer": int(rng.choice([0, 1, 3, 7])), "fwd_respread": int(rng.choice([0, 5, 16])),
-            "fwd_respread2": int(rng.choice([0, 3, 8]))}
+            "fwd_respread2": int(rng.choice([0, 3, 8])), "fwd_respread2_from": int(rng.choice([0, 0, 12, 48]))}
     d = make_problem(kind, B, N, 9000 + t, "dense" if structure == "nonsym" else structure)
     if structure == "nonsym":
         g = torch.Generator().manual_seed(t)
@@ -77,5 +77,5 @@ for t in range(trials):
         bad += 1
         print("FAIL", t, kind, N, B, structure, layout, eps, max_iter, opts, "err %.2e iters equal %.4f" % (err, same), flush=True)
 apply_opts({"fwd_lpp": 0, "fuse_fallback": -1, "fwd_compact": 0, "wpb": 0, "dense_wave64": 1, "lane_dense": 1,
-            "small_fwd": 1, "lane_defer": 0, "fwd_respread": 16, "fwd_respread2": 8})
+            "small_fwd": 1, "lane_defer": 0, "fwd_respread": 16, "fwd_respread2": 8, "fwd_respread2_from": 48})
 print("%d trials, %d failures, worst |dx| %.2e" % (trials, bad, worst))
