@@ -1452,7 +1452,7 @@ def test_full_size_config5_dense_n64(oracle, ops):
     xo, ito = oracle_fwd(oracle, "qp", d)
     # the matrix-core kernel re-associates the sums of the inverse (block Gauss-Jordan instead of LLT + substitutions):
     # x within 1e-6 everywhere, the iteration count equal to the oracle's on >= 99 % of the sample (measured: 1024 of 1024 equal,
-    # max |dx| 1.3e-14: profiles/r07b_cfg5_match.txt) and never more than 2 apart
+    # max |dx| 1.3e-14: profiles/r07d_cfg5_match.txt) and never more than 2 apart
     check_forward(x[idx], it[idx], xo, ito, min_match=0.99)
     assert np.abs(npy(it[idx]).astype(np.int64) - ito).max() <= 2
     gs, sts = hip_bwd(ops, "qp", dev(d), torch.from_numpy(xo).cuda())

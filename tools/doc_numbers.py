@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The measured numbers of DESIGN.md section 5 and of README.md's first screen, generated from ONE full bench record
 (profiles/<tag>_bench_details.json, written by `python bench.py --gpus 1 --steps 20 --warmup 5`) so that no figure is
-transcribed by hand:    python tools/doc_numbers.py profiles/r07c_bench_details.json [--write]
+transcribed by hand:    python tools/doc_numbers.py profiles/<tag>_bench_details.json [--write]
 --write replaces the text between the markers <!-- measured:begin --> / <!-- measured:end --> and
 <!-- result:begin --> / <!-- result:end --> (README.md)."""
 import json
@@ -77,7 +77,8 @@ def main():
         "`Solver.cpp:32-41`) matches the oracle's; on the other %.1f %% they are the reference's formula at the other exit (~3e-4 apart) |"
         % (100 * (1 - flip), 100 * flip),
         "| **the reference's own figure workload** (`P = diag(exp(U(−10,10)))`, eps 1e-10) | %.1f ms per 65 536 QP forwards, bound by ONE problem that "
-        "takes %d iterations (a lone wave: ≈ 0.18 µs per iteration) |" % (fig["qp_fwd_ms"], fig["qp_iterations"]["max"]),
+        "takes %d iterations (a lone wave: ≈ %.2f µs per iteration; 4.2–5.2 ms from run to run) |"
+        % (fig["qp_fwd_ms"], fig["qp_iterations"]["max"], fig["qp_fwd_ms"] * 1e3 / fig["qp_iterations"]["max"]),
     ])
     print(head + table)
     print()
