@@ -13,7 +13,8 @@ Workloads (`--config k` = k-th entry of BASELINE.json `configs`, 1-based as in B
   default   the headline: per GPU and step, QP forward+backward [configs[1] + its backward] AND QCQP
             forward+backward [configs[2]] on B=65536, N=8, diagonal P in the (B,8,8) layout = 2*B solves.  The two
             families are independent problems on DISTINCT inputs; their launch chains go to two HIP streams
-            (--streams 1: one stream).  Weak scaling.
+            (--streams 1: one stream) and swap streams every step (steps work on distinct buffer sets, so both streams
+            carry the same work; --alternate-streams 0: fixed assignment).  Weak scaling.
   2         B=65536 N=8 diagonal-P QP, forward only                                   (one launch per step)
   3         B=65536 N=8 QCQP forward+backward
   4         B=262144 N=32 QP forward+backward, the batch SPLIT over the ranks (strong scaling); `value` includes the
@@ -446,6 +447,8 @@ def measure(cfg, args, ctx, light=False):
     per_set = sum(c.bytes_per_set() for c in chains)
     per_launch = min(c.B * (c.N * c.N + 3 * c.N) * 8 for c in chains)
     nsets = 1 if (args.hot_only or per_launch >= 768 * 2**20) else min(32, max(3, int(np.ceil(768 * 2**20 / per_launch))))
+    if nsets > 1 and nsets % 2:
+        nsets += 1          # (even: with the families swapping streams every step a set keeps its stream)
     for c in chains:
         c.add_sets(nsets - 1)
     main_stream = torch.cuda.current_stream()
@@ -460,6 +463,7 @@ def measure(cfg, args, ctx, light=False):
             x_all[i] = torch.empty((B_gather, c.N, 1), dtype=F64, device=dev)
             gather_scratch[i] = torch.empty((rows, c.N, 1), dtype=F64, device=dev) if rows else None
 
+    alternate = bool(args.alternate_streams)
     ctr = [0]          # steps issued so far: step k works on set k mod nsets
     last_set = [0]
 
@@ -472,10 +476,16 @@ def measure(cfg, args, ctx, light=False):
     def step_on(s):
         """One pass of the hot path over this rank's batch (all chains; set s of each)."""
         if side is not None:  # interleave so that both streams are fed; the longer chain (the QCQP) first
-            chains[1].launch(0, streams[1], s)
-            chains[0].launch(0, streams[0], s)
-            chains[1].launch(1, streams[1], s)
-            chains[0].launch(1, streams[0], s)
+            # The chains are unequal (QCQP ~46 us of kernels, QP ~37): with a fixed family -> stream assignment the QP stream
+            # runs ahead and the region ends with the QCQP chain alone on the chip.  Steps on DISTINCT buffer sets are
+            # independent, so the families swap streams every step and both streams carry the same work: 60.3 -> 58.0 us per step
+            # (three alternations on one box).  A set's parity fixes its stream (nsets even), so the re-use of a set's buffers is
+            # stream-ordered.  --alternate-streams 0, or one set of buffers (--hot-only, the hot_* context): fixed assignment
+            a, b = (1, 0) if (alternate and nsets > 1 and (s & 1)) else (0, 1)
+            chains[1].launch(0, streams[b], s)
+            chains[0].launch(0, streams[a], s)
+            chains[1].launch(1, streams[b], s)
+            chains[0].launch(1, streams[a], s)
         else:
             for c in chains:
                 c.run(sh, s)
@@ -785,7 +795,8 @@ def measure(cfg, args, ctx, light=False):
             "p_layout": ("dense (declared)" if chains[0].layout == 1 else
                          "auto + DQQ_F_EXPECT_DENSE given by the caller (verified in-kernel all the same)" if chains[0].layout == 0x200 else
                          "auto (off-diagonals verified in-kernel; non-diagonal tiles go to the general kernel)"),
-            "launch": "eager, one C-ABI call per pass" + (", the two families on two streams" if side is not None else ""),
+            "launch": "eager, one C-ABI call per pass" + ((", the two families on two streams" + (
+                ", swapping streams every step" if (alternate and nsets > 1) else "")) if side is not None else ""),
             "sharding": (("batch split over the ranks" if scaling == "strong" else "every rank its own batch (weak scaling)") +
                          ", no data-path collective; RCCL all-gather of x per step, issued after the forward and overlapped with the backward"
                          if (gather and use_dist) else ("every rank its own batch (weak scaling), no data-path collective; the optional "
@@ -1119,6 +1130,9 @@ def main():
     ap.add_argument("--repeats", type=int, default=10, help="timed regions of exactly --steps steps; the median is reported")
     ap.add_argument("--streams", type=int, default=2, choices=(1, 2),
                     help="headline only: 2 = the QP chain and the QCQP chain on two HIP streams")
+    ap.add_argument("--alternate-streams", type=int, default=1, choices=(0, 1),
+                    help="headline on two streams with rotating buffers: the two families swap streams every step, so that both "
+                         "streams carry the same work (0: a fixed family -> stream assignment)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--hot-only", "--no-cold", dest="hot_only", action="store_true",
