@@ -63,9 +63,10 @@ def main():
     ]
     table = "| workload | ms / step | solves/s | fraction of 8 TB/s on bytes that move | notes |\n|---|---|---|---|---|\n"
     table += "\n".join("| " + " | ".join(r) + " |" for r in rows)
+    ptag = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get("_tag", tag)
     head = ("One run of the driver's command on the final tree (`profiles/%s_bench_line.json` = the 2.3 KB contract line, `%s_bench_details.json` = "
             "the full record; rocprofv3 summaries `profiles/%s_*kernel_stats.csv`, `%s_pmc.json`, `pmc_latest*.json`; generated by "
-            "`tools/doc_numbers.py`). Boxes of the pool differ by a few per cent.\n\n" % (tag, tag, tag, tag))
+            "`tools/doc_numbers.py`). Boxes of the pool differ by a few per cent.\n\n" % (tag, tag, ptag, ptag))
     result = "\n".join([
         "| | |", "|---|---|",
         "| **N = 8 QP forward+backward, B = 65536** (`qp_pair`, one stream) | %s solves/s on fresh buffers every step (%.4f ms; %.4f ms cache-resident); "
