@@ -127,7 +127,8 @@ int dqq_max_n(int kind, int p_layout);
 
 /* Replaces the loop qcqp.py:29-31 (QPFn2.forward -> diffqcqp.solveQP,
  * pybindings.cpp:17-22 -> Solver::solveQP, Solver.cpp:61-123).
- * iters (B ints, ADMM iterations executed per problem) may be NULL.
+ * iters (B ints, ADMM iterations executed per problem; -1 for a problem that could not be queued for the general kernel --
+ * work-list hygiene above -- whose x is NaN) may be NULL.
  * pdiag_out (B,N doubles) / diag_flags_out (B bytes), both optional and DQQ_P_AUTO only: the forward leaves
  * the diagonal of every problem it verified to be diagonal (flag 1; flag 2: the problem sat in a tile with
  * non-zero off-diagonals; flag 0: not examined) for the backward of the SAME P, which then does not read P again
