@@ -122,3 +122,24 @@ def test_group_solve_deferred_refactorisation_is_bit_identical(ops, fused, kind,
                     assert torch.equal(torch.nan_to_num(x1, nan=12345.0), torch.nan_to_num(xd, nan=12345.0))
     finally:
         knob("lane_defer", 0)
+
+
+@pytest.mark.parametrize("kind", ["qp", "qcqp"])
+def test_declared_dense_n8_is_the_same_solve_on_either_side_of_the_batch_size_rule(ops, kind):
+    """ADVICE r5.  Which kernel serves a DQQ_P_DENSE N = 8 batch is a function of B (B <= 32768: the group solve inside
+    fwd_diag_kernel, four lanes per problem; above: fwd_lane_dense_kernel, a lane per problem) -- two kernels, one algorithm and
+    ONE projection rule (|l|^2 > r |r| on the fused squares in both).  The same problems through both: iteration counts equal
+    on >= 99.9 %, x within 1e-9 where they are (the x-updates differ in operation order -- explicit inverse in registers
+    against factor + substitutions -- so bits may differ; the branch a projection takes at the cone must not)."""
+    from diffqcqp_amd import _capi
+    small, big = 32768, 40000
+    d = make_problem(kind, big, 8, 5900, "dense")
+    g = dev(d)
+    head = {k: v[:small].contiguous() for k, v in g.items()}
+    xa, ia = hip_fwd(ops, kind, head, layout=_capi.P_DENSE)      # group solve
+    xb, ib = hip_fwd(ops, kind, g, layout=_capi.P_DENSE)         # lane per problem
+    ia, ib = npy(ia), npy(ib)[:small]
+    same = ia == ib
+    assert same.mean() >= 0.999, same.mean()
+    assert np.abs(npy(xa) - npy(xb)[:small])[same].max() < 1e-9
+    assert np.abs(ia.astype(int) - ib.astype(int)).max() <= 2
